@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- GB/s scanned by the MI355X relative-search engine.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1], "C2"): 8-bit relative search, 12-character
+keyword, engine semantics with the reference's default 512 KiB blocks, on a
+synthetic ROM already resident in HBM.  One step = one full scan of the ROM:
+filter kernel + resolver + ordering + D2H of the offsets (+ the RCCL gather of
+the per-GPU offset lists at N > 1).  Weak scaling: every GPU holds its own
+4 GiB partition (block-aligned, pattern-length overlap) of an N x 4 GiB ROM.
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel
+(mm_filter_u8) with HIP events recorded on the scan's own stream;
+`cpu_baseline` times the reference's multi-threaded SearchEngine<uint8_t>::run
+(oracle/_ref, built from the unmodified reference sources) on a bounded sample
+of the same ROM on the host cores -- a reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+KEYWORD = "relativesrch"
+BLOCK = 524288
+SEED = 42
+PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak 8 TB/s (measured achievable ~6.3)
+
+
+def cpu_baseline(eng, spec_bytes, plan_kw, sample_bytes):
+    """Reference CPU engine on the first sample_bytes of the same ROM (rank 0, N = 1)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _oracle import Oracle, Ref
+    sample_bytes = min(sample_bytes, spec_bytes)
+    rom = eng.download(0, sample_bytes)
+    cores = os.cpu_count() or 1
+    if Ref.available():
+        ref = Ref()
+        tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
+        path = os.path.join(tmpdir, "mm_cpu_baseline_%d.bin" % os.getpid())
+        try:
+            rom.tofile(path)
+            best, offs = None, None
+            for _ in range(2):
+                t0 = time.perf_counter()
+                offs = ref.engine(1, None, plan_kw, ord("*"), None, threads=cores, block_size=BLOCK, path=path)
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+        finally:
+            if os.path.exists(path):
+                os.unlink(path)
+        return dict(value=sample_bytes / best / 1e9, unit="GB/s", cores=cores, kind="reference",
+                    sample="first %d MiB of the bench ROM in a tmpfs file, SearchEngine<uint8_t>::run, %d threads, "
+                           "512 KiB blocks, best of 2" % (sample_bytes >> 20, cores)), offs, sample_bytes
+    orc = Oracle()
+    t0 = time.perf_counter()
+    offs = orc.engine(orc.plan(1, plan_kw), rom, BLOCK)
+    dt = time.perf_counter() - t0
+    return dict(value=sample_bytes / dt / 1e9, unit="GB/s", cores=1, kind="port",
+                sample="first %d MiB of the bench ROM, scalar C restatement" % (sample_bytes >> 20)), offs, sample_bytes
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--gib-per-gpu", type=float, default=4.0)
+    ap.add_argument("--cpu-sample-mib", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from __graft_entry__ import load_package
+    mm = load_package()
+    if not os.path.exists(mm.LIB_PATH):
+        mm.build.build_all()
+
+    per_gpu = int(args.gib_per_gpu * (1 << 30)) // BLOCK * BLOCK
+    total = per_gpu * world
+    L = len(KEYWORD)
+    base = rank * per_gpu
+    shard = min(per_gpu + (L - 1), total - base)          # pattern-length overlap into the next partition
+
+    # HBM-resident shard owned by torch; the engine borrows the pointer and runs on torch's stream
+    buf = torch.empty(shard + 32, dtype=torch.uint8, device=dev)
+    eng = mm.Engine(local_rank)
+    eng.attach(buf.data_ptr(), shard)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    spec = mm.synth.RomSpec(SEED, total, KEYWORD, 1, None, False, BLOCK, base=base, nbytes=shard, partitions=8)
+    spec.apply_device(eng)
+    torch.cuda.synchronize()
+    plan = mm.plan_relative(1, KEYWORD)
+
+    def step():
+        offs = eng.scan(plan, block_bytes=BLOCK, base_offset=base)
+        if world == 1:
+            return offs
+        # RCCL gather of the per-GPU offset lists (already ascending, partitions in rank order)
+        n = torch.tensor([len(offs)], dtype=torch.int64, device=dev)
+        counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(counts, n)
+        counts = [int(c.item()) for c in counts]
+        mx = max(max(counts), 1)
+        mine = torch.zeros(mx, dtype=torch.int64, device=dev)
+        mine[: len(offs)] = torch.from_numpy(offs.astype(np.int64)).to(dev)
+        gathered = [torch.empty(mx, dtype=torch.int64, device=dev) for _ in range(world)] if rank == 0 else None
+        dist.gather(mine, gathered, dst=0)
+        if rank == 0:
+            return torch.cat([g[:c] for g, c in zip(gathered, counts)]).cpu().numpy().astype(np.uint64)
+        return offs
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    filt_ms, tot_ms = [], []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        offs = step()
+        t = eng.timings()
+        filt_ms.append(t["filter_ms"])
+        tot_ms.append(t["total_ms"])
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        ctr = eng.counters()
+        assert (np.diff(offs.astype(np.int64)) > 0).all(), "gathered offsets are not ascending"
+        filt = float(np.mean(filt_ms))
+        achieved = shard / (filt * 1e-3) / 1e9
+        res = {
+            "metric": "GB/s scanned (4 GiB synthetic ROM per GPU, 12-char 8-bit relative pattern)",
+            "value": total * args.steps / elapsed / 1e9,
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {
+                "workload": "C2: 8-bit relative search, keyword '%s' (L=12), engine semantics, 512 KiB blocks, "
+                            "%.1f GiB splitmix64 ROM per GPU resident in HBM, 1 planted match/MiB + boundary straddlers "
+                            "+ 0x00/0xFF/ramp runs" % (KEYWORD, per_gpu / (1 << 30)),
+                "rom_bytes_total": total,
+                "matches": int(len(offs)),
+                "candidates_rank0": ctr["candidates"],
+                "parallelism": "%d partition(s) on block boundaries, RCCL offset gather" % world,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "mm_filter_u8<2>",
+                "achieved": achieved,
+                "peak": PEAK_HBM_GBS,
+                "unit": "GB/s",
+                "frac": achieved / PEAK_HBM_GBS,
+                "traffic": None,
+                "kernel_ms": filt,
+                "scan_device_ms": float(np.mean(tot_ms)),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, cpu_offs, nsample = cpu_baseline(eng, shard, KEYWORD, args.cpu_sample_mib << 20)
+            res["cpu_baseline"] = cb
+            # parity of the timed configuration on the sample (blocks fully inside it)
+            lim = (nsample // BLOCK - 1) * BLOCK
+            g = offs[offs < lim].tolist()
+            c = [int(x) for x in cpu_offs if x < lim]
+            res["config"]["parity_vs_cpu_sample"] = bool(g == c)
+            assert g == c, "GPU offsets differ from the reference CPU engine on the sample"
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,134 @@
+/*
+ * mmoore_hip.h -- C ABI of the MI355X relative-search engine (libmmoore_hip.so).
+ *
+ * This is the drop-in boundary: plain C, pointers and sizes only, no C++ or
+ * torch types.  The C++17 facade in include/mmoore/ (MonkeyMoore<T>::search,
+ * SearchEngine<T>::run) is a thin caller of these entry points; any other host
+ * language binds the same symbols.
+ *
+ * Reference interfaces replaced (paths under the reference repository):
+ *   mmh_plan_relative / mmh_plan_value_scan
+ *        MonkeyMoore<Ty>::MonkeyMoore(...)           include/mmoore/monkey_moore.hpp:30-42
+ *        (initialize/preprocess*)                    src/core/monkey_moore.cpp:54-304
+ *   mmh_scan with block_bytes == 0
+ *        MonkeyMoore<Ty>::search(data, len)          include/mmoore/monkey_moore.hpp:51
+ *                                                    src/core/monkey_moore.cpp:316-410, 425-546
+ *   mmh_scan with block_bytes > 0
+ *        the per-block worker + merge of
+ *        SearchEngine<T>::run                        src/core/search_engine.cpp:107-168, 193-197, 218-253
+ *        (block offsets are 64 bit here; the reference multiplies in 32 bit, :241-242)
+ *
+ * All functions return 0 on success, a negative MMH_E_* code on failure and
+ * never throw; mmh_last_error() describes the last failure on the calling
+ * thread.  There is NO CPU fallback: without a usable HIP device every device
+ * entry point fails with MMH_E_DEVICE.
+ */
+#ifndef MMOORE_HIP_H
+#define MMOORE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMH_MAX_KEYWORD 32      /* longest keyword the GPU plan holds */
+
+enum {
+   MMH_OK = 0,
+   MMH_E_ARG = -1,              /* bad argument */
+   MMH_E_PLAN = -2,             /* keyword the reference rejects or cannot terminate on */
+   MMH_E_DEVICE = -3,           /* HIP error / no device */
+   MMH_E_CAPACITY = -4,         /* out buffer too small; *out_count holds the need */
+   MMH_E_STATE = -5             /* no ROM attached, etc. */
+};
+
+enum { MMH_MODE_SIMPLE = 1, MMH_MODE_WILDCARD = 2, MMH_MODE_VALUE_SCAN = 3 };
+
+/* Flattened pattern plan (POD).  One compare per keyword position i, visited
+ * from i = L-1 down to 0 exactly like the reference loops:
+ *    d = (int)x[h+i] - (int)x[h+i+bridge[i]];   mismatch iff ((d ^ expected[i]) & cmp_mask[i]) != 0
+ * cmp_mask is 0xFFFFFFFF on the simple / value-scan path (signed, un-wrapped
+ * compare, monkey_moore.cpp:336-345), the element mask on literal positions of
+ * the wildcard path (modular compare, :457-470) and 0 on wildcard positions.
+ * A mismatch at i jumps min(wst[i], max(skip(d), 1)); a match jumps match_jump. */
+typedef struct mmh_plan_desc {
+   uint32_t elem_bytes;                 /* 1 or 2 */
+   uint32_t mode;                       /* MMH_MODE_* */
+   uint32_t L;                          /* keyword length, 2..MMH_MAX_KEYWORD */
+   uint32_t match_jump;                 /* L-1 (:398) or L-1-leading wildcards (:526) */
+   uint32_t lead_wildcards;
+   uint32_t first_literal;              /* first non-wildcard position (:444-447) */
+   int32_t  default_skip;               /* skip for diffs not listed below */
+   uint32_t n_skip;                     /* number of listed diffs */
+   int32_t  expected[MMH_MAX_KEYWORD];  /* expected_diff */
+   uint32_t cmp_mask[MMH_MAX_KEYWORD];
+   int32_t  skip_diff[MMH_MAX_KEYWORD]; /* sparse bad-character table: diff -> raw skip value */
+   int32_t  skip_val[MMH_MAX_KEYWORD];
+   int8_t   bridge[MMH_MAX_KEYWORD];    /* wc_bridge_offset; -1 / L-1 on the simple path */
+   uint8_t  wst[MMH_MAX_KEYWORD];       /* wildcard_skip_table; 255 = no cap */
+} mmh_plan_desc;
+
+typedef struct mmh_ctx mmh_ctx;
+
+const char *mmh_last_error(void);
+
+/* ---- pattern plan (host only, no device needed) ------------------------- */
+
+/* keyword / char_seq: UTF-32 code points.  wildcard 0 = the MonkeyMoore default. */
+int mmh_plan_relative(uint32_t elem_bytes, const uint32_t *keyword, uint32_t keyword_len,
+                      uint32_t wildcard, const uint32_t *char_seq, uint32_t char_seq_len,
+                      mmh_plan_desc *out);
+int mmh_plan_value_scan(uint32_t elem_bytes, const int16_t *values, uint32_t n, mmh_plan_desc *out);
+
+/* ---- device context ------------------------------------------------------ */
+
+int mmh_device_count(int *count);
+int mmh_create(int device, mmh_ctx **out);
+void mmh_destroy(mmh_ctx *ctx);
+
+/* Launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the
+ * context's own stream. */
+int mmh_set_stream(mmh_ctx *ctx, void *hip_stream);
+
+/* ROM: either copied from host memory into a library-owned device buffer, or a
+ * borrowed device pointer (16-byte aligned, stays valid until detached). */
+int mmh_rom_upload(mmh_ctx *ctx, const void *host, uint64_t nbytes);
+int mmh_rom_attach(mmh_ctx *ctx, const void *device_ptr, uint64_t nbytes);
+int mmh_rom_download(mmh_ctx *ctx, uint64_t first_byte, void *host, uint64_t nbytes);
+
+/* Synthetic ROM (bench/tests): fill the attached/owned ROM [first_byte, +nbytes)
+ * with splitmix64 words indexed by (rom_base_offset + byte) / 8, on the device. */
+int mmh_rom_alloc(mmh_ctx *ctx, uint64_t nbytes);
+int mmh_rom_synth(mmh_ctx *ctx, uint64_t seed, uint64_t rom_base_offset);
+int mmh_rom_poke(mmh_ctx *ctx, uint64_t first_byte, const void *host, uint64_t nbytes);
+int mmh_rom_fill(mmh_ctx *ctx, uint64_t first_byte, uint64_t nbytes, int value, int ramp);
+
+/* ---- the scan -------------------------------------------------------------
+ * block_bytes == 0 : one chain over the whole ROM viewed as elements of
+ *                    plan->elem_bytes in device (little-endian) order; results
+ *                    are ELEMENT indices (MonkeyMoore<Ty>::search).
+ * block_bytes  > 0 : engine semantics -- the chain restarts at every block of
+ *                    block_bytes (+ (L-1)*elem_bytes overlap) and, for 16-bit
+ *                    elements, at each of the two byte alignments; results are
+ *                    BYTE offsets + base_offset (SearchEngine<T>::run).
+ * Results are written ascending to out (host memory).  If more than cap exist
+ * the call returns MMH_E_CAPACITY with *out_count = the total. */
+int mmh_scan(mmh_ctx *ctx, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian,
+             uint64_t base_offset, uint64_t *out, uint64_t cap, uint64_t *out_count);
+
+/* Engine selection for tests: 0 = auto (filter + certificate resolver, dense
+ * fallback), 1 = force the sequential per-domain chain kernel. */
+int mmh_set_engine(mmh_ctx *ctx, int engine);
+
+/* Per-stage device timings of the last mmh_scan, in milliseconds (HIP events on
+ * the scan's stream): [0] filter kernel, [1] resolve, [2] sort+copy, [3] total. */
+int mmh_last_timings(mmh_ctx *ctx, float *ms4);
+/* Counters of the last scan: [0] candidates, [1] matches, [2] resolver tiles walked,
+ * [3] path taken (0 fast, 1 sequential fallback). */
+int mmh_last_counters(mmh_ctx *ctx, uint64_t *c4);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

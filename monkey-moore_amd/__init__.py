@@ -1,0 +1,202 @@
+"""monkey-moore_amd -- MI355X-native relative-search engine (host-side Python binding).
+
+Thin ctypes layer over the C ABI of include/mmoore_hip.h (libmmoore_hip.so).
+PyTorch is not needed here; bench.py uses it only for device memory, streams and
+torch.distributed plumbing.  There is no CPU fallback: without the built HIP
+library, or without a GPU, the device entry points raise.
+
+The directory name contains a hyphen, so import it with `load_package()` from
+`__graft_entry__` / tests/conftest.py (importlib, module name `monkey_moore_amd`).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+from . import build, synth  # noqa: F401
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = _build.CAPI_SO
+
+MMH_MAX_KEYWORD = 32
+MMH_OK, MMH_E_ARG, MMH_E_PLAN, MMH_E_DEVICE, MMH_E_CAPACITY, MMH_E_STATE = 0, -1, -2, -3, -4, -5
+
+EXPORTS = [
+    "mmh_last_error", "mmh_plan_relative", "mmh_plan_value_scan", "mmh_device_count", "mmh_create", "mmh_destroy",
+    "mmh_set_stream", "mmh_rom_upload", "mmh_rom_attach", "mmh_rom_download", "mmh_rom_alloc", "mmh_rom_synth",
+    "mmh_rom_poke", "mmh_rom_fill", "mmh_scan", "mmh_set_engine", "mmh_last_timings", "mmh_last_counters",
+]
+
+
+class PlanDesc(C.Structure):
+    """mmh_plan_desc (include/mmoore_hip.h)."""
+    _fields_ = [
+        ("elem_bytes", C.c_uint32), ("mode", C.c_uint32), ("L", C.c_uint32), ("match_jump", C.c_uint32),
+        ("lead_wildcards", C.c_uint32), ("first_literal", C.c_uint32), ("default_skip", C.c_int32),
+        ("n_skip", C.c_uint32),
+        ("expected", C.c_int32 * MMH_MAX_KEYWORD), ("cmp_mask", C.c_uint32 * MMH_MAX_KEYWORD),
+        ("skip_diff", C.c_int32 * MMH_MAX_KEYWORD), ("skip_val", C.c_int32 * MMH_MAX_KEYWORD),
+        ("bridge", C.c_int8 * MMH_MAX_KEYWORD), ("wst", C.c_uint8 * MMH_MAX_KEYWORD),
+    ]
+
+
+class MMError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (code %d)" % (msg, code))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load libmmoore_hip.so; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MMError(MMH_E_DEVICE, "libmmoore_hip.so is not built (run __graft_entry__.build()): " + LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        u32p, u64p, i16p = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_int16)
+        L.mmh_last_error.restype = C.c_char_p
+        L.mmh_plan_relative.argtypes = [C.c_uint32, u32p, C.c_uint32, C.c_uint32, u32p, C.c_uint32, C.POINTER(PlanDesc)]
+        L.mmh_plan_value_scan.argtypes = [C.c_uint32, i16p, C.c_uint32, C.POINTER(PlanDesc)]
+        L.mmh_device_count.argtypes = [C.POINTER(C.c_int)]
+        L.mmh_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.mmh_destroy.argtypes = [C.c_void_p]
+        L.mmh_destroy.restype = None
+        L.mmh_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.mmh_set_engine.argtypes = [C.c_void_p, C.c_int]
+        L.mmh_rom_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.mmh_rom_attach.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.mmh_rom_download.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+        L.mmh_rom_alloc.argtypes = [C.c_void_p, C.c_uint64]
+        L.mmh_rom_synth.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+        L.mmh_rom_poke.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+        L.mmh_rom_fill.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
+        L.mmh_scan.argtypes = [C.c_void_p, C.POINTER(PlanDesc), C.c_uint64, C.c_int, C.c_uint64, u64p, C.c_uint64, u64p]
+        L.mmh_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.mmh_last_counters.argtypes = [C.c_void_p, u64p]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != MMH_OK:
+        raise MMError(rc, lib().mmh_last_error().decode("utf-8", "replace"))
+
+
+def _codepoints(s):
+    if s is None:
+        return np.zeros(0, np.uint32)
+    if isinstance(s, str):
+        return np.array([ord(ch) for ch in s], dtype=np.uint32)
+    return np.array(list(s), dtype=np.uint32)
+
+
+def _p(a, typ):
+    return a.ctypes.data_as(C.POINTER(typ)) if a.size else C.cast(None, C.POINTER(typ))
+
+
+def plan_relative(elem_bytes, keyword, wildcard=0, char_seq=None):
+    """MonkeyMoore<Ty>(keyword, wildcard, char_seq) -> flattened plan (host only)."""
+    kw, seq = _codepoints(keyword), _codepoints(char_seq)
+    d = PlanDesc()
+    _check(lib().mmh_plan_relative(elem_bytes, _p(kw, C.c_uint32), len(kw), int(wildcard), _p(seq, C.c_uint32), len(seq), C.byref(d)))
+    return d
+
+
+def plan_value_scan(elem_bytes, values):
+    """MonkeyMoore<Ty>(reference_values) -> flattened plan (host only)."""
+    v = np.array(list(values), dtype=np.int16)
+    d = PlanDesc()
+    _check(lib().mmh_plan_value_scan(elem_bytes, _p(v, C.c_int16), len(v), C.byref(d)))
+    return d
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = lib().mmh_device_count(C.byref(n))
+    return n.value if rc == MMH_OK else 0
+
+
+class Engine:
+    """One device context: a ROM resident in HBM plus scan workspace."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _check(lib().mmh_create(device, C.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().mmh_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- ROM ------------------------------------------------------------
+    def upload(self, data):
+        a = np.ascontiguousarray(data)
+        _check(lib().mmh_rom_upload(self._h, a.ctypes.data, a.nbytes))
+
+    def attach(self, device_ptr, nbytes):
+        _check(lib().mmh_rom_attach(self._h, C.c_void_p(device_ptr), nbytes))
+
+    def alloc(self, nbytes):
+        _check(lib().mmh_rom_alloc(self._h, nbytes))
+
+    def synth(self, seed, base_offset=0):
+        _check(lib().mmh_rom_synth(self._h, seed, base_offset))
+
+    def poke(self, first_byte, data):
+        a = np.ascontiguousarray(data, dtype=np.uint8)
+        _check(lib().mmh_rom_poke(self._h, first_byte, a.ctypes.data, a.nbytes))
+
+    def fill(self, first_byte, nbytes, value, ramp=0):
+        _check(lib().mmh_rom_fill(self._h, first_byte, nbytes, value, ramp))
+
+    def download(self, first_byte, nbytes):
+        out = np.empty(nbytes, np.uint8)
+        _check(lib().mmh_rom_download(self._h, first_byte, out.ctypes.data, nbytes))
+        return out
+
+    def set_stream(self, hip_stream):
+        _check(lib().mmh_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def set_engine(self, engine):
+        _check(lib().mmh_set_engine(self._h, engine))
+
+    # -- scan -----------------------------------------------------------
+    def scan(self, plan, block_bytes=0, big_endian=False, base_offset=0, cap=1 << 16):
+        """Returns ascending np.uint64 offsets (element indices when block_bytes == 0)."""
+        while True:
+            out = np.empty(cap, np.uint64)
+            n = C.c_uint64(0)
+            rc = lib().mmh_scan(self._h, C.byref(plan), block_bytes, int(big_endian), base_offset,
+                                out.ctypes.data_as(C.POINTER(C.c_uint64)), cap, C.byref(n))
+            if rc == MMH_E_CAPACITY:
+                cap = int(n.value) + 16
+                continue
+            _check(rc)
+            return out[: n.value].copy()
+
+    def timings(self):
+        t = (C.c_float * 4)()
+        _check(lib().mmh_last_timings(self._h, t))
+        return dict(filter_ms=t[0], resolve_ms=t[1], sort_copy_ms=t[2], total_ms=t[3])
+
+    def counters(self):
+        c = (C.c_uint64 * 4)()
+        _check(lib().mmh_last_counters(self._h, c))
+        return dict(candidates=int(c[0]), matches=int(c[1]), tiles_walked=int(c[2]), sequential=int(c[3]))

@@ -1,0 +1,70 @@
+"""Builds libmmoore_hip.so (HIP kernels + C ABI) and libmonkey-core.so (the C++17
+facade with the reference's include/mmoore API) in-tree, for gfx950 only.
+
+hipcc cross-compiles without a GPU, so this also runs in the build container.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+HOST = os.path.join(PKG, "host")
+LIB_DIR = os.path.join(PKG, "lib")
+CAPI_SO = os.path.join(LIB_DIR, "libmmoore_hip.so")
+CORE_SO = os.path.join(LIB_DIR, "libmonkey-core.so")
+
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+ARCH = "gfx950"
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout)
+        raise RuntimeError("build failed: " + " ".join(cmd))
+    return r.stdout
+
+
+def build_capi(force=False):
+    os.makedirs(LIB_DIR, exist_ok=True)
+    srcs = [os.path.join(CSRC, f) for f in ("mm_kernels.hip", "mm_capi.hip", "mm_plan.cpp")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("mm_internal.h", "mm_kernels.h")] + [
+        os.path.join(ROOT, "include", "mmoore_hip.h")]
+    if force or _newer(CAPI_SO, deps):
+        _run([HIPCC, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
+              "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-x", "hip", srcs[0], srcs[1], srcs[2],
+              "-o", CAPI_SO])
+    return CAPI_SO
+
+
+def build_core(force=False):
+    """The C++17 facade (MonkeyMoore<T>, SearchEngine<T>) over the C ABI."""
+    srcs = [os.path.join(HOST, f) for f in ("monkey_moore.cpp", "search_engine.cpp")]
+    if not all(os.path.exists(s) for s in srcs):
+        return None
+    inc = os.path.join(ROOT, "include", "mmoore")
+    deps = srcs + [os.path.join(inc, f) for f in os.listdir(inc)] + [CAPI_SO]
+    if force or _newer(CORE_SO, deps):
+        _run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-pthread", "-I" + os.path.join(ROOT, "include"),
+              *srcs, "-L" + LIB_DIR, "-lmmoore_hip", "-Wl,-rpath,$ORIGIN", "-o", CORE_SO])
+    return CORE_SO
+
+
+def build_all(force=False):
+    build_capi(force)
+    build_core(force)
+    return CAPI_SO
+
+
+if __name__ == "__main__":
+    print(build_all(force="--force" in sys.argv))

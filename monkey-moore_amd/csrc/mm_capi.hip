@@ -1,0 +1,485 @@
+// mm_capi.hip -- the C ABI of include/mmoore_hip.h: device context, ROM
+// ownership, and the orchestration of one scan on one HIP stream.
+//
+// There is no CPU compute path here: every entry point that touches data needs
+// a HIP device and fails with MMH_E_DEVICE otherwise.  The only host work is the
+// pattern plan (mm_plan.cpp), sizing buffers and -- for match lists too long for
+// the device rank sort -- ordering the offsets like search_engine.cpp:193-197.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mm_internal.h"
+#include "mm_kernels.h"
+
+namespace {
+
+thread_local std::string g_error;
+
+constexpr uint64_t kHeaderWords = 4;                 // device counters in front of the sorted list
+constexpr uint64_t kPrefetchWords = 8192;            // one D2H copy covers this many 64-bit words
+constexpr uint64_t kMaxRankSort = 65536;
+constexpr uint64_t kInitialCap = 1u << 20;
+
+bool hip_ok(hipError_t e, const char *what)
+{
+   if (e == hipSuccess) {
+      return true;
+   }
+   mmh_set_error("%s: %s", what, hipGetErrorString(e));
+   return false;
+}
+
+#define HIP_TRY(expr)                       \
+   do {                                     \
+      if (!hip_ok((expr), #expr)) {         \
+         return MMH_E_DEVICE;               \
+      }                                     \
+   } while (0)
+
+} // namespace
+
+extern "C" void mmh_set_error(const char *fmt, ...)
+{
+   char buf[512];
+   va_list ap;
+   va_start(ap, fmt);
+   vsnprintf(buf, sizeof(buf), fmt, ap);
+   va_end(ap);
+   g_error = buf;
+}
+
+extern "C" const char *mmh_last_error(void) { return g_error.c_str(); }
+
+struct mmh_ctx {
+   int device = 0;
+   hipStream_t own_stream = nullptr;
+   hipStream_t stream = nullptr;
+
+   uint8_t *rom = nullptr;
+   uint64_t rom_bytes = 0;
+   uint64_t rom_alloc = 0;          // > 0 when the library owns the buffer
+
+   uint64_t *d_cand = nullptr;      // candidate byte offsets
+   uint64_t cand_cap = 0;
+   uint64_t *d_out = nullptr;       // unordered matches
+   uint64_t *d_result = nullptr;    // [kHeaderWords counters][sorted matches]
+   uint64_t out_cap = 0;
+   uint64_t *h_pinned = nullptr;    // kPrefetchWords words
+
+   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+   int engine = 0;
+   float timings[4] = {0, 0, 0, 0};
+   uint64_t counters[4] = {0, 0, 0, 0};
+};
+
+namespace {
+
+unsigned long long *counter(mmh_ctx *c, int i) { return reinterpret_cast<unsigned long long *>(c->d_result) + i; }
+
+int ensure_workspace(mmh_ctx *c, uint64_t out_cap)
+{
+   HIP_TRY(hipSetDevice(c->device));
+   if (!c->d_cand) {
+      c->cand_cap = kInitialCap;
+      HIP_TRY(hipMalloc(&c->d_cand, c->cand_cap * sizeof(uint64_t)));
+   }
+   if (!c->h_pinned) {
+      HIP_TRY(hipHostMalloc(&c->h_pinned, kPrefetchWords * sizeof(uint64_t), hipHostMallocDefault));
+   }
+   if (out_cap > c->out_cap) {
+      if (c->d_out) {
+         HIP_TRY(hipFree(c->d_out));
+         c->d_out = nullptr;
+      }
+      if (c->d_result) {
+         HIP_TRY(hipFree(c->d_result));
+         c->d_result = nullptr;
+      }
+      HIP_TRY(hipMalloc(&c->d_out, out_cap * sizeof(uint64_t)));
+      HIP_TRY(hipMalloc(&c->d_result, (out_cap + kHeaderWords) * sizeof(uint64_t)));
+      c->out_cap = out_cap;
+   }
+   for (auto &e : c->ev) {
+      if (!e) {
+         HIP_TRY(hipEventCreate(&e));
+      }
+   }
+   return MMH_OK;
+}
+
+void release_rom(mmh_ctx *c)
+{
+   if (c->rom && c->rom_alloc) {
+      (void)hipFree(c->rom);
+   }
+   c->rom = nullptr;
+   c->rom_bytes = 0;
+   c->rom_alloc = 0;
+}
+
+} // namespace
+
+extern "C" int mmh_device_count(int *count)
+{
+   if (!count) {
+      mmh_set_error("mmh_device_count: null argument");
+      return MMH_E_ARG;
+   }
+   int n = 0;
+   hipError_t e = hipGetDeviceCount(&n);
+   if (e != hipSuccess) {
+      *count = 0;
+      mmh_set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+      return MMH_E_DEVICE;
+   }
+   *count = n;
+   return MMH_OK;
+}
+
+extern "C" int mmh_create(int device, mmh_ctx **out)
+{
+   if (!out) {
+      mmh_set_error("mmh_create: null argument");
+      return MMH_E_ARG;
+   }
+   *out = nullptr;
+   int n = 0;
+   if (mmh_device_count(&n) != MMH_OK || n == 0) {
+      if (n == 0) {
+         mmh_set_error("no HIP device available: the MI355X engine has no CPU fallback");
+      }
+      return MMH_E_DEVICE;
+   }
+   if (device < 0 || device >= n) {
+      mmh_set_error("mmh_create: device %d out of range (have %d)", device, n);
+      return MMH_E_ARG;
+   }
+   HIP_TRY(hipSetDevice(device));
+   mmh_ctx *c = new mmh_ctx();
+   c->device = device;
+   if (!hip_ok(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking), "hipStreamCreate")) {
+      delete c;
+      return MMH_E_DEVICE;
+   }
+   c->stream = c->own_stream;
+   *out = c;
+   return MMH_OK;
+}
+
+extern "C" void mmh_destroy(mmh_ctx *c)
+{
+   if (!c) {
+      return;
+   }
+   (void)hipSetDevice(c->device);
+   (void)hipStreamSynchronize(c->stream);
+   release_rom(c);
+   if (c->d_cand) (void)hipFree(c->d_cand);
+   if (c->d_out) (void)hipFree(c->d_out);
+   if (c->d_result) (void)hipFree(c->d_result);
+   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+   for (auto &e : c->ev) {
+      if (e) (void)hipEventDestroy(e);
+   }
+   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+   delete c;
+}
+
+extern "C" int mmh_set_stream(mmh_ctx *c, void *hip_stream)
+{
+   if (!c) {
+      mmh_set_error("mmh_set_stream: null context");
+      return MMH_E_ARG;
+   }
+   c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+   return MMH_OK;
+}
+
+extern "C" int mmh_set_engine(mmh_ctx *c, int engine)
+{
+   if (!c || engine < 0 || engine > 1) {
+      mmh_set_error("mmh_set_engine: bad argument");
+      return MMH_E_ARG;
+   }
+   c->engine = engine;
+   return MMH_OK;
+}
+
+extern "C" int mmh_rom_alloc(mmh_ctx *c, uint64_t nbytes)
+{
+   if (!c) {
+      mmh_set_error("mmh_rom_alloc: null context");
+      return MMH_E_ARG;
+   }
+   HIP_TRY(hipSetDevice(c->device));
+   uint64_t need = ((nbytes + 15) / 16) * 16 + 16;
+   if (!(c->rom && c->rom_alloc >= need)) {
+      release_rom(c);
+      void *p = nullptr;
+      HIP_TRY(hipMalloc(&p, need));
+      c->rom = static_cast<uint8_t *>(p);
+      c->rom_alloc = need;
+   }
+   c->rom_bytes = nbytes;
+   // the padding behind the ROM is never interpreted, but keep it defined
+   HIP_TRY(hipMemsetAsync(c->rom + (nbytes / 16) * 16, 0, need - (nbytes / 16) * 16, c->stream));
+   return MMH_OK;
+}
+
+extern "C" int mmh_rom_upload(mmh_ctx *c, const void *host, uint64_t nbytes)
+{
+   if (!c || (!host && nbytes)) {
+      mmh_set_error("mmh_rom_upload: bad argument");
+      return MMH_E_ARG;
+   }
+   int rc = mmh_rom_alloc(c, nbytes);
+   if (rc != MMH_OK) {
+      return rc;
+   }
+   if (nbytes) {
+      HIP_TRY(hipMemcpyAsync(c->rom, host, nbytes, hipMemcpyHostToDevice, c->stream));
+   }
+   HIP_TRY(hipStreamSynchronize(c->stream));
+   return MMH_OK;
+}
+
+extern "C" int mmh_rom_attach(mmh_ctx *c, const void *device_ptr, uint64_t nbytes)
+{
+   if (!c || (!device_ptr && nbytes)) {
+      mmh_set_error("mmh_rom_attach: bad argument");
+      return MMH_E_ARG;
+   }
+   if (reinterpret_cast<uintptr_t>(device_ptr) & 15) {
+      mmh_set_error("mmh_rom_attach: device pointer must be 16-byte aligned");
+      return MMH_E_ARG;
+   }
+   release_rom(c);
+   c->rom = const_cast<uint8_t *>(static_cast<const uint8_t *>(device_ptr));
+   c->rom_bytes = nbytes;
+   c->rom_alloc = 0;
+   return MMH_OK;
+}
+
+extern "C" int mmh_rom_download(mmh_ctx *c, uint64_t first_byte, void *host, uint64_t nbytes)
+{
+   if (!c || !host || !c->rom || first_byte + nbytes > c->rom_bytes) {
+      mmh_set_error("mmh_rom_download: bad argument");
+      return MMH_E_ARG;
+   }
+   HIP_TRY(hipSetDevice(c->device));
+   HIP_TRY(hipMemcpyAsync(host, c->rom + first_byte, nbytes, hipMemcpyDeviceToHost, c->stream));
+   HIP_TRY(hipStreamSynchronize(c->stream));
+   return MMH_OK;
+}
+
+extern "C" int mmh_rom_synth(mmh_ctx *c, uint64_t seed, uint64_t rom_base_offset)
+{
+   if (!c || !c->rom) {
+      mmh_set_error("mmh_rom_synth: no ROM");
+      return MMH_E_STATE;
+   }
+   if (rom_base_offset & 15) {
+      mmh_set_error("mmh_rom_synth: base offset must be a multiple of 16");
+      return MMH_E_ARG;
+   }
+   HIP_TRY(hipSetDevice(c->device));
+   mm::launch_synth(c->stream, c->rom, c->rom_bytes, seed, rom_base_offset);
+   HIP_TRY(hipGetLastError());
+   return MMH_OK;
+}
+
+extern "C" int mmh_rom_poke(mmh_ctx *c, uint64_t first_byte, const void *host, uint64_t nbytes)
+{
+   if (!c || !c->rom || !host || first_byte + nbytes > c->rom_bytes) {
+      mmh_set_error("mmh_rom_poke: bad argument");
+      return MMH_E_ARG;
+   }
+   HIP_TRY(hipSetDevice(c->device));
+   HIP_TRY(hipMemcpyAsync(c->rom + first_byte, host, nbytes, hipMemcpyHostToDevice, c->stream));
+   HIP_TRY(hipStreamSynchronize(c->stream));
+   return MMH_OK;
+}
+
+extern "C" int mmh_rom_fill(mmh_ctx *c, uint64_t first_byte, uint64_t nbytes, int value, int ramp)
+{
+   if (!c || !c->rom || first_byte + nbytes > c->rom_bytes) {
+      mmh_set_error("mmh_rom_fill: bad argument");
+      return MMH_E_ARG;
+   }
+   HIP_TRY(hipSetDevice(c->device));
+   mm::launch_pattern_fill(c->stream, c->rom, first_byte, nbytes, value, ramp);
+   HIP_TRY(hipGetLastError());
+   return MMH_OK;
+}
+
+namespace {
+
+struct Outcome {
+   uint64_t candidates = 0;
+   uint64_t matches = 0;
+   uint64_t tiles = 0;
+   bool sorted_on_device = false;
+};
+
+// enqueue [zero counters] -> engine kernels -> rank sort -> D2H prefetch, then wait
+int run_pipeline(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, const mm::FilterChoice &fc, bool sequential,
+                 uint64_t base_offset, uint32_t max_candidates, Outcome *oc)
+{
+   hipStream_t st = c->stream;
+   HIP_TRY(hipMemsetAsync(c->d_result, 0, kHeaderWords * sizeof(uint64_t), st));
+   HIP_TRY(hipEventRecord(c->ev[0], st));
+   if (!sequential) {
+      mm::launch_filter(st, g, pl, fc, c->d_cand, counter(c, 0), c->cand_cap);
+   }
+   HIP_TRY(hipEventRecord(c->ev[1], st));
+   if (!sequential) {
+      mm::launch_resolve(st, g, pl, c->d_cand, counter(c, 0), c->cand_cap, c->d_out, counter(c, 1), c->out_cap,
+                         counter(c, 2), base_offset, max_candidates);
+   }
+   else {
+      mm::launch_chain_seq(st, g, pl, c->d_out, counter(c, 1), c->out_cap, base_offset);
+   }
+   HIP_TRY(hipEventRecord(c->ev[2], st));
+   mm::launch_rank_sort(st, c->d_out, counter(c, 1), c->out_cap, kMaxRankSort, c->d_result + kHeaderWords);
+   HIP_TRY(hipGetLastError());
+   uint64_t prefetch = std::min<uint64_t>(kPrefetchWords, c->out_cap + kHeaderWords);
+   HIP_TRY(hipMemcpyAsync(c->h_pinned, c->d_result, prefetch * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+   HIP_TRY(hipEventRecord(c->ev[3], st));
+   HIP_TRY(hipStreamSynchronize(st));
+
+   oc->candidates = c->h_pinned[0];
+   oc->matches = c->h_pinned[1];
+   oc->tiles = c->h_pinned[2];
+   oc->sorted_on_device = oc->matches <= kMaxRankSort && oc->matches <= c->out_cap;
+   (void)hipEventElapsedTime(&c->timings[0], c->ev[0], c->ev[1]);
+   (void)hipEventElapsedTime(&c->timings[1], c->ev[1], c->ev[2]);
+   (void)hipEventElapsedTime(&c->timings[2], c->ev[2], c->ev[3]);
+   (void)hipEventElapsedTime(&c->timings[3], c->ev[0], c->ev[3]);
+   return MMH_OK;
+}
+
+} // namespace
+
+extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian,
+                        uint64_t base_offset, uint64_t *out, uint64_t cap, uint64_t *out_count)
+{
+   if (!c || !plan || !out_count || (!out && cap)) {
+      mmh_set_error("mmh_scan: bad argument");
+      return MMH_E_ARG;
+   }
+   *out_count = 0;
+   if (!c->rom) {
+      mmh_set_error("mmh_scan: no ROM attached");
+      return MMH_E_STATE;
+   }
+   if (plan->L < 2 || plan->L > MMH_MAX_KEYWORD || (plan->elem_bytes != 1 && plan->elem_bytes != 2) ||
+       plan->match_jump < 1 || plan->n_skip > MMH_MAX_KEYWORD) {
+      mmh_set_error("mmh_scan: malformed plan");
+      return MMH_E_PLAN;
+   }
+   HIP_TRY(hipSetDevice(c->device));
+
+   MmGeom g;
+   g.rom = c->rom;
+   g.nbytes = c->rom_bytes;
+   g.block_bytes = block_bytes;
+   g.S = plan->elem_bytes;
+   g.L = plan->L;
+   g.big_endian = (plan->elem_bytes == 2 && big_endian) ? 1u : 0u;
+   g.whole = block_bytes == 0 ? 1u : 0u;
+   g.nblocks = g.whole ? 1 : (g.nbytes + block_bytes - 1) / block_bytes;
+   if (g.whole) {
+      g.nbytes = (g.nbytes / g.S) * g.S;        // whole elements only, like search(const Ty*, len)
+   }
+
+   int rc = ensure_workspace(c, std::max<uint64_t>(c->out_cap, kInitialCap));
+   if (rc != MMH_OK) {
+      return rc;
+   }
+   std::memset(c->counters, 0, sizeof(c->counters));
+   if (g.nbytes == 0) {
+      std::memset(c->timings, 0, sizeof(c->timings));
+      return MMH_OK;
+   }
+
+   mm::FilterChoice fc;
+   bool have_filter = mm::choose_filter(*plan, &fc);
+   bool sequential = c->engine == 1 || !have_filter;
+   // dense candidate sets go to the sequential engine: it is linear in the ROM
+   // size, the per-candidate resolver is not
+   const uint32_t max_candidates = g.whole ? 262144u : 16384u;
+
+   Outcome oc;
+   for (int attempt = 0; attempt < 4; attempt++) {
+      rc = run_pipeline(c, g, *plan, fc, sequential, base_offset, max_candidates, &oc);
+      if (rc != MMH_OK) {
+         return rc;
+      }
+      if (!sequential && (oc.candidates > c->cand_cap || oc.candidates > max_candidates)) {
+         sequential = true;                       // too dense for the certificate resolver
+         continue;
+      }
+      if (oc.matches > c->out_cap) {
+         rc = ensure_workspace(c, oc.matches + oc.matches / 8 + 1024);
+         if (rc != MMH_OK) {
+            return rc;
+         }
+         continue;
+      }
+      break;
+   }
+   c->counters[0] = oc.candidates;
+   c->counters[1] = oc.matches;
+   c->counters[2] = oc.tiles;
+   c->counters[3] = sequential ? 1 : 0;
+
+   *out_count = oc.matches;
+   if (oc.matches > cap) {
+      mmh_set_error("mmh_scan: %llu matches do not fit the caller's buffer of %llu",
+                    (unsigned long long)oc.matches, (unsigned long long)cap);
+      return MMH_E_CAPACITY;
+   }
+   if (oc.matches == 0) {
+      return MMH_OK;
+   }
+   if (oc.sorted_on_device) {
+      uint64_t have = std::min<uint64_t>(oc.matches, kPrefetchWords - kHeaderWords);
+      std::memcpy(out, c->h_pinned + kHeaderWords, have * sizeof(uint64_t));
+      if (oc.matches > have) {
+         HIP_TRY(hipMemcpy(out + have, c->d_result + kHeaderWords + have, (oc.matches - have) * sizeof(uint64_t),
+                           hipMemcpyDeviceToHost));
+      }
+   }
+   else {
+      // very long match lists: order on the host, as search_engine.cpp:193-197 does
+      HIP_TRY(hipMemcpy(out, c->d_out, oc.matches * sizeof(uint64_t), hipMemcpyDeviceToHost));
+      std::sort(out, out + oc.matches);
+   }
+   return MMH_OK;
+}
+
+extern "C" int mmh_last_timings(mmh_ctx *c, float *ms4)
+{
+   if (!c || !ms4) {
+      mmh_set_error("mmh_last_timings: bad argument");
+      return MMH_E_ARG;
+   }
+   std::memcpy(ms4, c->timings, sizeof(c->timings));
+   return MMH_OK;
+}
+
+extern "C" int mmh_last_counters(mmh_ctx *c, uint64_t *c4)
+{
+   if (!c || !c4) {
+      mmh_set_error("mmh_last_counters: bad argument");
+      return MMH_E_ARG;
+   }
+   std::memcpy(c4, c->counters, sizeof(c->counters));
+   return MMH_OK;
+}

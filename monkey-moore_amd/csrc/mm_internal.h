@@ -1,0 +1,69 @@
+// mm_internal.h -- declarations shared by the host plan builder, the C ABI and
+// the HIP kernels.  Not installed; the public surface is include/mmoore_hip.h.
+#ifndef MM_INTERNAL_H
+#define MM_INTERNAL_H
+
+#include "mmoore_hip.h"
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+// printf-style setter for the thread-local error string behind mmh_last_error()
+void mmh_set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+#ifdef __cplusplus
+}
+#endif
+
+// ---- geometry of a scan: how the ROM splits into independent chain domains --
+//
+// A "domain" is one run of the reference's sequential chain:
+//   whole-buffer mode (block_bytes == 0): the single domain [0, nbytes/S) elements
+//   engine mode: one domain per (block b, byte alignment p in [0,S)), block b =
+//   bytes [b*B, b*B + min(B + (L-1)*S, N - b*B)), search_engine.cpp:218-253,:129-141.
+// Alignment START offsets of block b all lie in [b*B, (b+1)*B), so a byte
+// offset belongs to at most one domain.
+struct MmGeom {
+   const uint8_t *rom;
+   uint64_t nbytes;        // N
+   uint64_t block_bytes;   // B, 0 = whole buffer
+   uint64_t nblocks;       // ceil(N / B) (1 in whole-buffer mode)
+   uint32_t S;             // element bytes
+   uint32_t L;             // keyword length
+   uint32_t big_endian;    // 16-bit elements stored big endian
+   uint32_t whole;         // 1 = whole-buffer mode (results are element indices)
+};
+
+#if defined(__HIPCC__) || defined(__cplusplus)
+#if defined(__HIPCC__)
+#define MM_HD __host__ __device__ inline
+#else
+#define MM_HD inline
+#endif
+
+// number of valid alignments (chain positions) of domain (b, p); <= 0 means none
+MM_HD int64_t mm_domain_nv(const MmGeom &g, uint64_t b, uint32_t p)
+{
+   if (g.whole) {
+      return (int64_t)(g.nbytes / g.S) - (int64_t)g.L + 1;
+   }
+   uint64_t off = b * g.block_bytes;
+   uint64_t full = g.block_bytes + (uint64_t)(g.L - 1) * g.S;
+   uint64_t remaining = g.nbytes - off;
+   uint64_t size = remaining < full ? remaining : full;
+   uint64_t count = size / g.S;                       // search_engine.cpp:137
+   if ((uint64_t)p + count * g.S > size) {            // :139-141
+      count -= 1;
+   }
+   return (int64_t)count - (int64_t)g.L + 1;
+}
+
+// first byte of domain (b, p)
+MM_HD uint64_t mm_domain_start(const MmGeom &g, uint64_t b, uint32_t p)
+{
+   return g.whole ? 0 : b * g.block_bytes + p;
+}
+#endif
+
+#endif

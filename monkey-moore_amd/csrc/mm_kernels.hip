@@ -1,0 +1,813 @@
+// mm_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the relative-search engine.
+//
+// Pipeline of one scan (all launches on one stream, no host round trip between):
+//
+//   mm_filter_u8 / mm_filter_u16   HBM-bound streaming pass over the whole ROM.
+//        Coalesced 16 B/lane loads, SWAR test of the last one or two pattern
+//        deltas on every byte position (4 positions per 32-bit VALU op), exact
+//        verification of the full match predicate for the rare survivors,
+//        wave-aggregated append of CANDIDATES (positions where the reference's
+//        compare loop would report a match IF its chain visited them).
+//   mm_resolve                     one wavefront per candidate.  The reference
+//        is not a complete matcher: it only tests the positions its skip chain
+//        visits.  The resolver decides "is h on the chain of
+//        its domain" exactly, by pulling the set of acceptable chain phases
+//        back through tile maps (phase = position mod (L-1)) until the set is
+//        empty, full, or the domain start (phase 0) is reached.  Skip table,
+//        pattern deltas and the tile bytes live in LDS.
+//   mm_chain_seq                   one lane per domain walking the chain
+//        sequentially; exact by construction, used as the dense / generic
+//        fallback and as an on-device cross-check.
+//   mm_rank_sort                   orders the (few) matches ascending.
+//
+// No MFMA anywhere: the path is integer byte comparison (BASELINE.json).
+#include <hip/hip_runtime.h>
+
+#include "mm_internal.h"
+#include "mm_kernels.h"
+
+// --------------------------------------------------------------------------
+// small helpers
+// --------------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t mm_alignbit(uint32_t hi, uint32_t lo, uint32_t shift)
+{
+   return __builtin_amdgcn_alignbit(hi, lo, shift);   // ({hi,lo} >> shift)[31:0]
+}
+
+// per-byte (a - b) mod 256 on four packed bytes
+__device__ __forceinline__ uint32_t mm_bytesub(uint32_t a, uint32_t b)
+{
+   uint32_t t = (a | 0x80808080u) - (b & 0x7F7F7F7Fu);
+   return t ^ (~(a ^ b) & 0x80808080u);
+}
+
+// bit 7 of a byte set when (at least) that byte or a lower one is zero; used as a
+// superset filter, survivors are verified exactly
+__device__ __forceinline__ uint32_t mm_haszero8(uint32_t v)
+{
+   return (v - 0x01010101u) & ~v & 0x80808080u;
+}
+
+__device__ __forceinline__ uint32_t mm_haszero16(uint32_t v)
+{
+   return (v - 0x00010001u) & ~v & 0x80008000u;
+}
+
+__device__ __forceinline__ uint32_t mm_sub16x2(uint32_t a, uint32_t b)
+{
+   typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+   u16x2 x = __builtin_bit_cast(u16x2, a), y = __builtin_bit_cast(u16x2, b);
+   return __builtin_bit_cast(uint32_t, (u16x2)(x - y));             // v_pk_sub_u16
+}
+
+__device__ __forceinline__ uint32_t mm_bswap16x2(uint32_t v)
+{
+   return __builtin_amdgcn_perm(v, v, 0x02030001u);                 // swap bytes inside each half
+}
+
+// element j of the domain that starts at byte `start`
+__device__ __forceinline__ int mm_elem(const MmGeom &g, uint64_t start, int64_t j)
+{
+   const uint8_t *p = g.rom + start + (uint64_t)j * g.S;
+   if (g.S == 1) {
+      return p[0];
+   }
+   int lo = p[0], hi = p[1];
+   return g.big_endian ? (lo << 8 | hi) : (hi << 8 | lo);
+}
+
+__device__ __forceinline__ int mm_skip_sparse(const mmh_plan_desc &pl, int d)
+{
+   int s = pl.default_skip;
+   for (uint32_t k = 0; k < pl.n_skip; k++) {
+      if (pl.skip_diff[k] == d) {
+         s = pl.skip_val[k];
+      }
+   }
+   return s;
+}
+
+// The reference's compare loop at alignment j (unified form of
+// monkey_moore.cpp:347-407 and :449-543).  Returns the jump; *matched says
+// whether the loop reported a match.
+template <class Reader>
+__device__ __forceinline__ int mm_step(const mmh_plan_desc &pl, Reader rd, int64_t j, bool *matched)
+{
+   for (int i = (int)pl.L - 1; i >= 0; --i) {
+      int c = rd(j + i);
+      int p = rd(j + i + pl.bridge[i]);
+      int d = c - p;
+      if (((uint32_t)(d ^ pl.expected[i]) & pl.cmp_mask[i]) != 0) {
+         int s = mm_skip_sparse(pl, d);
+         s = s < 1 ? 1 : s;
+         int w = pl.wst[i];
+         *matched = false;
+         return s < w ? s : w;
+      }
+   }
+   *matched = true;
+   return (int)pl.match_jump;
+}
+
+// which domain a byte offset belongs to; returns false when the offset is not a
+// valid alignment of any domain (tail of the file, 16-bit odd boundary, ...)
+__device__ __forceinline__ bool mm_locate(const MmGeom &g, uint64_t o, uint64_t *b, uint32_t *p, int64_t *j)
+{
+   if (g.whole) {
+      if (o % g.S) {
+         return false;
+      }
+      *b = 0; *p = 0; *j = (int64_t)(o / g.S);
+   }
+   else {
+      uint64_t blk = o / g.block_bytes;
+      uint64_t r = o - blk * g.block_bytes;
+      *b = blk; *p = (uint32_t)(r % g.S); *j = (int64_t)(r / g.S);
+   }
+   return *j < mm_domain_nv(g, *b, *p);
+}
+
+// wave-aggregated append (ballot + prefix popcount -> one atomic per wave)
+__device__ __forceinline__ void mm_append(uint64_t *list, unsigned long long *count, uint64_t cap, bool want, uint64_t value)
+{
+   unsigned long long mask = __ballot(want);
+   if (mask == 0) {
+      return;
+   }
+   unsigned lane = __lane_id();
+   unsigned long long base = 0;
+   int leader = __ffsll((long long)mask) - 1;
+   if ((int)lane == leader) {
+      base = atomicAdd(count, (unsigned long long)__popcll(mask));
+   }
+   base = __shfl(base, leader);
+   if (want) {
+      unsigned long long slot = base + __popcll(mask & ((1ull << lane) - 1));
+      if (slot < cap) {
+         list[slot] = value;
+      }
+   }
+}
+
+// verify the full match predicate at byte offset o and append it as a candidate
+__device__ __forceinline__ bool mm_is_candidate(const MmGeom &g, const mmh_plan_desc &pl, int64_t o)
+{
+   if (o < 0) {
+      return false;
+   }
+   uint64_t b; uint32_t p; int64_t j;
+   if (!mm_locate(g, (uint64_t)o, &b, &p, &j)) {
+      return false;
+   }
+   uint64_t start = mm_domain_start(g, b, p);
+   bool matched;
+   mm_step(pl, [&](int64_t k) { return mm_elem(g, start, k); }, j, &matched);
+   return matched;
+}
+
+// --------------------------------------------------------------------------
+// streaming filter, 8-bit elements
+// --------------------------------------------------------------------------
+//
+// One 16-byte chunk per lane per iteration (lane l of a wave reads bytes
+// [16l, 16l+16) of a 1 KiB line group -> fully coalesced dwordx4), plus the 4
+// bytes in front of it.  For every byte t the SWAR code evaluates
+//     (x[t]   - x[t-1]) mod 256 == patA          (delta of keyword position iA)
+//     (x[t-1] - x[t-2]) mod 256 == patB          (delta of position iA-1, NCOND == 2)
+// which is necessary for a match starting at t - iA on both reference paths
+// (signed equality implies modular equality).  Survivors (2^-16 of positions on
+// random data) are verified exactly.
+
+struct MmFilterArgs {
+   MmGeom g;
+   mmh_plan_desc plan;
+   uint32_t patA;          // replicated over the SWAR lanes
+   uint32_t patB;
+   uint32_t iA;            // keyword index of the element whose delta is patA
+   uint32_t ncond;
+   uint64_t *cand;         // candidate byte offsets
+   unsigned long long *cand_count;
+   uint64_t cand_cap;
+};
+
+__device__ __forceinline__ uint4 mm_load_chunk(const uint8_t *rom, uint64_t nbytes, uint64_t byte0)
+{
+   if (byte0 + 16 <= nbytes) {
+      return *reinterpret_cast<const uint4 *>(rom + byte0);
+   }
+   uint32_t w[4] = {0, 0, 0, 0};
+   for (uint64_t k = byte0; k < nbytes; k++) {
+      w[(k - byte0) >> 2] |= (uint32_t)rom[k] << (8 * ((k - byte0) & 3));
+   }
+   return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <int NCOND>
+__device__ __forceinline__ uint32_t mm_f8_hits(uint32_t w, uint32_t wprev, uint32_t &dbprev, uint32_t patA, uint32_t patB)
+{
+   uint32_t db = mm_bytesub(w, mm_alignbit(w, wprev, 24));
+   uint32_t z = db ^ patA;
+   if (NCOND == 2) {
+      z |= mm_alignbit(db, dbprev, 24) ^ patB;
+   }
+   dbprev = db;
+   return mm_haszero8(z);
+}
+
+template <int NCOND>
+__global__ __launch_bounds__(256) void mm_filter_u8(MmFilterArgs a)
+{
+   const uint64_t nchunks = (a.g.nbytes + 15) / 16;
+   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+   constexpr int UNROLL = 4;
+   // same trip count in every lane: the ballots below must see whole waves
+   const uint64_t iters = (nchunks + stride * UNROLL - 1) / (stride * UNROLL);
+
+   for (uint64_t it = 0; it < iters; it++) {
+      const uint64_t c0 = it * stride * UNROLL + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+      uint4 w[UNROLL];
+      uint32_t back[UNROLL];
+      uint32_t hits[UNROLL][4];
+      uint32_t any = 0;
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++) {
+         uint64_t c = c0 + stride * u;
+         if (c < nchunks) {
+            w[u] = mm_load_chunk(a.g.rom, a.g.nbytes, c * 16);
+            back[u] = c ? *reinterpret_cast<const uint32_t *>(a.g.rom + c * 16 - 4) : 0u;
+         }
+         else {
+            w[u] = make_uint4(0, 0, 0, 0);
+            back[u] = 0;
+         }
+      }
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++) {
+         // delta of the byte just in front of the chunk; its predecessor sits in the same word
+         uint32_t dbprev = mm_bytesub(back[u], back[u] << 8);
+         hits[u][0] = mm_f8_hits<NCOND>(w[u].x, back[u], dbprev, a.patA, a.patB);
+         hits[u][1] = mm_f8_hits<NCOND>(w[u].y, w[u].x, dbprev, a.patA, a.patB);
+         hits[u][2] = mm_f8_hits<NCOND>(w[u].z, w[u].y, dbprev, a.patA, a.patB);
+         hits[u][3] = mm_f8_hits<NCOND>(w[u].w, w[u].z, dbprev, a.patA, a.patB);
+         any |= hits[u][0] | hits[u][1] | hits[u][2] | hits[u][3];
+      }
+      if (__ballot(any != 0) == 0) {
+         continue;                              // the common case: nothing in this wave's 4 KiB
+      }
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++) {
+         uint64_t c = c0 + stride * u;
+#pragma unroll
+         for (int k = 0; k < 4; k++) {
+            uint32_t h = (c < nchunks) ? hits[u][k] : 0u;
+            while (__ballot(h != 0) != 0) {
+               bool want = false;
+               uint64_t off = 0;
+               if (h) {
+                  int bit = __ffs((int)h) - 1;
+                  h &= h - 1;
+                  int64_t t = (int64_t)(c * 16 + 4 * k + (bit >> 3));
+                  int64_t o = t - (int64_t)a.iA;
+                  if (mm_is_candidate(a.g, a.plan, o)) {
+                     want = true;
+                     off = (uint64_t)o;
+                  }
+               }
+               mm_append(a.cand, a.cand_count, a.cand_cap, want, off);
+            }
+         }
+      }
+   }
+}
+
+// --------------------------------------------------------------------------
+// streaming filter, 16-bit elements (both byte alignments from one read)
+// --------------------------------------------------------------------------
+//
+// For every byte position u the element e(u) = 16 bits at bytes u,u+1 (file
+// endianness).  Hit when (e(u) - e(u-2)) mod 65536 == patA, candidate start
+// o = u - 2*iA.  Even and odd u are two SWAR streams over the same registers.
+
+__device__ __forceinline__ uint32_t mm_f16_hits(uint32_t cur, uint32_t prev, uint32_t patA)
+{
+   uint32_t d = mm_sub16x2(cur, mm_alignbit(cur, prev, 16));
+   return mm_haszero16(d ^ patA);
+}
+
+__global__ __launch_bounds__(256) void mm_filter_u16(MmFilterArgs a)
+{
+   const uint64_t nchunks = (a.g.nbytes + 15) / 16;
+   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+   constexpr int UNROLL = 2;
+   const bool be = a.g.big_endian != 0;
+   const uint64_t iters = (nchunks + stride * UNROLL - 1) / (stride * UNROLL);
+
+   for (uint64_t it = 0; it < iters; it++) {
+      const uint64_t c0 = it * stride * UNROLL + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+      uint4 w[UNROLL];
+      uint2 back[UNROLL];
+      uint32_t he[UNROLL][4], ho[UNROLL][4];
+      uint32_t any = 0;
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++) {
+         uint64_t c = c0 + stride * u;
+         if (c < nchunks) {
+            w[u] = mm_load_chunk(a.g.rom, a.g.nbytes, c * 16);
+            back[u] = c ? *reinterpret_cast<const uint2 *>(a.g.rom + c * 16 - 8) : make_uint2(0, 0);
+         }
+         else {
+            w[u] = make_uint4(0, 0, 0, 0);
+            back[u] = make_uint2(0, 0);
+         }
+      }
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++) {
+         uint32_t r[6] = {back[u].x, back[u].y, w[u].x, w[u].y, w[u].z, w[u].w};
+         uint32_t ev[6], od[6];
+#pragma unroll
+         for (int k = 0; k < 6; k++) {
+            ev[k] = be ? mm_bswap16x2(r[k]) : r[k];                 // elements at bytes 4k, 4k+2
+         }
+#pragma unroll
+         for (int k = 1; k < 6; k++) {
+            uint32_t o = mm_alignbit(r[k], r[k - 1], 24);           // bytes 4k-1 .. 4k+2
+            od[k] = be ? mm_bswap16x2(o) : o;                        // elements at bytes 4k-1, 4k+1
+         }
+#pragma unroll
+         for (int k = 0; k < 4; k++) {
+            he[u][k] = mm_f16_hits(ev[k + 2], ev[k + 1], a.patA);
+            ho[u][k] = mm_f16_hits(od[k + 2], od[k + 1], a.patA);
+            any |= he[u][k] | ho[u][k];
+         }
+      }
+      if (__ballot(any != 0) == 0) {
+         continue;
+      }
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++) {
+         uint64_t c = c0 + stride * u;
+#pragma unroll
+         for (int k = 0; k < 4; k++) {
+#pragma unroll
+            for (int par = 0; par < 2; par++) {
+               uint32_t h = (c < nchunks) ? (par ? ho[u][k] : he[u][k]) : 0u;
+               while (__ballot(h != 0) != 0) {
+                  bool want = false;
+                  uint64_t off = 0;
+                  if (h) {
+                     int bit = __ffs((int)h) - 1;
+                     h &= h - 1;
+                     // bit 15 -> low half, bit 31 -> high half
+                     int64_t ubyte = (int64_t)(c * 16 + 4 * k + ((bit >> 4) << 1)) - (par ? 1 : 0);
+                     int64_t o = ubyte - 2 * (int64_t)a.iA;
+                     if (mm_is_candidate(a.g, a.plan, o)) {
+                        want = true;
+                        off = (uint64_t)o;
+                     }
+                  }
+                  mm_append(a.cand, a.cand_count, a.cand_cap, want, off);
+               }
+            }
+         }
+      }
+   }
+}
+
+// --------------------------------------------------------------------------
+// certificate resolver: is candidate h on the chain of its domain?
+// --------------------------------------------------------------------------
+//
+// Chain state = the next position the reference will visit.  Every jump is in
+// [1, D] with D = L-1, so at any boundary a the next visited position lies in
+// [a, a+D) and is identified by its PHASE (position mod D).  Processing position
+// j moves "phase j mod D" to "phase (j + J(j)) mod D" and leaves the others
+// alone; a jump of exactly D changes nothing.  A tile's effect is therefore a
+// map Z_D -> Z_D, computed as 64 lane-local maps (sequential inside a lane's
+// 64 positions) chained through LDS.
+//
+// For a candidate at j_c we keep the set A of phases that lead to visiting it,
+// starting with {j_c mod D} at the frontier j_c, and pull it back tile by tile:
+// A' = {e : tile_map(e) in A}.  A' empty -> not visited, A' = everything ->
+// visited (no matter how the chain entered), otherwise continue; at the domain
+// start the chain is in phase 0 (monkey_moore.cpp:329).
+
+constexpr int MM_SEG = 64;                    // positions per lane
+constexpr int MM_TILE = 64 * MM_SEG;          // positions per tile
+constexpr int MM_RESOLVE_WAVES = 4;
+
+struct MmResolveArgs {
+   MmGeom g;
+   mmh_plan_desc plan;
+   const uint64_t *cand;
+   const unsigned long long *cand_count;
+   uint64_t cand_cap;
+   uint64_t *out;
+   unsigned long long *out_count;
+   uint64_t out_cap;
+   unsigned long long *tiles_walked;
+   uint64_t base_offset;                      // added to reported byte offsets
+   uint32_t max_candidates;                   // above this the host falls back to mm_chain_seq
+};
+
+struct MmResolveLds {
+   int32_t expected[MMH_MAX_KEYWORD];
+   uint32_t cmp_mask[MMH_MAX_KEYWORD];
+   int8_t bridge[MMH_MAX_KEYWORD];
+   uint8_t wst[MMH_MAX_KEYWORD];
+   uint8_t skip8[512];                                                 // dense bad-character table (8-bit)
+   uint8_t maps[MM_RESOLVE_WAVES][64][MMH_MAX_KEYWORD];                // lane maps
+   uint8_t tile[MM_RESOLVE_WAVES][(MM_TILE + MMH_MAX_KEYWORD) * 2 + 16];
+};
+
+__global__ __launch_bounds__(256) void mm_resolve(MmResolveArgs a)
+{
+   __shared__ MmResolveLds lds;
+   const int L = (int)a.plan.L;
+   const int D = L - 1;
+   const int S = (int)a.g.S;
+   const int wave = threadIdx.x >> 6;
+   const int lane = threadIdx.x & 63;
+
+   for (int i = threadIdx.x; i < MMH_MAX_KEYWORD; i += blockDim.x) {
+      lds.expected[i] = a.plan.expected[i];
+      lds.cmp_mask[i] = a.plan.cmp_mask[i];
+      lds.bridge[i] = a.plan.bridge[i];
+      lds.wst[i] = a.plan.wst[i];
+   }
+   if (S == 1) {
+      for (int i = threadIdx.x; i < 512; i += blockDim.x) {
+         int s = a.plan.default_skip;
+         s = s < 1 ? 1 : s;
+         lds.skip8[i] = (uint8_t)s;
+      }
+      __syncthreads();
+      for (int i = threadIdx.x; i < (int)a.plan.n_skip; i += blockDim.x) {
+         int s = a.plan.skip_val[i];
+         s = s < 1 ? 1 : s;
+         lds.skip8[a.plan.skip_diff[i] + 255] = (uint8_t)s;
+      }
+   }
+   __syncthreads();
+
+   unsigned long long ncand = *a.cand_count;
+   if (ncand > a.cand_cap || ncand > a.max_candidates) {
+      return;                                  // dense input: the host runs the sequential engine instead
+   }
+   const uint64_t nwaves = (uint64_t)gridDim.x * MM_RESOLVE_WAVES;
+   uint8_t *tile = lds.tile[wave];
+   unsigned long long walked = 0;
+
+   for (uint64_t ci = (uint64_t)blockIdx.x * MM_RESOLVE_WAVES + wave; ci < ncand; ci += nwaves) {
+      const uint64_t o = a.cand[ci];
+      uint64_t b; uint32_t p; int64_t jc;
+      mm_locate(a.g, o, &b, &p, &jc);          // candidates were located by the filter already
+      const uint64_t start = mm_domain_start(a.g, b, p);
+
+      const uint32_t full = D >= 32 ? 0xFFFFFFFFu : ((1u << D) - 1u);
+      uint32_t A = 1u << (uint32_t)(jc % D);
+      int64_t hi = jc;
+      bool visited = false;
+      while (true) {
+         if (hi == 0) {
+            visited = (A & 1u) != 0;
+            break;
+         }
+         const int64_t lo = ((hi - 1) / MM_TILE) * MM_TILE;
+         const int npos = (int)(hi - lo);
+         // stage the tile's bytes: elements [lo, hi + L - 1)
+         const int nstage = (npos + L - 1) * S;
+         const uint8_t *src = a.g.rom + start + (uint64_t)lo * S;
+         if ((((uintptr_t)src) & 3) == 0) {
+            const uint32_t *s4 = reinterpret_cast<const uint32_t *>(src);
+            uint32_t *d4 = reinterpret_cast<uint32_t *>(tile);
+            int nw = nstage >> 2;
+            for (int k = lane; k < nw; k += 64) {
+               d4[k] = s4[k];
+            }
+            for (int k = (nw << 2) + lane; k < nstage; k += 64) {
+               tile[k] = src[k];
+            }
+         }
+         else {
+            for (int k = lane; k < nstage; k += 64) {
+               tile[k] = src[k];
+            }
+         }
+         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+         __builtin_amdgcn_wave_barrier();
+
+         // lane-local map of positions [lo + lane*SEG, ...) below hi
+         uint8_t m[MMH_MAX_KEYWORD];
+#pragma unroll
+         for (int e = 0; e < MMH_MAX_KEYWORD; e++) {
+            m[e] = (uint8_t)e;
+         }
+         const int seg0 = lane * MM_SEG;
+         const int seg1 = min(seg0 + MM_SEG, npos);
+         int r = (int)((lo + seg0) % D);
+         const bool be = a.g.big_endian != 0;
+         for (int q = seg0; q < seg1; q++) {
+            int J = (int)a.plan.match_jump;
+            for (int i = L - 1; i >= 0; --i) {
+               int ia = (q + i) * S, ib = (q + i + lds.bridge[i]) * S;
+               int c, pv;
+               if (S == 1) {
+                  c = tile[ia];
+                  pv = tile[ib];
+               }
+               else {
+                  c = be ? (tile[ia] << 8 | tile[ia + 1]) : (tile[ia + 1] << 8 | tile[ia]);
+                  pv = be ? (tile[ib] << 8 | tile[ib + 1]) : (tile[ib + 1] << 8 | tile[ib]);
+               }
+               int d = c - pv;
+               if (((uint32_t)(d ^ lds.expected[i]) & lds.cmp_mask[i]) != 0) {
+                  int s;
+                  if (S == 1) {
+                     s = lds.skip8[d + 255];
+                  }
+                  else {
+                     s = mm_skip_sparse(a.plan, d);
+                     s = s < 1 ? 1 : s;
+                  }
+                  int w = lds.wst[i];
+                  J = s < w ? s : w;
+                  break;
+               }
+            }
+            if (J != D) {
+               int r2 = r + J;
+               r2 = r2 >= D ? r2 - D : r2;
+#pragma unroll
+               for (int e = 0; e < MMH_MAX_KEYWORD; e++) {
+                  m[e] = (m[e] == r) ? (uint8_t)r2 : m[e];
+               }
+            }
+            r = (r + 1 == D) ? 0 : r + 1;
+         }
+#pragma unroll
+         for (int e = 0; e < MMH_MAX_KEYWORD; e++) {
+            lds.maps[wave][lane][e] = m[e];
+         }
+         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+         __builtin_amdgcn_wave_barrier();
+
+         // lane e chases entry phase e through the 64 lane maps
+         int v = lane < D ? lane : 0;
+         const int nseg = (npos + MM_SEG - 1) / MM_SEG;
+         for (int s = 0; s < nseg; s++) {
+            v = lds.maps[wave][s][v];
+         }
+         uint32_t Anew = (uint32_t)__ballot(lane < D && ((A >> v) & 1u));
+         __builtin_amdgcn_wave_barrier();
+         walked++;
+         if (Anew == full) {
+            visited = true;
+            break;
+         }
+         if (Anew == 0) {
+            visited = false;
+            break;
+         }
+         A = Anew;
+         hi = lo;
+      }
+      if (lane == 0 && visited) {
+         unsigned long long slot = atomicAdd(a.out_count, 1ull);
+         if (slot < a.out_cap) {
+            a.out[slot] = a.g.whole ? o / a.g.S : o + a.base_offset;
+         }
+      }
+   }
+   if (lane == 0 && walked) {
+      atomicAdd(a.tiles_walked, walked);
+   }
+}
+
+// --------------------------------------------------------------------------
+// sequential engine: one lane per domain, exact by construction
+// --------------------------------------------------------------------------
+
+struct MmSeqArgs {
+   MmGeom g;
+   mmh_plan_desc plan;
+   uint64_t *out;
+   unsigned long long *out_count;
+   uint64_t out_cap;
+   uint64_t base_offset;
+};
+
+__global__ __launch_bounds__(64) void mm_chain_seq(MmSeqArgs a)
+{
+   const uint64_t ndom = a.g.whole ? 1 : a.g.nblocks * a.g.S;
+   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+   // every lane of the wave runs the loop the same number of times so that the
+   // wave-aggregated append stays convergent
+   const uint64_t rounds = (ndom + stride - 1) / stride;
+   for (uint64_t rd = 0; rd < rounds; rd++) {
+      uint64_t dom = rd * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+      bool live = dom < ndom;
+      uint64_t b = live ? dom / a.g.S : 0;
+      uint32_t p = live ? (uint32_t)(dom % a.g.S) : 0;
+      int64_t nv = live ? mm_domain_nv(a.g, b, p) : 0;
+      uint64_t start = mm_domain_start(a.g, b, p);
+      int64_t h = 0;
+      while (__ballot(live && h < nv) != 0) {
+         bool want = false;
+         uint64_t val = 0;
+         if (live && h < nv) {
+            bool matched;
+            int J = mm_step(a.plan, [&](int64_t k) { return mm_elem(a.g, start, k); }, h, &matched);
+            if (matched) {
+               want = true;
+               val = a.g.whole ? (uint64_t)h : start + (uint64_t)h * a.g.S + a.base_offset;
+            }
+            h += J;
+         }
+         mm_append(a.out, a.out_count, a.out_cap, want, val);
+      }
+   }
+}
+
+// --------------------------------------------------------------------------
+// ordering of the match list (unique keys): rank = number of smaller keys
+// --------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void mm_rank_sort(const uint64_t *in, const unsigned long long *count, uint64_t cap,
+                                                    uint64_t max_n, uint64_t *out)
+{
+   unsigned long long n = *count;
+   if (n > cap || n > max_n) {
+      return;                                  // the host orders large lists itself
+   }
+   __shared__ uint64_t chunk[1024];
+   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+   const uint64_t rounds = (n + stride - 1) / stride;
+   for (uint64_t rd = 0; rd < rounds; rd++) {
+      uint64_t i = rd * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+      uint64_t key = i < n ? in[i] : ~0ull;
+      uint64_t rank = 0;
+      for (uint64_t base = 0; base < n; base += 1024) {
+         __syncthreads();
+         for (uint64_t k = threadIdx.x; k < 1024; k += blockDim.x) {
+            chunk[k] = base + k < n ? in[base + k] : ~0ull;
+         }
+         __syncthreads();
+         uint64_t lim = n - base < 1024 ? n - base : 1024;
+         for (uint64_t k = 0; k < lim; k++) {
+            rank += chunk[k] < key;
+         }
+      }
+      if (i < n) {
+         out[rank] = key;
+      }
+   }
+}
+
+// --------------------------------------------------------------------------
+// synthetic ROM (bench / tests): splitmix64 words, SURVEY 8d
+// --------------------------------------------------------------------------
+
+__device__ __forceinline__ uint64_t mm_splitmix(uint64_t seed, uint64_t k)
+{
+   uint64_t z = seed + (k + 1) * 0x9E3779B97F4A7C15ull;
+   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+   return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void mm_synth_fill(uint8_t *rom, uint64_t nbytes, uint64_t seed, uint64_t base_offset)
+{
+   // base_offset is a multiple of 16: each thread writes two consecutive 64-bit words
+   const uint64_t npairs = (nbytes + 15) / 16;
+   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npairs; i += stride) {
+      uint64_t k = (base_offset >> 3) + 2 * i;
+      uint64_t w0 = mm_splitmix(seed, k), w1 = mm_splitmix(seed, k + 1);
+      if (i * 16 + 16 <= nbytes) {
+         *reinterpret_cast<ulonglong2 *>(rom + i * 16) = make_ulonglong2(w0, w1);
+      }
+      else {
+         for (uint64_t q = i * 16; q < nbytes; q++) {
+            uint64_t w = (q - i * 16) < 8 ? w0 : w1;
+            rom[q] = (uint8_t)(w >> (8 * (q & 7)));
+         }
+      }
+   }
+}
+
+__global__ __launch_bounds__(256) void mm_pattern_fill(uint8_t *rom, uint64_t first, uint64_t nbytes, int value, int ramp)
+{
+   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nbytes; i += stride) {
+      rom[first + i] = (uint8_t)(ramp ? value + (int)(i & 0xFF) * ramp : value);
+   }
+}
+
+// --------------------------------------------------------------------------
+// launch wrappers (called from mm_capi.hip)
+// --------------------------------------------------------------------------
+
+namespace mm {
+
+static int filter_grid(uint64_t nbytes, int threads_per_chunk_group)
+{
+   uint64_t nchunks = (nbytes + 15) / 16;
+   uint64_t blocks = (nchunks + (uint64_t)256 * threads_per_chunk_group - 1) / ((uint64_t)256 * threads_per_chunk_group);
+   uint64_t cap = 256 * 8;                     // 256 CUs x 8 resident workgroups
+   if (blocks > cap) {
+      blocks = cap;
+   }
+   return (int)(blocks ? blocks : 1);
+}
+
+bool choose_filter(const mmh_plan_desc &pl, FilterChoice *fc)
+{
+   const int L = (int)pl.L;
+   const uint32_t emask = pl.elem_bytes == 1 ? 0xFFu : 0xFFFFu;
+   auto adjacent = [&](int i) { return i >= 1 && pl.cmp_mask[i] != 0 && pl.bridge[i] == -1; };
+   fc->ncond = 0;
+   if (pl.elem_bytes == 1) {
+      for (int i = L - 1; i >= 2; --i) {
+         if (adjacent(i) && adjacent(i - 1)) {
+            fc->ncond = 2; fc->iA = (uint32_t)i;
+            fc->patA = ((uint32_t)pl.expected[i] & emask) * 0x01010101u;
+            fc->patB = ((uint32_t)pl.expected[i - 1] & emask) * 0x01010101u;
+            return true;
+         }
+      }
+   }
+   for (int i = L - 1; i >= 1; --i) {
+      if (adjacent(i)) {
+         fc->ncond = 1; fc->iA = (uint32_t)i;
+         fc->patA = ((uint32_t)pl.expected[i] & emask) * (pl.elem_bytes == 1 ? 0x01010101u : 0x00010001u);
+         fc->patB = 0;
+         return true;
+      }
+   }
+   return false;
+}
+
+void launch_filter(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc,
+                   uint64_t *cand, unsigned long long *cand_count, uint64_t cand_cap)
+{
+   MmFilterArgs a;
+   a.g = g; a.plan = pl; a.patA = fc.patA; a.patB = fc.patB; a.iA = fc.iA; a.ncond = fc.ncond;
+   a.cand = cand; a.cand_count = cand_count; a.cand_cap = cand_cap;
+   if (pl.elem_bytes == 1) {
+      int grid = filter_grid(g.nbytes, 4);
+      if (fc.ncond == 2) {
+         hipLaunchKernelGGL(mm_filter_u8<2>, dim3(grid), dim3(256), 0, st, a);
+      }
+      else {
+         hipLaunchKernelGGL(mm_filter_u8<1>, dim3(grid), dim3(256), 0, st, a);
+      }
+   }
+   else {
+      int grid = filter_grid(g.nbytes, 2);
+      hipLaunchKernelGGL(mm_filter_u16, dim3(grid), dim3(256), 0, st, a);
+   }
+}
+
+void launch_resolve(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const uint64_t *cand,
+                    const unsigned long long *cand_count, uint64_t cand_cap, uint64_t *out,
+                    unsigned long long *out_count, uint64_t out_cap, unsigned long long *tiles_walked,
+                    uint64_t base_offset, uint32_t max_candidates)
+{
+   MmResolveArgs a;
+   a.g = g; a.plan = pl; a.cand = cand; a.cand_count = cand_count; a.cand_cap = cand_cap;
+   a.out = out; a.out_count = out_count; a.out_cap = out_cap; a.tiles_walked = tiles_walked;
+   a.base_offset = base_offset; a.max_candidates = max_candidates;
+   hipLaunchKernelGGL(mm_resolve, dim3(512), dim3(64 * MM_RESOLVE_WAVES), 0, st, a);
+}
+
+void launch_chain_seq(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, uint64_t *out,
+                      unsigned long long *out_count, uint64_t out_cap, uint64_t base_offset)
+{
+   MmSeqArgs a;
+   a.g = g; a.plan = pl; a.out = out; a.out_count = out_count; a.out_cap = out_cap; a.base_offset = base_offset;
+   uint64_t ndom = g.whole ? 1 : g.nblocks * g.S;
+   uint64_t blocks = (ndom + 63) / 64;
+   if (blocks > 4096) {
+      blocks = 4096;
+   }
+   hipLaunchKernelGGL(mm_chain_seq, dim3((unsigned)blocks), dim3(64), 0, st, a);
+}
+
+void launch_rank_sort(hipStream_t st, const uint64_t *in, const unsigned long long *count, uint64_t cap,
+                      uint64_t max_n, uint64_t *out)
+{
+   hipLaunchKernelGGL(mm_rank_sort, dim3(64), dim3(256), 0, st, in, count, cap, max_n, out);
+}
+
+void launch_synth(hipStream_t st, uint8_t *rom, uint64_t nbytes, uint64_t seed, uint64_t base_offset)
+{
+   hipLaunchKernelGGL(mm_synth_fill, dim3(2048), dim3(256), 0, st, rom, nbytes, seed, base_offset);
+}
+
+void launch_pattern_fill(hipStream_t st, uint8_t *rom, uint64_t first, uint64_t nbytes, int value, int ramp)
+{
+   hipLaunchKernelGGL(mm_pattern_fill, dim3(256), dim3(256), 0, st, rom, first, nbytes, value, ramp);
+}
+
+} // namespace mm

@@ -211,7 +211,7 @@ class Ref:
             path = tmp
             cap = fb.size + 16
         else:
-            cap = (os.path.getsize(path) if os.path.exists(path) else 0) + 16
+            cap = min((os.path.getsize(path) if os.path.exists(path) else 0) + 16, 1 << 24)
         try:
             out = np.zeros(cap, np.uint64)
             n = self.lib.mmref_engine(elem_bytes, path.encode(), int(values is None), _ptr(kw, u32p), len(kw),
@@ -220,6 +220,8 @@ class Ref:
                                       abort_after, _ptr(out, u64p), cap)
             if n < 0:
                 raise self._err()
+            if n > cap:
+                raise RuntimeError("more matches than the binding's buffer holds")
             return out[:n].copy()
         finally:
             if tmp:

@@ -23,3 +23,33 @@ def load_golden(name):
 def oracle():
     from _oracle import Oracle
     return Oracle()
+
+
+def load_package():
+    """Import monkey-moore_amd/ (hyphenated directory) as module `monkey_moore_amd`."""
+    import importlib.util
+    if "monkey_moore_amd" in sys.modules:
+        return sys.modules["monkey_moore_amd"]
+    pkg_dir = os.path.join(ROOT, "monkey-moore_amd")
+    spec = importlib.util.spec_from_file_location(
+        "monkey_moore_amd", os.path.join(pkg_dir, "__init__.py"), submodule_search_locations=[pkg_dir])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["monkey_moore_amd"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(scope="session")
+def mm():
+    mod = load_package()
+    mod.build.build_all()
+    return mod
+
+
+@pytest.fixture(scope="session")
+def gpu_engine(mm):
+    if mm.device_count() == 0:
+        pytest.fail("no HIP device: the gpu tests need a real MI355X (there is no CPU fallback)")
+    eng = mm.Engine(0)
+    yield eng
+    eng.close()

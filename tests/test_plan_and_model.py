@@ -1,0 +1,103 @@
+"""CPU tests of the product's host logic and of the device ALGORITHM (via the
+Python model in tests/_model.py), against the golden vectors and the oracle.
+No GPU needed."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import _model
+from conftest import ROOT, load_golden
+
+
+def _plan(mm, c):
+    if c.get("values") is not None:
+        return mm.plan_value_scan(c["elem_bytes"], c["values"])
+    return mm.plan_relative(c["elem_bytes"], c["keyword"], c["wildcard"], c.get("char_seq"))
+
+
+def _rom(c, key="data"):
+    if key == "data":
+        dt = np.uint8 if c["elem_bytes"] == 1 else "<u2"
+        return np.array(c["data"], dtype=dt).view(np.uint8)
+    return np.array(c["file"], dtype=np.uint8)
+
+
+def test_library_exports_every_declared_symbol(mm):
+    """The C-ABI library loads (no GPU needed) and exports all of include/mmoore_hip.h."""
+    header = open(os.path.join(ROOT, "include", "mmoore_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(mmh_[a-z_]+)\s*\(", header)))
+    assert len(declared) >= 18
+    lib = C.CDLL(mm.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(mm.EXPORTS) == declared
+
+
+def test_no_gpu_means_loud_failure(mm):
+    if mm.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(mm.MMError) as e:
+        mm.Engine(0)
+    assert e.value.code == mm.MMH_E_DEVICE
+
+
+def test_plan_rejects_what_the_reference_rejects(mm):
+    for args in ((1, "a"), (1, "*a", ord("*")), (1, [0x3042, 0x41]), (1, "x" * 33), (1, "***", ord("*"))):
+        with pytest.raises(mm.MMError) as e:
+            mm.plan_relative(*args)
+        assert e.value.code == mm.MMH_E_PLAN
+    with pytest.raises(mm.MMError):
+        mm.plan_value_scan(1, [5])
+    with pytest.raises(mm.MMError):
+        mm.plan_relative(3, "abc")
+
+
+@pytest.mark.parametrize("case", load_golden("kat_matcher.json"), ids=lambda c: c["name"])
+def test_plan_sequential_model_matcher_kats(mm, case):
+    pl = _plan(mm, case)
+    rom = _rom(case)
+    g = _model.Geom(rom.size, case["elem_bytes"], pl.L)
+    assert _model.chain_seq(pl, rom, g) == case["expect"]
+    assert _model.fast_path(pl, rom, g, tile=8, seg=2) == case["expect"]
+
+
+@pytest.mark.parametrize("case", load_golden("kat_engine.json"), ids=lambda c: c["name"])
+def test_plan_models_engine_kats(mm, case):
+    pl = _plan(mm, case)
+    rom = _rom(case, "file")
+    for bs in case["block_sizes"]:
+        g = _model.Geom(rom.size, case["elem_bytes"], pl.L, bs, case["big_endian"])
+        assert _model.chain_seq(pl, rom, g) == case["expect"], bs
+        assert _model.fast_path(pl, rom, g, tile=8, seg=2) == case["expect"], bs
+
+
+def test_models_against_reference_vectors(mm):
+    """Host plan + sequential model + filter/resolver model == compiled reference."""
+    cases = load_golden("diff_search.json")
+    rng = np.random.default_rng(5)
+    n_fast = 0
+    for idx, c in enumerate(cases):
+        pl = _plan(mm, c)
+        rom = _rom(c)
+        g = _model.Geom(rom.size, c["elem_bytes"], pl.L)
+        assert _model.chain_seq(pl, rom, g) == c["expect"], c
+        if idx % 3 == 0:
+            tile = int(rng.choice([4, 8, 16, 64]))
+            seg = int(rng.choice([1, 2, 4]))
+            assert _model.fast_path(pl, rom, g, tile=tile, seg=seg) == c["expect"], (c, tile, seg)
+            n_fast += 1
+    assert n_fast > 500
+
+
+def test_models_against_reference_engine_vectors(mm):
+    cases = load_golden("diff_engine.json")
+    for idx, c in enumerate(cases):
+        pl = _plan(mm, c)
+        rom = _rom(c, "file")
+        g = _model.Geom(rom.size, c["elem_bytes"], pl.L, c["block_size"], c["big_endian"])
+        assert _model.chain_seq(pl, rom, g) == c["expect"], c
+        if idx % 2 == 0:
+            assert _model.fast_path(pl, rom, g, tile=16, seg=4) == c["expect"], c
