@@ -189,6 +189,9 @@ struct MmFilterArgs {
    uint64_t *cand;         // candidate byte offsets
    unsigned long long *cand_count;
    uint64_t cand_cap;
+   uint64_t ngroups;       // span kernel: number of whole 4 KiB groups it covers
+   uint32_t groups_per_span;
+   uint64_t edge_first;    // edge kernel: 16-byte chunks [edge_first, nchunks)
 };
 
 __device__ __forceinline__ uint4 mm_load_chunk(const uint8_t *rom, uint64_t nbytes, uint64_t byte0)
@@ -216,16 +219,18 @@ __device__ __forceinline__ uint32_t mm_f8_hits(uint32_t w, uint32_t wprev, uint3
 }
 
 template <int NCOND>
-__global__ __launch_bounds__(256) void mm_filter_u8(MmFilterArgs a)
+__global__ __launch_bounds__(256) void mm_filter_u8_edge(MmFilterArgs a)
 {
+   // bounds-checked version for the ragged end of the ROM (everything behind the
+   // last whole 4 KiB group); same arithmetic as the span kernel below
    const uint64_t nchunks = (a.g.nbytes + 15) / 16;
    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
    constexpr int UNROLL = 4;
    // same trip count in every lane: the ballots below must see whole waves
-   const uint64_t iters = (nchunks + stride * UNROLL - 1) / (stride * UNROLL);
+   const uint64_t iters = (nchunks - a.edge_first + stride * UNROLL - 1) / (stride * UNROLL);
 
    for (uint64_t it = 0; it < iters; it++) {
-      const uint64_t c0 = it * stride * UNROLL + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+      const uint64_t c0 = a.edge_first + it * stride * UNROLL + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
       uint4 w[UNROLL];
       uint32_t back[UNROLL];
       uint32_t hits[UNROLL][4];
@@ -277,6 +282,91 @@ __global__ __launch_bounds__(256) void mm_filter_u8(MmFilterArgs a)
                mm_append(a.cand, a.cand_count, a.cand_cap, want, off);
             }
          }
+      }
+   }
+}
+
+
+// The hot kernel.  The ROM is cut into 4 KiB groups; a wave owns SPANS of
+// consecutive groups and streams through them, 4 x dwordx4 per lane per group
+// (each wave instruction = 1 KiB contiguous).  The byte in front of a lane's
+// chunk comes from the neighbouring lane (DPP wave_shr:1), lane 0 takes it from
+// lane 63 of the previous piece (v_readlane) -- no second memory access.
+template <int NCOND>
+__device__ __forceinline__ uint32_t mm_f8_piece(const uint4 &w, uint32_t carry, uint32_t patA, uint32_t patB, uint32_t (&h)[4])
+{
+   // last dword of the previous 16 bytes: lane l-1's w.w, lane 0 keeps `carry`
+   uint32_t back = __builtin_amdgcn_update_dpp(carry, w.w, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+   uint32_t dbprev = mm_bytesub(back, back << 8);
+   h[0] = mm_f8_hits<NCOND>(w.x, back, dbprev, patA, patB);
+   h[1] = mm_f8_hits<NCOND>(w.y, w.x, dbprev, patA, patB);
+   h[2] = mm_f8_hits<NCOND>(w.z, w.y, dbprev, patA, patB);
+   h[3] = mm_f8_hits<NCOND>(w.w, w.z, dbprev, patA, patB);
+   return h[0] | h[1] | h[2] | h[3];
+}
+
+// rare path: the wave found at least one SWAR survivor in this group.  Kept
+// inline (a call would force the hit words and the kernel arguments through
+// scratch on every iteration) but as ONE loop over a 64-bit per-lane flag word.
+__device__ __forceinline__ uint32_t mm_f8_pack(const uint32_t (&h)[4])
+{
+   return (h[0] >> 7) | (h[1] >> 6) | (h[2] >> 5) | (h[3] >> 4);   // bit 8*b + k <-> dword k, byte b
+}
+
+__device__ __forceinline__ void mm_f8_survivors(const MmFilterArgs &a, uint64_t group, uint32_t lane, uint64_t bits)
+{
+   // bit (32*half + 8*b + 4*(u&1) + k) <-> piece u = 2*half + (u&1), dword k, byte b
+   while (__ballot(bits != 0) != 0) {
+      bool want = false;
+      uint64_t off = 0;
+      if (bits) {
+         int bit = __ffsll((long long)bits) - 1;
+         bits &= bits - 1;
+         int half = bit >> 5, b = (bit >> 3) & 3, u = 2 * half + ((bit >> 2) & 1), k = bit & 3;
+         int64_t t = (int64_t)(group * 4096 + (uint64_t)u * 1024 + lane * 16 + 4 * k + b);
+         int64_t o = t - (int64_t)a.iA;
+         if (mm_is_candidate(a.g, a.plan, o)) {
+            want = true;
+            off = (uint64_t)o;
+         }
+      }
+      mm_append(a.cand, a.cand_count, a.cand_cap, want, off);
+   }
+}
+
+template <int NCOND>
+__global__ __launch_bounds__(256) void mm_filter_u8(MmFilterArgs a)
+{
+   const uint32_t lane = threadIdx.x & 63;
+   const uint64_t wave = __builtin_amdgcn_readfirstlane((uint32_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+   const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+   const uint64_t gps = a.groups_per_span;
+   const uint4 *rom4 = reinterpret_cast<const uint4 *>(a.g.rom);
+   const uint32_t *rom1 = reinterpret_cast<const uint32_t *>(a.g.rom);
+
+   for (uint64_t g0 = wave * gps; g0 < a.ngroups; g0 += nwaves * gps) {
+      const uint64_t g1 = g0 + gps < a.ngroups ? g0 + gps : a.ngroups;
+      uint32_t carry = g0 ? rom1[g0 * 1024 - 1] : 0u;          // dword in front of the span (wave uniform)
+      const uint4 *p = rom4 + g0 * 256 + lane;
+      uint4 w0 = p[0], w1 = p[64], w2 = p[128], w3 = p[192];
+      for (uint64_t g = g0; g < g1; g++) {
+         // issue the next group's loads before touching this one's data
+         const uint64_t gn = g + 1 < g1 ? g + 1 : g;
+         const uint4 *pn = rom4 + gn * 256 + lane;
+         uint4 n0 = pn[0], n1 = pn[64], n2 = pn[128], n3 = pn[192];
+
+         uint32_t h0[4], h1[4], h2[4], h3[4];
+         uint32_t any = mm_f8_piece<NCOND>(w0, carry, a.patA, a.patB, h0);
+         any |= mm_f8_piece<NCOND>(w1, __builtin_amdgcn_readlane(w0.w, 63), a.patA, a.patB, h1);
+         any |= mm_f8_piece<NCOND>(w2, __builtin_amdgcn_readlane(w1.w, 63), a.patA, a.patB, h2);
+         any |= mm_f8_piece<NCOND>(w3, __builtin_amdgcn_readlane(w2.w, 63), a.patA, a.patB, h3);
+         carry = __builtin_amdgcn_readlane(w3.w, 63);
+         if (__ballot(any != 0) != 0) {
+            uint64_t bits = (uint64_t)(mm_f8_pack(h0) | (mm_f8_pack(h1) << 4)) |
+                            ((uint64_t)(mm_f8_pack(h2) | (mm_f8_pack(h3) << 4)) << 32);
+            mm_f8_survivors(a, g, lane, bits);
+         }
+         w0 = n0; w1 = n1; w2 = n2; w3 = n3;
       }
    }
 }
@@ -754,13 +844,31 @@ void launch_filter(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, con
    MmFilterArgs a;
    a.g = g; a.plan = pl; a.patA = fc.patA; a.patB = fc.patB; a.iA = fc.iA; a.ncond = fc.ncond;
    a.cand = cand; a.cand_count = cand_count; a.cand_cap = cand_cap;
+   a.ngroups = 0; a.groups_per_span = 16; a.edge_first = 0;
    if (pl.elem_bytes == 1) {
-      int grid = filter_grid(g.nbytes, 4);
-      if (fc.ncond == 2) {
-         hipLaunchKernelGGL(mm_filter_u8<2>, dim3(grid), dim3(256), 0, st, a);
+      // whole 4 KiB groups go to the span kernel, the ragged end to the bounds-checked one
+      a.ngroups = g.nbytes / 4096;
+      a.edge_first = a.ngroups * 256;
+      if (a.ngroups) {
+         uint64_t spans = (a.ngroups + a.groups_per_span - 1) / a.groups_per_span;
+         uint64_t blocks = (spans + 3) / 4;
+         if (blocks > 256 * 8) {
+            blocks = 256 * 8;
+         }
+         if (fc.ncond == 2) {
+            hipLaunchKernelGGL(mm_filter_u8<2>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+         }
+         else {
+            hipLaunchKernelGGL(mm_filter_u8<1>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+         }
       }
-      else {
-         hipLaunchKernelGGL(mm_filter_u8<1>, dim3(grid), dim3(256), 0, st, a);
+      if (a.edge_first * 16 < g.nbytes) {
+         if (fc.ncond == 2) {
+            hipLaunchKernelGGL(mm_filter_u8_edge<2>, dim3(1), dim3(256), 0, st, a);
+         }
+         else {
+            hipLaunchKernelGGL(mm_filter_u8_edge<1>, dim3(1), dim3(256), 0, st, a);
+         }
       }
    }
    else {

@@ -1,0 +1,114 @@
+// stream_probe.hip -- read-bandwidth ceilings on the box for the access patterns
+// the filter kernel can use.  Dev tool (not part of the product).
+//   hipcc --offload-arch=gfx950 -O3 tools/stream_probe.hip -o /tmp/stream_probe && /tmp/stream_probe [GiB]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+// pattern A: grid-stride, one 16B chunk per lane per load, UNROLL loads stride apart
+template <int UNROLL>
+__global__ __launch_bounds__(256) void read_gridstride(const uint4 *p, uint64_t nchunks, uint32_t *sink)
+{
+   uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+   uint32_t acc = 0;
+   for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c + stride * (UNROLL - 1) < nchunks; c += stride * UNROLL) {
+      uint4 w[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++) w[u] = p[c + stride * u];
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++) acc ^= w[u].x ^ w[u].y ^ w[u].z ^ w[u].w;
+   }
+   if (acc == 0x12345678) sink[0] = acc;
+}
+
+// pattern B: each wave streams a contiguous span, UNROLL consecutive 1 KiB pieces per iteration
+template <int UNROLL>
+__global__ __launch_bounds__(256) void read_wavespan(const uint4 *p, uint64_t nchunks, uint64_t span_chunks, uint32_t *sink)
+{
+   uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+   uint32_t lane = threadIdx.x & 63;
+   uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+   uint32_t acc = 0;
+   for (uint64_t s = wave * span_chunks; s < nchunks; s += nwaves * span_chunks) {
+      uint64_t e = s + span_chunks < nchunks ? s + span_chunks : nchunks;
+      for (uint64_t c = s + lane; c + 64 * (UNROLL - 1) < e; c += 64 * UNROLL) {
+         uint4 w[UNROLL];
+#pragma unroll
+         for (int u = 0; u < UNROLL; u++) w[u] = p[c + 64 * u];
+#pragma unroll
+         for (int u = 0; u < UNROLL; u++) acc ^= w[u].x ^ w[u].y ^ w[u].z ^ w[u].w;
+      }
+   }
+   if (acc == 0x12345678) sink[0] = acc;
+}
+
+// pattern A plus the 4-byte look-back load the v1 filter does
+template <int UNROLL>
+__global__ __launch_bounds__(256) void read_gridstride_back(const uint4 *p, uint64_t nchunks, uint32_t *sink)
+{
+   uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+   uint32_t acc = 0;
+   const uint32_t *p32 = reinterpret_cast<const uint32_t *>(p);
+   for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; c + stride * (UNROLL - 1) < nchunks; c += stride * UNROLL) {
+      uint4 w[UNROLL]; uint32_t b[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++) { w[u] = p[c + stride * u]; b[u] = p32[(c + stride * u) * 4 - 1]; }
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++) acc ^= w[u].x ^ w[u].y ^ w[u].z ^ w[u].w ^ b[u];
+   }
+   if (acc == 0x12345678) sink[0] = acc;
+}
+
+template <class F>
+void timeit(const char *name, uint64_t bytes, F launch)
+{
+   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+   for (int i = 0; i < 3; i++) launch();
+   CK(hipDeviceSynchronize());
+   float best = 1e9, sum = 0; int n = 10;
+   for (int i = 0; i < n; i++) {
+      CK(hipEventRecord(a)); launch(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+      float ms; CK(hipEventElapsedTime(&ms, a, b)); best = ms < best ? ms : best; sum += ms;
+   }
+   printf("%-44s avg %.3f ms  %.0f GB/s   best %.3f ms  %.0f GB/s\n", name, sum / n, bytes / (sum / n) / 1e6, best, bytes / best / 1e6);
+}
+
+__global__ void fill(uint4 *p, uint64_t n) {
+   uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+      uint32_t x = (uint32_t)(i * 2654435761u);
+      p[i] = make_uint4(x, x ^ 0x9e3779b9u, x * 31u, x + 7u);
+   }
+}
+
+int main(int argc, char **argv)
+{
+   double gib = argc > 1 ? atof(argv[1]) : 4.0;
+   uint64_t bytes = (uint64_t)(gib * (1ull << 30));
+   uint64_t nchunks = bytes / 16;
+   uint4 *p; uint32_t *sink;
+   CK(hipMalloc(&p, bytes)); CK(hipMalloc(&sink, 64));
+   hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, p, nchunks);
+   CK(hipDeviceSynchronize());
+   for (int grid : {1024, 2048, 4096, 8192}) {
+      char nm[128];
+      snprintf(nm, sizeof nm, "gridstride u1 grid %d", grid);
+      timeit(nm, bytes, [&] { hipLaunchKernelGGL(read_gridstride<1>, dim3(grid), dim3(256), 0, 0, p, nchunks, sink); });
+      snprintf(nm, sizeof nm, "gridstride u4 grid %d", grid);
+      timeit(nm, bytes, [&] { hipLaunchKernelGGL(read_gridstride<4>, dim3(grid), dim3(256), 0, 0, p, nchunks, sink); });
+      snprintf(nm, sizeof nm, "gridstride u8 grid %d", grid);
+      timeit(nm, bytes, [&] { hipLaunchKernelGGL(read_gridstride<8>, dim3(grid), dim3(256), 0, 0, p, nchunks, sink); });
+      snprintf(nm, sizeof nm, "gridstride+back u4 grid %d", grid);
+      timeit(nm, bytes, [&] { hipLaunchKernelGGL(read_gridstride_back<4>, dim3(grid), dim3(256), 0, 0, p, nchunks, sink); });
+      for (uint64_t span_kb : {16, 64, 512}) {
+         snprintf(nm, sizeof nm, "wavespan u4 span %lluK grid %d", (unsigned long long)span_kb, grid);
+         timeit(nm, bytes, [&] { hipLaunchKernelGGL(read_wavespan<4>, dim3(grid), dim3(256), 0, 0, p, nchunks, span_kb * 64, sink); });
+      }
+      snprintf(nm, sizeof nm, "wavespan u8 span 64K grid %d", grid);
+      timeit(nm, bytes, [&] { hipLaunchKernelGGL(read_wavespan<8>, dim3(grid), dim3(256), 0, 0, p, nchunks, 64 * 64, sink); });
+   }
+   return 0;
+}
