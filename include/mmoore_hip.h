@@ -125,7 +125,7 @@ int mmh_set_engine(mmh_ctx *ctx, int engine);
  * the scan's stream): [0] filter kernel, [1] resolve, [2] sort+copy, [3] total. */
 int mmh_last_timings(mmh_ctx *ctx, float *ms4);
 /* Counters of the last scan: [0] candidates, [1] matches, [2] resolver tiles walked,
- * [3] path taken (0 fast, 1 sequential fallback). */
+ * [3] path taken (0 filter + resolver, 1 sequential engine, 2 filter + resolver + hard resolver). */
 int mmh_last_counters(mmh_ctx *ctx, uint64_t *c4);
 
 #ifdef __cplusplus

@@ -199,4 +199,4 @@ class Engine:
     def counters(self):
         c = (C.c_uint64 * 4)()
         _check(lib().mmh_last_counters(self._h, c))
-        return dict(candidates=int(c[0]), matches=int(c[1]), tiles_walked=int(c[2]), sequential=int(c[3]))
+        return dict(candidates=int(c[0]), matches=int(c[1]), tiles_walked=int(c[2]), path=int(c[3]))

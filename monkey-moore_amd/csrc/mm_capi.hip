@@ -21,9 +21,8 @@ namespace {
 
 thread_local std::string g_error;
 
-constexpr uint64_t kHeaderWords = 4;                 // device counters in front of the sorted list
-constexpr uint64_t kPrefetchWords = 8192;            // one D2H copy covers this many 64-bit words
-constexpr uint64_t kMaxRankSort = 65536;
+constexpr uint64_t kHeaderWords = 8;                 // counters in front of the ordered list (pinned host memory)
+constexpr uint32_t kMaxRankSort = 16384;             // longest list the device orders
 constexpr uint64_t kInitialCap = 1u << 20;
 
 bool hip_ok(hipError_t e, const char *what)
@@ -68,9 +67,15 @@ struct mmh_ctx {
    uint64_t *d_cand = nullptr;      // candidate byte offsets
    uint64_t cand_cap = 0;
    uint64_t *d_out = nullptr;       // unordered matches
-   uint64_t *d_result = nullptr;    // [kHeaderWords counters][sorted matches]
    uint64_t out_cap = 0;
-   uint64_t *h_pinned = nullptr;    // kPrefetchWords words
+   unsigned long long *d_ctrl = nullptr;   // counters + arrival tickets, zeroed per scan (mm::ResolveBuffers)
+   uint64_t *d_hard_off = nullptr;
+   uint64_t *d_hard_hi = nullptr;
+   uint32_t *d_hard_set = nullptr;
+   uint32_t *d_hard_slot = nullptr;
+   uint8_t *d_scratch = nullptr;    // tile maps of hard candidates
+   uint32_t *d_partials = nullptr;  // rank sort partial counts
+   uint64_t *h_result = nullptr;    // pinned: [kHeaderWords counters][kMaxRankSort ordered matches], written by the device
 
    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
    int engine = 0;
@@ -80,29 +85,27 @@ struct mmh_ctx {
 
 namespace {
 
-unsigned long long *counter(mmh_ctx *c, int i) { return reinterpret_cast<unsigned long long *>(c->d_result) + i; }
-
 int ensure_workspace(mmh_ctx *c, uint64_t out_cap)
 {
    HIP_TRY(hipSetDevice(c->device));
    if (!c->d_cand) {
       c->cand_cap = kInitialCap;
       HIP_TRY(hipMalloc(&c->d_cand, c->cand_cap * sizeof(uint64_t)));
-   }
-   if (!c->h_pinned) {
-      HIP_TRY(hipHostMalloc(&c->h_pinned, kPrefetchWords * sizeof(uint64_t), hipHostMallocDefault));
+      HIP_TRY(hipMalloc(&c->d_ctrl, mm::ctrl_bytes()));
+      HIP_TRY(hipMalloc(&c->d_hard_off, mm::hard_cap() * sizeof(uint64_t)));
+      HIP_TRY(hipMalloc(&c->d_hard_hi, mm::hard_cap() * sizeof(uint64_t)));
+      HIP_TRY(hipMalloc(&c->d_hard_set, mm::hard_cap() * sizeof(uint32_t)));
+      HIP_TRY(hipMalloc(&c->d_hard_slot, mm::hard_cap() * sizeof(uint32_t)));
+      HIP_TRY(hipMalloc(&c->d_scratch, mm::hard_scratch_bytes()));
+      HIP_TRY(hipMalloc(&c->d_partials, mm::rank_partials_bytes(kMaxRankSort)));
+      HIP_TRY(hipHostMalloc(&c->h_result, (kHeaderWords + kMaxRankSort) * sizeof(uint64_t), hipHostMallocDefault));
    }
    if (out_cap > c->out_cap) {
       if (c->d_out) {
          HIP_TRY(hipFree(c->d_out));
          c->d_out = nullptr;
       }
-      if (c->d_result) {
-         HIP_TRY(hipFree(c->d_result));
-         c->d_result = nullptr;
-      }
       HIP_TRY(hipMalloc(&c->d_out, out_cap * sizeof(uint64_t)));
-      HIP_TRY(hipMalloc(&c->d_result, (out_cap + kHeaderWords) * sizeof(uint64_t)));
       c->out_cap = out_cap;
    }
    for (auto &e : c->ev) {
@@ -182,8 +185,14 @@ extern "C" void mmh_destroy(mmh_ctx *c)
    release_rom(c);
    if (c->d_cand) (void)hipFree(c->d_cand);
    if (c->d_out) (void)hipFree(c->d_out);
-   if (c->d_result) (void)hipFree(c->d_result);
-   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+   if (c->d_ctrl) (void)hipFree(c->d_ctrl);
+   if (c->d_hard_off) (void)hipFree(c->d_hard_off);
+   if (c->d_hard_hi) (void)hipFree(c->d_hard_hi);
+   if (c->d_hard_set) (void)hipFree(c->d_hard_set);
+   if (c->d_hard_slot) (void)hipFree(c->d_hard_slot);
+   if (c->d_scratch) (void)hipFree(c->d_scratch);
+   if (c->d_partials) (void)hipFree(c->d_partials);
+   if (c->h_result) (void)hipHostFree(c->h_result);
    for (auto &e : c->ev) {
       if (e) (void)hipEventDestroy(e);
    }
@@ -321,42 +330,52 @@ extern "C" int mmh_rom_fill(mmh_ctx *c, uint64_t first_byte, uint64_t nbytes, in
 namespace {
 
 struct Outcome {
-   uint64_t candidates = 0;
-   uint64_t matches = 0;
+   uint64_t candidates = 0;         // filter survivors (0 on the sequential path)
+   uint64_t listed = 0;             // keys in d_out: result slots (fast path) or appended matches (sequential)
+   uint64_t matches = 0;            // valid when sorted_on_device
    uint64_t tiles = 0;
+   uint32_t hard = 0;
+   bool hard_overflow = false;
    bool sorted_on_device = false;
 };
 
-// enqueue [zero counters] -> engine kernels -> rank sort -> D2H prefetch, then wait
+// enqueue [zero counters] -> engine kernels -> ordering into pinned host memory, then wait
 int run_pipeline(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, const mm::FilterChoice &fc, bool sequential,
                  uint64_t base_offset, uint32_t max_candidates, Outcome *oc)
 {
    hipStream_t st = c->stream;
-   HIP_TRY(hipMemsetAsync(c->d_result, 0, kHeaderWords * sizeof(uint64_t), st));
+   mm::ResolveBuffers rb;
+   rb.cand = c->d_cand; rb.cand_cap = c->cand_cap; rb.out = c->d_out; rb.out_cap = c->out_cap; rb.ctrl = c->d_ctrl;
+   rb.hard_off = c->d_hard_off; rb.hard_hi = c->d_hard_hi; rb.hard_set = c->d_hard_set; rb.hard_slot = c->d_hard_slot;
+   rb.scratch = c->d_scratch;
+   const int count_index = sequential ? 1 : 0;
+
+   c->h_result[6] = 0;                         // mm_rank_scatter publishes "matches + 1" here
+   HIP_TRY(hipMemsetAsync(c->d_ctrl, 0, mm::ctrl_bytes(), st));
    HIP_TRY(hipEventRecord(c->ev[0], st));
    if (!sequential) {
-      mm::launch_filter(st, g, pl, fc, c->d_cand, counter(c, 0), c->cand_cap);
+      mm::launch_filter(st, g, pl, fc, c->d_cand, c->d_ctrl + 0, c->cand_cap);
    }
    HIP_TRY(hipEventRecord(c->ev[1], st));
    if (!sequential) {
-      mm::launch_resolve(st, g, pl, c->d_cand, counter(c, 0), c->cand_cap, c->d_out, counter(c, 1), c->out_cap,
-                         counter(c, 2), base_offset, max_candidates);
+      mm::launch_resolve(st, g, pl, rb, base_offset, max_candidates);
    }
    else {
-      mm::launch_chain_seq(st, g, pl, c->d_out, counter(c, 1), c->out_cap, base_offset);
+      mm::launch_chain_seq(st, g, pl, c->d_out, c->d_ctrl + 1, c->out_cap, base_offset);
    }
    HIP_TRY(hipEventRecord(c->ev[2], st));
-   mm::launch_rank_sort(st, c->d_out, counter(c, 1), c->out_cap, kMaxRankSort, c->d_result + kHeaderWords);
+   mm::launch_rank_sort(st, c->d_out, c->d_ctrl, count_index, c->out_cap, kMaxRankSort, c->d_partials, c->h_result);
    HIP_TRY(hipGetLastError());
-   uint64_t prefetch = std::min<uint64_t>(kPrefetchWords, c->out_cap + kHeaderWords);
-   HIP_TRY(hipMemcpyAsync(c->h_pinned, c->d_result, prefetch * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
    HIP_TRY(hipEventRecord(c->ev[3], st));
    HIP_TRY(hipStreamSynchronize(st));
 
-   oc->candidates = c->h_pinned[0];
-   oc->matches = c->h_pinned[1];
-   oc->tiles = c->h_pinned[2];
-   oc->sorted_on_device = oc->matches <= kMaxRankSort && oc->matches <= c->out_cap;
+   oc->candidates = c->h_result[0];
+   oc->listed = c->h_result[count_index];
+   oc->tiles = c->h_result[2];
+   oc->hard = (uint32_t)(c->h_result[3] & 0xFFFFFFFFu);
+   oc->hard_overflow = (c->h_result[3] >> 32) != 0;
+   oc->sorted_on_device = oc->listed <= kMaxRankSort && oc->listed <= c->out_cap;
+   oc->matches = c->h_result[6] ? c->h_result[6] - 1 : oc->listed;
    (void)hipEventElapsedTime(&c->timings[0], c->ev[0], c->ev[1]);
    (void)hipEventElapsedTime(&c->timings[1], c->ev[1], c->ev[2]);
    (void)hipEventElapsedTime(&c->timings[2], c->ev[2], c->ev[3]);
@@ -421,12 +440,12 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
       if (rc != MMH_OK) {
          return rc;
       }
-      if (!sequential && (oc.candidates > c->cand_cap || oc.candidates > max_candidates)) {
-         sequential = true;                       // too dense for the certificate resolver
+      if (!sequential && (oc.candidates > c->cand_cap || oc.candidates > max_candidates || oc.hard_overflow)) {
+         sequential = true;                       // too dense / too long for the per-candidate resolvers
          continue;
       }
-      if (oc.matches > c->out_cap) {
-         rc = ensure_workspace(c, oc.matches + oc.matches / 8 + 1024);
+      if (oc.listed > c->out_cap) {
+         rc = ensure_workspace(c, oc.listed + oc.listed / 8 + 1024);
          if (rc != MMH_OK) {
             return rc;
          }
@@ -434,10 +453,21 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
       }
       break;
    }
+
+   // lists too long for the device rank sort: fetch, drop the "not a match" slots and
+   // order on the host, as search_engine.cpp:193-197 does
+   std::vector<uint64_t> long_list;
+   if (!oc.sorted_on_device) {
+      long_list.resize(oc.listed);
+      HIP_TRY(hipMemcpy(long_list.data(), c->d_out, oc.listed * sizeof(uint64_t), hipMemcpyDeviceToHost));
+      long_list.erase(std::remove(long_list.begin(), long_list.end(), ~0ull), long_list.end());
+      std::sort(long_list.begin(), long_list.end());
+      oc.matches = long_list.size();
+   }
    c->counters[0] = oc.candidates;
    c->counters[1] = oc.matches;
    c->counters[2] = oc.tiles;
-   c->counters[3] = sequential ? 1 : 0;
+   c->counters[3] = sequential ? 1 : (oc.hard ? 2 : 0);
 
    *out_count = oc.matches;
    if (oc.matches > cap) {
@@ -449,17 +479,10 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
       return MMH_OK;
    }
    if (oc.sorted_on_device) {
-      uint64_t have = std::min<uint64_t>(oc.matches, kPrefetchWords - kHeaderWords);
-      std::memcpy(out, c->h_pinned + kHeaderWords, have * sizeof(uint64_t));
-      if (oc.matches > have) {
-         HIP_TRY(hipMemcpy(out + have, c->d_result + kHeaderWords + have, (oc.matches - have) * sizeof(uint64_t),
-                           hipMemcpyDeviceToHost));
-      }
+      std::memcpy(out, c->h_result + kHeaderWords, oc.matches * sizeof(uint64_t));
    }
    else {
-      // very long match lists: order on the host, as search_engine.cpp:193-197 does
-      HIP_TRY(hipMemcpy(out, c->d_out, oc.matches * sizeof(uint64_t), hipMemcpyDeviceToHost));
-      std::sort(out, out + oc.matches);
+      std::memcpy(out, long_list.data(), oc.matches * sizeof(uint64_t));
    }
    return MMH_OK;
 }

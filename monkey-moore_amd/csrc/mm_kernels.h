@@ -19,14 +19,39 @@ bool choose_filter(const mmh_plan_desc &pl, FilterChoice *fc);
 
 void launch_filter(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc,
                    uint64_t *cand, unsigned long long *cand_count, uint64_t cand_cap);
-void launch_resolve(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const uint64_t *cand,
-                    const unsigned long long *cand_count, uint64_t cand_cap, uint64_t *out,
-                    unsigned long long *out_count, uint64_t out_cap, unsigned long long *tiles_walked,
+
+// Device buffers of one scan.  ctrl (zeroed before every scan) is
+//   u64 [0] candidates (filter)          [1] matches appended by mm_chain_seq
+//       [2] unused                       [3] lo: hard candidates, hi: overflow flag
+//       [4..7] spare                     [8..8+stat stripes) tiles walked, striped
+//   then unsigned int done[hard_cap()]   arrival tickets of mm_hard_resolve
+// Filter + resolver path: out[i] is the result SLOT of candidate i (reported value or
+// ~0 = not a match).  Sequential path: out is an append list of ctrl[1] matches.
+struct ResolveBuffers {
+   uint64_t *cand;
+   uint64_t cand_cap;
+   uint64_t *out;
+   uint64_t out_cap;
+   unsigned long long *ctrl;
+   uint64_t *hard_off;
+   uint64_t *hard_hi;
+   uint32_t *hard_set;
+   uint32_t *hard_slot;
+   uint8_t *scratch;
+};
+
+void launch_resolve(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const ResolveBuffers &rb,
                     uint64_t base_offset, uint32_t max_candidates);
+size_t hard_scratch_bytes();
+size_t hard_cap();
+size_t ctrl_bytes();
+size_t rank_partials_bytes(uint32_t max_n);
 void launch_chain_seq(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, uint64_t *out,
                       unsigned long long *out_count, uint64_t out_cap, uint64_t base_offset);
-void launch_rank_sort(hipStream_t st, const uint64_t *in, const unsigned long long *count, uint64_t cap,
-                      uint64_t max_n, uint64_t *out);
+// orders the ctrl[count_index] keys of `in` into host_result[8..] (pinned host memory) and
+// publishes the counters in host_result[0..8); see mm_rank_scatter
+void launch_rank_sort(hipStream_t st, const uint64_t *in, const unsigned long long *ctrl, int count_index, uint64_t cap,
+                      uint32_t max_n, uint32_t *partials, uint64_t *host_result);
 void launch_synth(hipStream_t st, uint8_t *rom, uint64_t nbytes, uint64_t seed, uint64_t base_offset);
 void launch_pattern_fill(hipStream_t st, uint8_t *rom, uint64_t first, uint64_t nbytes, int value, int ramp);
 

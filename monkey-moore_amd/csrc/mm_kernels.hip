@@ -464,215 +464,7 @@ __global__ __launch_bounds__(256) void mm_filter_u16(MmFilterArgs a)
    }
 }
 
-// --------------------------------------------------------------------------
-// certificate resolver: is candidate h on the chain of its domain?
-// --------------------------------------------------------------------------
-//
-// Chain state = the next position the reference will visit.  Every jump is in
-// [1, D] with D = L-1, so at any boundary a the next visited position lies in
-// [a, a+D) and is identified by its PHASE (position mod D).  Processing position
-// j moves "phase j mod D" to "phase (j + J(j)) mod D" and leaves the others
-// alone; a jump of exactly D changes nothing.  A tile's effect is therefore a
-// map Z_D -> Z_D, computed as 64 lane-local maps (sequential inside a lane's
-// 64 positions) chained through LDS.
-//
-// For a candidate at j_c we keep the set A of phases that lead to visiting it,
-// starting with {j_c mod D} at the frontier j_c, and pull it back tile by tile:
-// A' = {e : tile_map(e) in A}.  A' empty -> not visited, A' = everything ->
-// visited (no matter how the chain entered), otherwise continue; at the domain
-// start the chain is in phase 0 (monkey_moore.cpp:329).
-
-constexpr int MM_SEG = 64;                    // positions per lane
-constexpr int MM_TILE = 64 * MM_SEG;          // positions per tile
-constexpr int MM_RESOLVE_WAVES = 4;
-
-struct MmResolveArgs {
-   MmGeom g;
-   mmh_plan_desc plan;
-   const uint64_t *cand;
-   const unsigned long long *cand_count;
-   uint64_t cand_cap;
-   uint64_t *out;
-   unsigned long long *out_count;
-   uint64_t out_cap;
-   unsigned long long *tiles_walked;
-   uint64_t base_offset;                      // added to reported byte offsets
-   uint32_t max_candidates;                   // above this the host falls back to mm_chain_seq
-};
-
-struct MmResolveLds {
-   int32_t expected[MMH_MAX_KEYWORD];
-   uint32_t cmp_mask[MMH_MAX_KEYWORD];
-   int8_t bridge[MMH_MAX_KEYWORD];
-   uint8_t wst[MMH_MAX_KEYWORD];
-   uint8_t skip8[512];                                                 // dense bad-character table (8-bit)
-   uint8_t maps[MM_RESOLVE_WAVES][64][MMH_MAX_KEYWORD];                // lane maps
-   uint8_t tile[MM_RESOLVE_WAVES][(MM_TILE + MMH_MAX_KEYWORD) * 2 + 16];
-};
-
-__global__ __launch_bounds__(256) void mm_resolve(MmResolveArgs a)
-{
-   __shared__ MmResolveLds lds;
-   const int L = (int)a.plan.L;
-   const int D = L - 1;
-   const int S = (int)a.g.S;
-   const int wave = threadIdx.x >> 6;
-   const int lane = threadIdx.x & 63;
-
-   for (int i = threadIdx.x; i < MMH_MAX_KEYWORD; i += blockDim.x) {
-      lds.expected[i] = a.plan.expected[i];
-      lds.cmp_mask[i] = a.plan.cmp_mask[i];
-      lds.bridge[i] = a.plan.bridge[i];
-      lds.wst[i] = a.plan.wst[i];
-   }
-   if (S == 1) {
-      for (int i = threadIdx.x; i < 512; i += blockDim.x) {
-         int s = a.plan.default_skip;
-         s = s < 1 ? 1 : s;
-         lds.skip8[i] = (uint8_t)s;
-      }
-      __syncthreads();
-      for (int i = threadIdx.x; i < (int)a.plan.n_skip; i += blockDim.x) {
-         int s = a.plan.skip_val[i];
-         s = s < 1 ? 1 : s;
-         lds.skip8[a.plan.skip_diff[i] + 255] = (uint8_t)s;
-      }
-   }
-   __syncthreads();
-
-   unsigned long long ncand = *a.cand_count;
-   if (ncand > a.cand_cap || ncand > a.max_candidates) {
-      return;                                  // dense input: the host runs the sequential engine instead
-   }
-   const uint64_t nwaves = (uint64_t)gridDim.x * MM_RESOLVE_WAVES;
-   uint8_t *tile = lds.tile[wave];
-   unsigned long long walked = 0;
-
-   for (uint64_t ci = (uint64_t)blockIdx.x * MM_RESOLVE_WAVES + wave; ci < ncand; ci += nwaves) {
-      const uint64_t o = a.cand[ci];
-      uint64_t b; uint32_t p; int64_t jc;
-      mm_locate(a.g, o, &b, &p, &jc);          // candidates were located by the filter already
-      const uint64_t start = mm_domain_start(a.g, b, p);
-
-      const uint32_t full = D >= 32 ? 0xFFFFFFFFu : ((1u << D) - 1u);
-      uint32_t A = 1u << (uint32_t)(jc % D);
-      int64_t hi = jc;
-      bool visited = false;
-      while (true) {
-         if (hi == 0) {
-            visited = (A & 1u) != 0;
-            break;
-         }
-         const int64_t lo = ((hi - 1) / MM_TILE) * MM_TILE;
-         const int npos = (int)(hi - lo);
-         // stage the tile's bytes: elements [lo, hi + L - 1)
-         const int nstage = (npos + L - 1) * S;
-         const uint8_t *src = a.g.rom + start + (uint64_t)lo * S;
-         if ((((uintptr_t)src) & 3) == 0) {
-            const uint32_t *s4 = reinterpret_cast<const uint32_t *>(src);
-            uint32_t *d4 = reinterpret_cast<uint32_t *>(tile);
-            int nw = nstage >> 2;
-            for (int k = lane; k < nw; k += 64) {
-               d4[k] = s4[k];
-            }
-            for (int k = (nw << 2) + lane; k < nstage; k += 64) {
-               tile[k] = src[k];
-            }
-         }
-         else {
-            for (int k = lane; k < nstage; k += 64) {
-               tile[k] = src[k];
-            }
-         }
-         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-         __builtin_amdgcn_wave_barrier();
-
-         // lane-local map of positions [lo + lane*SEG, ...) below hi
-         uint8_t m[MMH_MAX_KEYWORD];
-#pragma unroll
-         for (int e = 0; e < MMH_MAX_KEYWORD; e++) {
-            m[e] = (uint8_t)e;
-         }
-         const int seg0 = lane * MM_SEG;
-         const int seg1 = min(seg0 + MM_SEG, npos);
-         int r = (int)((lo + seg0) % D);
-         const bool be = a.g.big_endian != 0;
-         for (int q = seg0; q < seg1; q++) {
-            int J = (int)a.plan.match_jump;
-            for (int i = L - 1; i >= 0; --i) {
-               int ia = (q + i) * S, ib = (q + i + lds.bridge[i]) * S;
-               int c, pv;
-               if (S == 1) {
-                  c = tile[ia];
-                  pv = tile[ib];
-               }
-               else {
-                  c = be ? (tile[ia] << 8 | tile[ia + 1]) : (tile[ia + 1] << 8 | tile[ia]);
-                  pv = be ? (tile[ib] << 8 | tile[ib + 1]) : (tile[ib + 1] << 8 | tile[ib]);
-               }
-               int d = c - pv;
-               if (((uint32_t)(d ^ lds.expected[i]) & lds.cmp_mask[i]) != 0) {
-                  int s;
-                  if (S == 1) {
-                     s = lds.skip8[d + 255];
-                  }
-                  else {
-                     s = mm_skip_sparse(a.plan, d);
-                     s = s < 1 ? 1 : s;
-                  }
-                  int w = lds.wst[i];
-                  J = s < w ? s : w;
-                  break;
-               }
-            }
-            if (J != D) {
-               int r2 = r + J;
-               r2 = r2 >= D ? r2 - D : r2;
-#pragma unroll
-               for (int e = 0; e < MMH_MAX_KEYWORD; e++) {
-                  m[e] = (m[e] == r) ? (uint8_t)r2 : m[e];
-               }
-            }
-            r = (r + 1 == D) ? 0 : r + 1;
-         }
-#pragma unroll
-         for (int e = 0; e < MMH_MAX_KEYWORD; e++) {
-            lds.maps[wave][lane][e] = m[e];
-         }
-         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-         __builtin_amdgcn_wave_barrier();
-
-         // lane e chases entry phase e through the 64 lane maps
-         int v = lane < D ? lane : 0;
-         const int nseg = (npos + MM_SEG - 1) / MM_SEG;
-         for (int s = 0; s < nseg; s++) {
-            v = lds.maps[wave][s][v];
-         }
-         uint32_t Anew = (uint32_t)__ballot(lane < D && ((A >> v) & 1u));
-         __builtin_amdgcn_wave_barrier();
-         walked++;
-         if (Anew == full) {
-            visited = true;
-            break;
-         }
-         if (Anew == 0) {
-            visited = false;
-            break;
-         }
-         A = Anew;
-         hi = lo;
-      }
-      if (lane == 0 && visited) {
-         unsigned long long slot = atomicAdd(a.out_count, 1ull);
-         if (slot < a.out_cap) {
-            a.out[slot] = a.g.whole ? o / a.g.S : o + a.base_offset;
-         }
-      }
-   }
-   if (lane == 0 && walked) {
-      atomicAdd(a.tiles_walked, walked);
-   }
-}
+#include "mm_tiles.h"
 
 // --------------------------------------------------------------------------
 // sequential engine: one lane per domain, exact by construction
@@ -722,34 +514,88 @@ __global__ __launch_bounds__(64) void mm_chain_seq(MmSeqArgs a)
 // --------------------------------------------------------------------------
 // ordering of the match list (unique keys): rank = number of smaller keys
 // --------------------------------------------------------------------------
+//
+// Two small launches with fixed grids (the count only exists on the device):
+//   mm_rank_count    block (x, s): for keys i = x*256+tid (grid-stride) count the
+//                    keys of slice s that are smaller -> partials[s][i]
+//   mm_rank_scatter  rank = sum of the partials; result[rank] = key, written
+//                    straight into pinned host memory together with the counters
+// Lists longer than max_n are ordered by the host (search_engine.cpp:193-197).
 
-__global__ __launch_bounds__(256) void mm_rank_sort(const uint64_t *in, const unsigned long long *count, uint64_t cap,
-                                                    uint64_t max_n, uint64_t *out)
+constexpr int MM_RANK_SLICES = 32;
+
+__global__ __launch_bounds__(256) void mm_rank_count(const uint64_t *in, const unsigned long long *count, uint64_t cap,
+                                                     uint32_t max_n, uint32_t *partials)
 {
-   unsigned long long n = *count;
-   if (n > cap || n > max_n) {
-      return;                                  // the host orders large lists itself
+   __shared__ uint64_t slice[1024];
+   const unsigned long long n64 = *count;
+   if (n64 > cap || n64 > max_n || n64 == 0) {
+      return;
    }
-   __shared__ uint64_t chunk[1024];
-   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-   const uint64_t rounds = (n + stride - 1) / stride;
-   for (uint64_t rd = 0; rd < rounds; rd++) {
-      uint64_t i = rd * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-      uint64_t key = i < n ? in[i] : ~0ull;
-      uint64_t rank = 0;
-      for (uint64_t base = 0; base < n; base += 1024) {
-         __syncthreads();
-         for (uint64_t k = threadIdx.x; k < 1024; k += blockDim.x) {
-            chunk[k] = base + k < n ? in[base + k] : ~0ull;
-         }
-         __syncthreads();
-         uint64_t lim = n - base < 1024 ? n - base : 1024;
-         for (uint64_t k = 0; k < lim; k++) {
-            rank += chunk[k] < key;
+   const uint32_t n = (uint32_t)n64;
+   const uint32_t slen = (n + MM_RANK_SLICES - 1) / MM_RANK_SLICES;      // <= max_n / 32 <= 1024
+   const uint32_t s0 = blockIdx.y * slen;
+   if (s0 >= n || blockIdx.x * 256u >= n) {
+      // slices past the end still owe zeros to the scatter pass
+      if (s0 >= n) {
+         for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+            partials[blockIdx.y * max_n + i] = 0;
          }
       }
-      if (i < n) {
-         out[rank] = key;
+      return;
+   }
+   const uint32_t s1 = s0 + slen < n ? s0 + slen : n;
+   for (uint32_t k = threadIdx.x; k < s1 - s0; k += 256) {
+      slice[k] = in[s0 + k];
+   }
+   __syncthreads();
+   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+      const uint64_t key = in[i];
+      uint32_t r = 0;
+      const uint32_t len = s1 - s0;
+#pragma unroll 8
+      for (uint32_t k = 0; k < len; k++) {
+         r += slice[k] < key ? 1u : 0u;
+      }
+      partials[blockIdx.y * max_n + i] = r;
+   }
+}
+
+// `in` holds ctrl[count_index] keys; MM_NO_MATCH keys (candidates that are not on the
+// chain) sort behind everything else, so their common rank IS the number of matches:
+// it is published as host_result[6] = rank + 1 (the host zeroes that word before the
+// scan; 0 afterwards means "every key is a match").
+__global__ __launch_bounds__(256) void mm_rank_scatter(const uint64_t *in, const unsigned long long *ctrl, int count_index,
+                                                       uint64_t cap, uint32_t max_n, const uint32_t *partials,
+                                                       uint64_t *host_result)
+{
+   const unsigned long long n64 = ctrl[count_index];
+   if (blockIdx.x == 0 && threadIdx.x < 8 && threadIdx.x != 6) {
+      unsigned long long v = ctrl[threadIdx.x];            // counters travel with the results
+      if (threadIdx.x == 2) {
+         v = 0;
+         for (int k = 0; k < MM_STAT_STRIPES; k++) {
+            v += ctrl[8 + k];
+         }
+      }
+      host_result[threadIdx.x] = v;
+   }
+   if (n64 > cap || n64 > max_n) {
+      return;
+   }
+   const uint32_t n = (uint32_t)n64;
+   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+      uint32_t r = 0;
+#pragma unroll
+      for (int s = 0; s < MM_RANK_SLICES; s++) {
+         r += partials[s * max_n + i];
+      }
+      const uint64_t key = in[i];
+      if (key == MM_NO_MATCH) {
+         host_result[6] = (uint64_t)r + 1;
+      }
+      else {
+         host_result[8 + r] = key;
       }
    }
 }
@@ -877,17 +723,47 @@ void launch_filter(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, con
    }
 }
 
-void launch_resolve(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const uint64_t *cand,
-                    const unsigned long long *cand_count, uint64_t cand_cap, uint64_t *out,
-                    unsigned long long *out_count, uint64_t out_cap, unsigned long long *tiles_walked,
+static MmTileArgs tile_args(const MmGeom &g, const mmh_plan_desc &pl)
+{
+   MmTileArgs t;
+   t.g = g; t.plan = pl;
+   const uint32_t D = pl.L - 1;
+   t.inv_d = (65536u + D - 1) / D;
+   t.skip_bloom = 0;
+   for (uint32_t k = 0; k < pl.n_skip; k++) {
+      t.skip_bloom |= 1ull << ((uint32_t)pl.skip_diff[k] & 63);
+   }
+   return t;
+}
+
+void launch_resolve(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const ResolveBuffers &rb,
                     uint64_t base_offset, uint32_t max_candidates)
 {
    MmResolveArgs a;
-   a.g = g; a.plan = pl; a.cand = cand; a.cand_count = cand_count; a.cand_cap = cand_cap;
-   a.out = out; a.out_count = out_count; a.out_cap = out_cap; a.tiles_walked = tiles_walked;
+   a.t = tile_args(g, pl);
+   a.cand = rb.cand; a.cand_count = rb.ctrl + 0; a.cand_cap = rb.cand_cap < rb.out_cap ? rb.cand_cap : rb.out_cap;
+   a.out = rb.out; a.tiles_walked = rb.ctrl + 8;
    a.base_offset = base_offset; a.max_candidates = max_candidates;
-   hipLaunchKernelGGL(mm_resolve, dim3(512), dim3(64 * MM_RESOLVE_WAVES), 0, st, a);
+   a.hard_off = rb.hard_off; a.hard_hi = rb.hard_hi; a.hard_set = rb.hard_set; a.hard_slot = rb.hard_slot;
+   a.hard_count = reinterpret_cast<unsigned int *>(rb.ctrl + 3);
+   hipLaunchKernelGGL(mm_resolve, dim3(4096), dim3(64 * MM_WAVES), 0, st, a);
+
+   MmHardArgs h;
+   h.t = a.t;
+   h.hard_off = rb.hard_off; h.hard_hi = rb.hard_hi; h.hard_set = rb.hard_set; h.hard_slot = rb.hard_slot;
+   h.hard_count = reinterpret_cast<unsigned int *>(rb.ctrl + 3);
+   h.overflow = reinterpret_cast<unsigned int *>(rb.ctrl + 3) + 1;
+   h.done = reinterpret_cast<unsigned int *>(rb.ctrl + 8 + MM_STAT_STRIPES);
+   h.scratch = rb.scratch;
+   h.out = rb.out; h.tiles_walked = rb.ctrl + 8;
+   h.base_offset = base_offset;
+   hipLaunchKernelGGL(mm_hard_resolve, dim3(MM_HARD_PARTS, MM_HARD_CAP), dim3(64 * MM_WAVES), 0, st, h);
 }
+
+size_t hard_scratch_bytes() { return (size_t)MM_HARD_CAP * MM_HARD_MAX_TILES * MM_MAXD; }
+size_t hard_cap() { return MM_HARD_CAP; }
+size_t ctrl_bytes() { return (8 + MM_STAT_STRIPES) * sizeof(uint64_t) + MM_HARD_CAP * sizeof(unsigned int); }
+size_t rank_partials_bytes(uint32_t max_n) { return (size_t)MM_RANK_SLICES * max_n * sizeof(uint32_t); }
 
 void launch_chain_seq(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, uint64_t *out,
                       unsigned long long *out_count, uint64_t out_cap, uint64_t base_offset)
@@ -902,10 +778,13 @@ void launch_chain_seq(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, 
    hipLaunchKernelGGL(mm_chain_seq, dim3((unsigned)blocks), dim3(64), 0, st, a);
 }
 
-void launch_rank_sort(hipStream_t st, const uint64_t *in, const unsigned long long *count, uint64_t cap,
-                      uint64_t max_n, uint64_t *out)
+void launch_rank_sort(hipStream_t st, const uint64_t *in, const unsigned long long *ctrl, int count_index, uint64_t cap,
+                      uint32_t max_n, uint32_t *partials, uint64_t *host_result)
 {
-   hipLaunchKernelGGL(mm_rank_sort, dim3(64), dim3(256), 0, st, in, count, cap, max_n, out);
+   hipLaunchKernelGGL(mm_rank_count, dim3(16, MM_RANK_SLICES), dim3(256), 0, st, in, ctrl + count_index, cap, max_n,
+                      partials);
+   hipLaunchKernelGGL(mm_rank_scatter, dim3(64), dim3(256), 0, st, in, ctrl, count_index, cap, max_n, partials,
+                      host_result);
 }
 
 void launch_synth(hipStream_t st, uint8_t *rom, uint64_t nbytes, uint64_t seed, uint64_t base_offset)

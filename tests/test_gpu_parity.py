@@ -94,18 +94,18 @@ def _spec_case(mm, oracle, eng, nbytes, keyword, elem, wildcard=None, be=False, 
 
 def test_c2_shape_16mib(mm, gpu_engine, oracle):
     got, ctr = _spec_case(mm, oracle, gpu_engine, 16 << 20, "relativesrch", 1)
-    assert len(got) >= 8 and ctr["sequential"] == 0
+    assert len(got) >= 8 and ctr["path"] != 1
 
 
 def test_c3_shape_wildcards_16mib(mm, gpu_engine, oracle):
     got, ctr = _spec_case(mm, oracle, gpu_engine, 16 << 20, "re*ative*ear*hxy", 1, wildcard=ord("*"))
-    assert len(got) >= 8 and ctr["sequential"] == 0
+    assert len(got) >= 8 and ctr["path"] != 1
 
 
 @pytest.mark.parametrize("be", [False, True])
 def test_c4_shape_16bit_32mib(mm, gpu_engine, oracle, be):
     got, ctr = _spec_case(mm, oracle, gpu_engine, 32 << 20, "textsrch", 2, be=be)
-    assert len(got) >= 8 and ctr["sequential"] == 0
+    assert len(got) >= 8 and ctr["path"] != 1
 
 
 @pytest.mark.parametrize("kw", ["monkey", "abcde", "relativesrch"])
