@@ -354,7 +354,7 @@ int run_pipeline(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, const mm:
    HIP_TRY(hipMemsetAsync(c->d_ctrl, 0, mm::ctrl_bytes(), st));
    HIP_TRY(hipEventRecord(c->ev[0], st));
    if (!sequential) {
-      mm::launch_filter(st, g, pl, fc, c->d_cand, c->d_ctrl + 0, c->cand_cap);
+      mm::launch_filter(st, g, pl, fc, c->d_cand, c->d_ctrl, c->cand_cap);
    }
    HIP_TRY(hipEventRecord(c->ev[1], st));
    if (!sequential) {
@@ -440,7 +440,7 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
       if (rc != MMH_OK) {
          return rc;
       }
-      if (!sequential && (oc.candidates > c->cand_cap || oc.candidates > max_candidates || oc.hard_overflow)) {
+      if (!sequential && (oc.candidates > c->out_cap || oc.candidates > max_candidates || oc.hard_overflow)) {
          sequential = true;                       // too dense / too long for the per-candidate resolvers
          continue;
       }

@@ -35,6 +35,24 @@ struct MmGeom {
    uint32_t whole;         // 1 = whole-buffer mode (results are element indices)
 };
 
+// ---- per-scan control block (device memory, zeroed before every scan), in u64 words --
+//
+// Returning atomics on ONE address serialise at ~20 ns each on MI355X even when they are
+// spread out in time (measured: 4 K candidate appends cost the streaming filter +85 us),
+// so the filter appends to MM_CAND_LISTS independent lists, each with its counter on a
+// 128-byte line of its own; mm_resolve renumbers them compactly.
+enum {
+   MM_CTRL_TOTAL = 0,        // candidates over all lists (written by mm_resolve; ~0 = a list overflowed)
+   MM_CTRL_APPENDED = 1,     // matches appended by mm_chain_seq
+   MM_CTRL_HARD = 3,         // lo 32: hard candidates, hi 32: "prefix too long" flag
+   MM_CTRL_TILES = 8,        // MM_STAT_STRIPES striped counters of tiles walked
+   MM_STAT_STRIPES = 16,
+   MM_CTRL_LISTS = 32,       // MM_CAND_LISTS list counters, MM_LIST_STRIDE words apart
+   MM_CAND_LISTS = 64,
+   MM_LIST_STRIDE = 16,
+   MM_CTRL_DONE = MM_CTRL_LISTS + MM_CAND_LISTS * MM_LIST_STRIDE   // unsigned int tickets of mm_hard_resolve
+};
+
 #if defined(__HIPCC__) || defined(__cplusplus)
 #if defined(__HIPCC__)
 #define MM_HD __host__ __device__ inline

@@ -10,21 +10,17 @@ namespace mm {
 
 struct FilterChoice {
    uint32_t ncond;   // 0 = no usable SWAR condition (pattern has no two adjacent literals)
-   uint32_t iA;
-   uint32_t patA;
-   uint32_t patB;
+   uint32_t iA;      // keyword position whose delta is condition 0
+   uint32_t pat[4];  // condition k = delta of position iA-k, replicated over the SWAR lanes
 };
 
 bool choose_filter(const mmh_plan_desc &pl, FilterChoice *fc);
 
 void launch_filter(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc,
-                   uint64_t *cand, unsigned long long *cand_count, uint64_t cand_cap);
+                   uint64_t *cand, unsigned long long *ctrl, uint64_t cand_cap);
 
-// Device buffers of one scan.  ctrl (zeroed before every scan) is
-//   u64 [0] candidates (filter)          [1] matches appended by mm_chain_seq
-//       [2] unused                       [3] lo: hard candidates, hi: overflow flag
-//       [4..7] spare                     [8..8+stat stripes) tiles walked, striped
-//   then unsigned int done[hard_cap()]   arrival tickets of mm_hard_resolve
+// Device buffers of one scan.  ctrl is zeroed before every scan; layout: MM_CTRL_* in
+// mm_internal.h.  cand holds MM_CAND_LISTS candidate lists of cand_cap / MM_CAND_LISTS entries.
 // Filter + resolver path: out[i] is the result SLOT of candidate i (reported value or
 // ~0 = not a match).  Sequential path: out is an append list of ctrl[1] matches.
 struct ResolveBuffers {

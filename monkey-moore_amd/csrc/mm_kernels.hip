@@ -170,29 +170,39 @@ __device__ __forceinline__ bool mm_is_candidate(const MmGeom &g, const mmh_plan_
 // streaming filter, 8-bit elements
 // --------------------------------------------------------------------------
 //
-// One 16-byte chunk per lane per iteration (lane l of a wave reads bytes
-// [16l, 16l+16) of a 1 KiB line group -> fully coalesced dwordx4), plus the 4
-// bytes in front of it.  For every byte t the SWAR code evaluates
-//     (x[t]   - x[t-1]) mod 256 == patA          (delta of keyword position iA)
-//     (x[t-1] - x[t-2]) mod 256 == patB          (delta of position iA-1, NCOND == 2)
-// which is necessary for a match starting at t - iA on both reference paths
-// (signed equality implies modular equality).  Survivors (2^-16 of positions on
-// random data) are verified exactly.
+// One 16-byte chunk per lane (lane l of a wave reads bytes [16l, 16l+16) of a
+// 1 KiB piece -> fully coalesced dwordx4).  For every byte t the SWAR code
+// evaluates NCOND (1..4) necessary conditions for a match starting at t - iA:
+//     (x[t-k] - x[t-k-1]) mod 256 == pat[k]      delta of keyword position iA-k
+// for k = 0 .. NCOND-1 (signed equality on the simple path implies modular
+// equality, so this is a superset on both reference paths).  On random bytes
+// 2^(-8 NCOND) of the positions survive; survivors are verified exactly with
+// the reference's own compare loop.  Four conditions cost 21 VALU ops per dword
+// and leave essentially only real candidates, which keeps the divergent
+// verification (and the tail it would put on some waves) out of the picture.
 
 struct MmFilterArgs {
    MmGeom g;
    mmh_plan_desc plan;
-   uint32_t patA;          // replicated over the SWAR lanes
-   uint32_t patB;
-   uint32_t iA;            // keyword index of the element whose delta is patA
+   uint32_t pat[4];        // condition k, replicated over the SWAR lanes
+   uint32_t iA;            // keyword index of the element whose delta is pat[0]
    uint32_t ncond;
-   uint64_t *cand;         // candidate byte offsets
-   unsigned long long *cand_count;
-   uint64_t cand_cap;
+   uint32_t verify;        // 1: run the full compare loop on survivors here; 0: leave it to mm_resolve
+
+   uint64_t *cand;         // MM_CAND_LISTS lists of candidate byte offsets, list_cap entries each
+   unsigned long long *list_count;   // their counters, MM_LIST_STRIDE words apart (mm_internal.h)
+   uint64_t list_cap;
    uint64_t ngroups;       // span kernel: number of whole 4 KiB groups it covers
    uint32_t groups_per_span;
    uint64_t edge_first;    // edge kernel: 16-byte chunks [edge_first, nchunks)
 };
+
+// a workgroup always appends to the same list: no two lists share an atomic address
+__device__ __forceinline__ void mm_cand_append(const MmFilterArgs &a, bool want, uint64_t off)
+{
+   const uint32_t c = blockIdx.x & (MM_CAND_LISTS - 1);
+   mm_append(a.cand + (uint64_t)c * a.list_cap, a.list_count + c * MM_LIST_STRIDE, a.list_cap, want, off);
+}
 
 __device__ __forceinline__ uint4 mm_load_chunk(const uint8_t *rom, uint64_t nbytes, uint64_t byte0)
 {
@@ -206,137 +216,101 @@ __device__ __forceinline__ uint4 mm_load_chunk(const uint8_t *rom, uint64_t nbyt
    return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// hit flags (bit 7 of a byte) of one dword; dbprev = byte deltas of the previous dword
 template <int NCOND>
-__device__ __forceinline__ uint32_t mm_f8_hits(uint32_t w, uint32_t wprev, uint32_t &dbprev, uint32_t patA, uint32_t patB)
+__device__ __forceinline__ uint32_t mm_f8_hits(uint32_t w, uint32_t wprev, uint32_t &dbprev, const uint32_t (&pat)[4])
 {
-   uint32_t db = mm_bytesub(w, mm_alignbit(w, wprev, 24));
-   uint32_t z = db ^ patA;
-   if (NCOND == 2) {
-      z |= mm_alignbit(db, dbprev, 24) ^ patB;
+   const uint32_t db = mm_bytesub(w, mm_alignbit(w, wprev, 24));
+   uint32_t z = db ^ pat[0];
+   if (NCOND >= 2) {
+      z |= mm_alignbit(db, dbprev, 24) ^ pat[1];
+   }
+   if (NCOND >= 3) {
+      z |= mm_alignbit(db, dbprev, 16) ^ pat[2];
+   }
+   if (NCOND >= 4) {
+      z |= mm_alignbit(db, dbprev, 8) ^ pat[3];
    }
    dbprev = db;
    return mm_haszero8(z);
 }
 
+// hit flags of a 16-byte chunk; `back` = the dword in front of it
 template <int NCOND>
-__global__ __launch_bounds__(256) void mm_filter_u8_edge(MmFilterArgs a)
+__device__ __forceinline__ uint32_t mm_f8_chunk(const uint4 &w, uint32_t back, const uint32_t (&pat)[4], uint32_t (&h)[4])
 {
-   // bounds-checked version for the ragged end of the ROM (everything behind the
-   // last whole 4 KiB group); same arithmetic as the span kernel below
-   const uint64_t nchunks = (a.g.nbytes + 15) / 16;
-   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-   constexpr int UNROLL = 4;
-   // same trip count in every lane: the ballots below must see whole waves
-   const uint64_t iters = (nchunks - a.edge_first + stride * UNROLL - 1) / (stride * UNROLL);
-
-   for (uint64_t it = 0; it < iters; it++) {
-      const uint64_t c0 = a.edge_first + it * stride * UNROLL + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-      uint4 w[UNROLL];
-      uint32_t back[UNROLL];
-      uint32_t hits[UNROLL][4];
-      uint32_t any = 0;
-#pragma unroll
-      for (int u = 0; u < UNROLL; u++) {
-         uint64_t c = c0 + stride * u;
-         if (c < nchunks) {
-            w[u] = mm_load_chunk(a.g.rom, a.g.nbytes, c * 16);
-            back[u] = c ? *reinterpret_cast<const uint32_t *>(a.g.rom + c * 16 - 4) : 0u;
-         }
-         else {
-            w[u] = make_uint4(0, 0, 0, 0);
-            back[u] = 0;
-         }
-      }
-#pragma unroll
-      for (int u = 0; u < UNROLL; u++) {
-         // delta of the byte just in front of the chunk; its predecessor sits in the same word
-         uint32_t dbprev = mm_bytesub(back[u], back[u] << 8);
-         hits[u][0] = mm_f8_hits<NCOND>(w[u].x, back[u], dbprev, a.patA, a.patB);
-         hits[u][1] = mm_f8_hits<NCOND>(w[u].y, w[u].x, dbprev, a.patA, a.patB);
-         hits[u][2] = mm_f8_hits<NCOND>(w[u].z, w[u].y, dbprev, a.patA, a.patB);
-         hits[u][3] = mm_f8_hits<NCOND>(w[u].w, w[u].z, dbprev, a.patA, a.patB);
-         any |= hits[u][0] | hits[u][1] | hits[u][2] | hits[u][3];
-      }
-      if (__ballot(any != 0) == 0) {
-         continue;                              // the common case: nothing in this wave's 4 KiB
-      }
-#pragma unroll
-      for (int u = 0; u < UNROLL; u++) {
-         uint64_t c = c0 + stride * u;
-#pragma unroll
-         for (int k = 0; k < 4; k++) {
-            uint32_t h = (c < nchunks) ? hits[u][k] : 0u;
-            while (__ballot(h != 0) != 0) {
-               bool want = false;
-               uint64_t off = 0;
-               if (h) {
-                  int bit = __ffs((int)h) - 1;
-                  h &= h - 1;
-                  int64_t t = (int64_t)(c * 16 + 4 * k + (bit >> 3));
-                  int64_t o = t - (int64_t)a.iA;
-                  if (mm_is_candidate(a.g, a.plan, o)) {
-                     want = true;
-                     off = (uint64_t)o;
-                  }
-               }
-               mm_append(a.cand, a.cand_count, a.cand_cap, want, off);
-            }
-         }
-      }
-   }
-}
-
-
-// The hot kernel.  The ROM is cut into 4 KiB groups; a wave owns SPANS of
-// consecutive groups and streams through them, 4 x dwordx4 per lane per group
-// (each wave instruction = 1 KiB contiguous).  The byte in front of a lane's
-// chunk comes from the neighbouring lane (DPP wave_shr:1), lane 0 takes it from
-// lane 63 of the previous piece (v_readlane) -- no second memory access.
-template <int NCOND>
-__device__ __forceinline__ uint32_t mm_f8_piece(const uint4 &w, uint32_t carry, uint32_t patA, uint32_t patB, uint32_t (&h)[4])
-{
-   // last dword of the previous 16 bytes: lane l-1's w.w, lane 0 keeps `carry`
-   uint32_t back = __builtin_amdgcn_update_dpp(carry, w.w, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-   uint32_t dbprev = mm_bytesub(back, back << 8);
-   h[0] = mm_f8_hits<NCOND>(w.x, back, dbprev, patA, patB);
-   h[1] = mm_f8_hits<NCOND>(w.y, w.x, dbprev, patA, patB);
-   h[2] = mm_f8_hits<NCOND>(w.z, w.y, dbprev, patA, patB);
-   h[3] = mm_f8_hits<NCOND>(w.w, w.z, dbprev, patA, patB);
+   uint32_t dbprev = mm_bytesub(back, back << 8);      // deltas of bytes -3..-1 (byte -4's is not needed)
+   h[0] = mm_f8_hits<NCOND>(w.x, back, dbprev, pat);
+   h[1] = mm_f8_hits<NCOND>(w.y, w.x, dbprev, pat);
+   h[2] = mm_f8_hits<NCOND>(w.z, w.y, dbprev, pat);
+   h[3] = mm_f8_hits<NCOND>(w.w, w.z, dbprev, pat);
    return h[0] | h[1] | h[2] | h[3];
 }
 
-// rare path: the wave found at least one SWAR survivor in this group.  Kept
-// inline (a call would force the hit words and the kernel arguments through
-// scratch on every iteration) but as ONE loop over a 64-bit per-lane flag word.
 __device__ __forceinline__ uint32_t mm_f8_pack(const uint32_t (&h)[4])
 {
    return (h[0] >> 7) | (h[1] >> 6) | (h[2] >> 5) | (h[3] >> 4);   // bit 8*b + k <-> dword k, byte b
 }
 
-__device__ __forceinline__ void mm_f8_survivors(const MmFilterArgs &a, uint64_t group, uint32_t lane, uint64_t bits)
+// verify the survivors flagged in `bits` (bit 8*b + k of this lane's chunk at byte `chunk0`)
+// and append the real candidates; the whole wave takes part (ballots inside)
+__device__ __forceinline__ void mm_f8_survivors(const MmFilterArgs &a, uint64_t chunk0, uint32_t bits)
 {
-   // bit (32*half + 8*b + 4*(u&1) + k) <-> piece u = 2*half + (u&1), dword k, byte b
    while (__ballot(bits != 0) != 0) {
       bool want = false;
       uint64_t off = 0;
       if (bits) {
-         int bit = __ffsll((long long)bits) - 1;
+         const int bit = __ffs((int)bits) - 1;
          bits &= bits - 1;
-         int half = bit >> 5, b = (bit >> 3) & 3, u = 2 * half + ((bit >> 2) & 1), k = bit & 3;
-         int64_t t = (int64_t)(group * 4096 + (uint64_t)u * 1024 + lane * 16 + 4 * k + b);
-         int64_t o = t - (int64_t)a.iA;
-         if (mm_is_candidate(a.g, a.plan, o)) {
+         const int64_t t = (int64_t)(chunk0 + 4 * (bit & 3) + (bit >> 3));
+         const int64_t o = t - (int64_t)a.iA;
+         // With four SWAR conditions practically every survivor is a real candidate and the
+         // resolver (which stages the bytes anyway) verifies it; running the dependent-load
+         // compare loop here would stall this wave's stream for microseconds per survivor.
+         if (a.verify ? mm_is_candidate(a.g, a.plan, o) : (o >= 0)) {
             want = true;
             off = (uint64_t)o;
          }
       }
-      mm_append(a.cand, a.cand_count, a.cand_cap, want, off);
+      mm_cand_append(a, want, off);
    }
 }
 
+// bounds-checked version for the ragged end of the ROM (everything behind the last
+// whole 4 KiB group): one chunk per lane per iteration, look-back by a second load
+template <int NCOND>
+__global__ __launch_bounds__(256) void mm_filter_u8_edge(MmFilterArgs a)
+{
+   const uint64_t nchunks = (a.g.nbytes + 15) / 16;
+   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+   // same trip count in every lane: the ballots must see whole waves
+   const uint64_t iters = (nchunks - a.edge_first + stride - 1) / stride;
+   for (uint64_t it = 0; it < iters; it++) {
+      const uint64_t c = a.edge_first + it * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+      uint32_t h[4] = {0, 0, 0, 0};
+      uint32_t any = 0;
+      if (c < nchunks) {
+         const uint4 w = mm_load_chunk(a.g.rom, a.g.nbytes, c * 16);
+         const uint32_t back = c ? *reinterpret_cast<const uint32_t *>(a.g.rom + c * 16 - 4) : 0u;
+         any = mm_f8_chunk<NCOND>(w, back, a.pat, h);
+      }
+      if (__ballot(any != 0) != 0) {
+         mm_f8_survivors(a, c * 16, mm_f8_pack(h));
+      }
+   }
+}
+
+// The hot kernel.  The ROM is cut into 4 KiB groups; a wave owns SPANS of
+// consecutive groups and streams through them, 4 x dwordx4 per lane per group
+// (each wave instruction = 1 KiB contiguous), with the loads of the next TWO
+// groups in flight while a group is processed (8 KiB per wave; depth 1 leaves
+// ~4 % of the read bandwidth on the table).  The dword in front of a lane's
+// chunk comes from the neighbouring lane (DPP wave_shr:1), lane 0 takes it from
+// lane 63 of the previous piece (v_readlane) -- no second memory access.
 template <int NCOND>
 __global__ __launch_bounds__(256) void mm_filter_u8(MmFilterArgs a)
 {
+   constexpr int DEPTH = 2;
    const uint32_t lane = threadIdx.x & 63;
    const uint64_t wave = __builtin_amdgcn_readfirstlane((uint32_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
@@ -347,26 +321,43 @@ __global__ __launch_bounds__(256) void mm_filter_u8(MmFilterArgs a)
    for (uint64_t g0 = wave * gps; g0 < a.ngroups; g0 += nwaves * gps) {
       const uint64_t g1 = g0 + gps < a.ngroups ? g0 + gps : a.ngroups;
       uint32_t carry = g0 ? rom1[g0 * 1024 - 1] : 0u;          // dword in front of the span (wave uniform)
-      const uint4 *p = rom4 + g0 * 256 + lane;
-      uint4 w0 = p[0], w1 = p[64], w2 = p[128], w3 = p[192];
-      for (uint64_t g = g0; g < g1; g++) {
-         // issue the next group's loads before touching this one's data
-         const uint64_t gn = g + 1 < g1 ? g + 1 : g;
-         const uint4 *pn = rom4 + gn * 256 + lane;
-         uint4 n0 = pn[0], n1 = pn[64], n2 = pn[128], n3 = pn[192];
-
-         uint32_t h0[4], h1[4], h2[4], h3[4];
-         uint32_t any = mm_f8_piece<NCOND>(w0, carry, a.patA, a.patB, h0);
-         any |= mm_f8_piece<NCOND>(w1, __builtin_amdgcn_readlane(w0.w, 63), a.patA, a.patB, h1);
-         any |= mm_f8_piece<NCOND>(w2, __builtin_amdgcn_readlane(w1.w, 63), a.patA, a.patB, h2);
-         any |= mm_f8_piece<NCOND>(w3, __builtin_amdgcn_readlane(w2.w, 63), a.patA, a.patB, h3);
-         carry = __builtin_amdgcn_readlane(w3.w, 63);
-         if (__ballot(any != 0) != 0) {
-            uint64_t bits = (uint64_t)(mm_f8_pack(h0) | (mm_f8_pack(h1) << 4)) |
-                            ((uint64_t)(mm_f8_pack(h2) | (mm_f8_pack(h3) << 4)) << 32);
-            mm_f8_survivors(a, g, lane, bits);
+      uint4 w[DEPTH + 1][4];
+#pragma unroll
+      for (int d = 0; d < DEPTH; d++) {
+         const uint64_t gg = g0 + d < g1 ? g0 + d : g1 - 1;
+         const uint4 *p = rom4 + gg * 256 + lane;
+         w[d][0] = p[0]; w[d][1] = p[64]; w[d][2] = p[128]; w[d][3] = p[192];
+      }
+      for (uint64_t g = g0; g < g1; g += DEPTH + 1) {
+#pragma unroll
+         for (int s = 0; s <= DEPTH; s++) {
+            // ring slot s holds group g+s; refill the slot that is DEPTH groups ahead
+            constexpr int RING = DEPTH + 1;
+            const int slot_new = (s + DEPTH) % RING;
+            const uint64_t gn = g + s + DEPTH < g1 ? g + s + DEPTH : g1 - 1;
+            const uint4 *pn = rom4 + gn * 256 + lane;
+            w[slot_new][0] = pn[0]; w[slot_new][1] = pn[64]; w[slot_new][2] = pn[128]; w[slot_new][3] = pn[192];
+            if (g + s < g1) {
+               uint32_t h[4][4];
+               uint32_t any = 0;
+#pragma unroll
+               for (int u = 0; u < 4; u++) {
+                  // last dword of the previous 16 bytes: lane l-1's w.w; lane 0 keeps c
+                  const uint32_t c = u == 0 ? carry : __builtin_amdgcn_readlane(w[s][u - 1].w, 63);
+                  const uint32_t back = __builtin_amdgcn_update_dpp(c, w[s][u].w, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                  any |= mm_f8_chunk<NCOND>(w[s][u], back, a.pat, h[u]);
+               }
+               carry = __builtin_amdgcn_readlane(w[s][3].w, 63);
+               if (__ballot(any != 0) != 0) {
+                  // rare: kept as one loop per piece so that the hot loop stays small
+#pragma unroll 1
+                  for (int u = 0; u < 4; u++) {
+                     const uint32_t bits = u == 0 ? mm_f8_pack(h[0]) : (u == 1 ? mm_f8_pack(h[1]) : (u == 2 ? mm_f8_pack(h[2]) : mm_f8_pack(h[3])));
+                     mm_f8_survivors(a, (g + s) * 4096 + (uint64_t)u * 1024 + lane * 16, bits);
+                  }
+               }
+            }
          }
-         w0 = n0; w1 = n1; w2 = n2; w3 = n3;
       }
    }
 }
@@ -426,8 +417,8 @@ __global__ __launch_bounds__(256) void mm_filter_u16(MmFilterArgs a)
          }
 #pragma unroll
          for (int k = 0; k < 4; k++) {
-            he[u][k] = mm_f16_hits(ev[k + 2], ev[k + 1], a.patA);
-            ho[u][k] = mm_f16_hits(od[k + 2], od[k + 1], a.patA);
+            he[u][k] = mm_f16_hits(ev[k + 2], ev[k + 1], a.pat[0]);
+            ho[u][k] = mm_f16_hits(od[k + 2], od[k + 1], a.pat[0]);
             any |= he[u][k] | ho[u][k];
          }
       }
@@ -456,7 +447,7 @@ __global__ __launch_bounds__(256) void mm_filter_u16(MmFilterArgs a)
                         off = (uint64_t)o;
                      }
                   }
-                  mm_append(a.cand, a.cand_count, a.cand_cap, want, off);
+                  mm_cand_append(a, want, off);
                }
             }
          }
@@ -575,7 +566,7 @@ __global__ __launch_bounds__(256) void mm_rank_scatter(const uint64_t *in, const
       if (threadIdx.x == 2) {
          v = 0;
          for (int k = 0; k < MM_STAT_STRIPES; k++) {
-            v += ctrl[8 + k];
+            v += ctrl[MM_CTRL_TILES + k];
          }
       }
       host_result[threadIdx.x] = v;
@@ -661,60 +652,66 @@ bool choose_filter(const mmh_plan_desc &pl, FilterChoice *fc)
 {
    const int L = (int)pl.L;
    const uint32_t emask = pl.elem_bytes == 1 ? 0xFFu : 0xFFFFu;
+   const uint32_t rep = pl.elem_bytes == 1 ? 0x01010101u : 0x00010001u;
+   // position i can serve as a condition when it is a literal compared with its left neighbour
    auto adjacent = [&](int i) { return i >= 1 && pl.cmp_mask[i] != 0 && pl.bridge[i] == -1; };
+   const int want = pl.elem_bytes == 1 ? 4 : 1;
    fc->ncond = 0;
-   if (pl.elem_bytes == 1) {
-      for (int i = L - 1; i >= 2; --i) {
-         if (adjacent(i) && adjacent(i - 1)) {
-            fc->ncond = 2; fc->iA = (uint32_t)i;
-            fc->patA = ((uint32_t)pl.expected[i] & emask) * 0x01010101u;
-            fc->patB = ((uint32_t)pl.expected[i - 1] & emask) * 0x01010101u;
-            return true;
+   for (int nc = want; nc >= 1 && fc->ncond == 0; nc--) {
+      for (int i = L - 1; i >= nc; --i) {
+         bool ok = true;
+         for (int k = 0; k < nc; k++) {
+            ok = ok && adjacent(i - k);
+         }
+         if (ok) {
+            fc->ncond = (uint32_t)nc;
+            fc->iA = (uint32_t)i;
+            for (int k = 0; k < 4; k++) {
+               fc->pat[k] = k < nc ? ((uint32_t)pl.expected[i - k] & emask) * rep : 0u;
+            }
+            break;
          }
       }
    }
-   for (int i = L - 1; i >= 1; --i) {
-      if (adjacent(i)) {
-         fc->ncond = 1; fc->iA = (uint32_t)i;
-         fc->patA = ((uint32_t)pl.expected[i] & emask) * (pl.elem_bytes == 1 ? 0x01010101u : 0x00010001u);
-         fc->patB = 0;
-         return true;
+   return fc->ncond != 0;
+}
+
+template <int NCOND>
+static void launch_filter_u8(hipStream_t st, const MmFilterArgs &a, const MmGeom &g)
+{
+   if (a.ngroups) {
+      uint64_t spans = (a.ngroups + a.groups_per_span - 1) / a.groups_per_span;
+      uint64_t blocks = (spans + 3) / 4;
+      if (blocks > 256 * 8) {
+         blocks = 256 * 8;
       }
+      hipLaunchKernelGGL(mm_filter_u8<NCOND>, dim3((unsigned)blocks), dim3(256), 0, st, a);
    }
-   return false;
+   if (a.edge_first * 16 < g.nbytes) {
+      hipLaunchKernelGGL(mm_filter_u8_edge<NCOND>, dim3(1), dim3(256), 0, st, a);
+   }
 }
 
 void launch_filter(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc,
-                   uint64_t *cand, unsigned long long *cand_count, uint64_t cand_cap)
+                   uint64_t *cand, unsigned long long *ctrl, uint64_t cand_cap)
 {
    MmFilterArgs a;
-   a.g = g; a.plan = pl; a.patA = fc.patA; a.patB = fc.patB; a.iA = fc.iA; a.ncond = fc.ncond;
-   a.cand = cand; a.cand_count = cand_count; a.cand_cap = cand_cap;
+   a.g = g; a.plan = pl; a.iA = fc.iA; a.ncond = fc.ncond;
+   a.verify = (pl.elem_bytes == 1 && fc.ncond == 4) ? 0u : 1u;
+   for (int k = 0; k < 4; k++) {
+      a.pat[k] = fc.pat[k];
+   }
+   a.cand = cand; a.list_count = ctrl + MM_CTRL_LISTS; a.list_cap = cand_cap / MM_CAND_LISTS;
    a.ngroups = 0; a.groups_per_span = 16; a.edge_first = 0;
    if (pl.elem_bytes == 1) {
       // whole 4 KiB groups go to the span kernel, the ragged end to the bounds-checked one
       a.ngroups = g.nbytes / 4096;
       a.edge_first = a.ngroups * 256;
-      if (a.ngroups) {
-         uint64_t spans = (a.ngroups + a.groups_per_span - 1) / a.groups_per_span;
-         uint64_t blocks = (spans + 3) / 4;
-         if (blocks > 256 * 8) {
-            blocks = 256 * 8;
-         }
-         if (fc.ncond == 2) {
-            hipLaunchKernelGGL(mm_filter_u8<2>, dim3((unsigned)blocks), dim3(256), 0, st, a);
-         }
-         else {
-            hipLaunchKernelGGL(mm_filter_u8<1>, dim3((unsigned)blocks), dim3(256), 0, st, a);
-         }
-      }
-      if (a.edge_first * 16 < g.nbytes) {
-         if (fc.ncond == 2) {
-            hipLaunchKernelGGL(mm_filter_u8_edge<2>, dim3(1), dim3(256), 0, st, a);
-         }
-         else {
-            hipLaunchKernelGGL(mm_filter_u8_edge<1>, dim3(1), dim3(256), 0, st, a);
-         }
+      switch (fc.ncond) {
+      case 4: launch_filter_u8<4>(st, a, g); break;
+      case 3: launch_filter_u8<3>(st, a, g); break;
+      case 2: launch_filter_u8<2>(st, a, g); break;
+      default: launch_filter_u8<1>(st, a, g); break;
       }
    }
    else {
@@ -741,28 +738,29 @@ void launch_resolve(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, co
 {
    MmResolveArgs a;
    a.t = tile_args(g, pl);
-   a.cand = rb.cand; a.cand_count = rb.ctrl + 0; a.cand_cap = rb.cand_cap < rb.out_cap ? rb.cand_cap : rb.out_cap;
-   a.out = rb.out; a.tiles_walked = rb.ctrl + 8;
+   a.cand = rb.cand; a.list_count = rb.ctrl + MM_CTRL_LISTS; a.list_cap = rb.cand_cap / MM_CAND_LISTS;
+   a.total_out = rb.ctrl + MM_CTRL_TOTAL;
+   a.out = rb.out; a.out_cap = rb.out_cap; a.tiles_walked = rb.ctrl + MM_CTRL_TILES;
    a.base_offset = base_offset; a.max_candidates = max_candidates;
    a.hard_off = rb.hard_off; a.hard_hi = rb.hard_hi; a.hard_set = rb.hard_set; a.hard_slot = rb.hard_slot;
-   a.hard_count = reinterpret_cast<unsigned int *>(rb.ctrl + 3);
+   a.hard_count = reinterpret_cast<unsigned int *>(rb.ctrl + MM_CTRL_HARD);
    hipLaunchKernelGGL(mm_resolve, dim3(4096), dim3(64 * MM_WAVES), 0, st, a);
 
    MmHardArgs h;
    h.t = a.t;
    h.hard_off = rb.hard_off; h.hard_hi = rb.hard_hi; h.hard_set = rb.hard_set; h.hard_slot = rb.hard_slot;
-   h.hard_count = reinterpret_cast<unsigned int *>(rb.ctrl + 3);
-   h.overflow = reinterpret_cast<unsigned int *>(rb.ctrl + 3) + 1;
-   h.done = reinterpret_cast<unsigned int *>(rb.ctrl + 8 + MM_STAT_STRIPES);
+   h.hard_count = reinterpret_cast<unsigned int *>(rb.ctrl + MM_CTRL_HARD);
+   h.overflow = reinterpret_cast<unsigned int *>(rb.ctrl + MM_CTRL_HARD) + 1;
+   h.done = reinterpret_cast<unsigned int *>(rb.ctrl + MM_CTRL_DONE);
    h.scratch = rb.scratch;
-   h.out = rb.out; h.tiles_walked = rb.ctrl + 8;
+   h.out = rb.out; h.tiles_walked = rb.ctrl + MM_CTRL_TILES;
    h.base_offset = base_offset;
    hipLaunchKernelGGL(mm_hard_resolve, dim3(MM_HARD_PARTS, MM_HARD_CAP), dim3(64 * MM_WAVES), 0, st, h);
 }
 
 size_t hard_scratch_bytes() { return (size_t)MM_HARD_CAP * MM_HARD_MAX_TILES * MM_MAXD; }
 size_t hard_cap() { return MM_HARD_CAP; }
-size_t ctrl_bytes() { return (8 + MM_STAT_STRIPES) * sizeof(uint64_t) + MM_HARD_CAP * sizeof(unsigned int); }
+size_t ctrl_bytes() { return MM_CTRL_DONE * sizeof(uint64_t) + MM_HARD_CAP * sizeof(unsigned int); }
 size_t rank_partials_bytes(uint32_t max_n) { return (size_t)MM_RANK_SLICES * max_n * sizeof(uint32_t); }
 
 void launch_chain_seq(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, uint64_t *out,

@@ -60,7 +60,7 @@ struct MmPlanLds {
 };
 
 struct MmWaveLds {
-   uint32_t tile[((MM_TILE + MMH_MAX_KEYWORD) * 2 + 16) / 4];
+   uint32_t tile[((MM_TILE + MMH_MAX_KEYWORD + 1) * 2 + 16) / 4];
 };
 
 // tell the compiler a value is the same in every lane (keeps it in SGPRs / on the scalar unit)
@@ -171,7 +171,9 @@ __device__ __forceinline__ int mm_stage_tile(const MmTileArgs &a, MmWaveLds &W, 
 {
    const int S = (int)a.g.S;
    const uint64_t src0 = start + (uint64_t)lo * S;
-   const int nstage = (npos + (int)a.plan.L - 1) * S;
+   // one element more than the tile's own compares need: the caller may evaluate the
+   // compare loop AT position npos (the candidate) as well
+   const int nstage = (npos + (int)a.plan.L) * S;
    const int mis = (int)(((uintptr_t)(a.g.rom + src0)) & 3);
    const uint32_t *s4 = reinterpret_cast<const uint32_t *>(a.g.rom + src0 - mis);
    const int nw = (nstage + mis + 3) >> 2;
@@ -226,9 +228,25 @@ __device__ __forceinline__ uint32_t mm_modd(const MmTileArgs &a, uint32_t x)
 
 // map of positions [lo, lo + npos) of the domain at byte `start`; lo_mod = lo mod D.
 // The result is wave uniform.
+// the reference's compare loop at position q of the staged tile: does it report a match?
+__device__ __forceinline__ bool mm_tile_matches(const MmTileArgs &a, const MmPlanLds &P, const uint8_t *tile, int q)
+{
+   const int L = (int)a.plan.L, S = (int)a.g.S;
+   const bool be = a.g.big_endian != 0;
+   for (int i = L - 1; i >= 0; --i) {
+      const int ci = mm_tile_elem(tile, q + i, S, be);
+      const int pi = mm_tile_elem(tile, q + i + P.bridge[i], S, be);
+      if (((uint32_t)((ci - pi) ^ P.expected[i]) & P.cmp_mask[i]) != 0) {
+         return false;
+      }
+   }
+   return true;
+}
+
 template <int BITS>
 __device__ __forceinline__ void mm_tile_map(const MmTileArgs &a, const MmPlanLds &P, MmWaveLds &W, uint64_t start, int64_t lo,
-                                            int npos, uint32_t lo_mod, int lane, MmPhaseMap<BITS> &M)
+                                            int npos, uint32_t lo_mod, int lane, MmPhaseMap<BITS> &M,
+                                            bool *end_matches = nullptr)
 {
    start = mm_uniform64(start);
    lo = (int64_t)mm_uniform64((uint64_t)lo);
@@ -302,6 +320,11 @@ __device__ __forceinline__ void mm_tile_map(const MmTileArgs &a, const MmPlanLds
       c = cn;
       pv = pn;
    }
+   if (end_matches) {
+      // position npos itself (the candidate in front of which this window ends); only
+      // meaningful when the domain holds L elements from there, which the caller checked
+      *end_matches = mm_tile_matches(a, P, tile, npos);
+   }
    mm_wave_sync();                                        // the tile buffer may be restaged now
 }
 
@@ -322,9 +345,11 @@ __device__ __forceinline__ uint32_t mm_pull_back(uint32_t A, int D, const MmPhas
 
 struct MmResolveArgs {
    MmTileArgs t;
-   const uint64_t *cand;
-   const unsigned long long *cand_count;
-   uint64_t cand_cap;
+   const uint64_t *cand;                      // MM_CAND_LISTS candidate lists of list_cap entries (filter output)
+   const unsigned long long *list_count;      // their counters, MM_LIST_STRIDE words apart
+   uint64_t list_cap;
+   unsigned long long *total_out;             // compact candidate count (~0: a list overflowed), for the later stages
+   uint64_t out_cap;
    // One result slot per candidate: the reported value of a match, MM_NO_MATCH otherwise.
    // (A shared append counter would serialise: one device-scope atomic address takes
    // ~11 ns per add, i.e. ~50 us for the bench's 4 K candidates.)
@@ -341,7 +366,6 @@ struct MmResolveArgs {
 };
 
 constexpr uint64_t MM_NO_MATCH = ~0ull;
-constexpr int MM_STAT_STRIPES = 16;
 
 __device__ __forceinline__ uint64_t mm_report_value(const MmGeom &g, uint64_t o, uint64_t base_offset)
 {
@@ -354,8 +378,24 @@ __device__ __forceinline__ void mm_resolve_body(const MmResolveArgs &a, const Mm
    const int D = (int)a.t.plan.L - 1;
    const int wave = (int)mm_uniform(threadIdx.x >> 6);
    const int lane = threadIdx.x & 63;
-   const unsigned long long ncand = *a.cand_count;
-   if (ncand > a.cand_cap || ncand > a.max_candidates) {
+   // the filter's MM_CAND_LISTS (= 64 = one per lane) lists get one compact numbering:
+   // candidate ci is entry ci - excl[c] of the list c with excl[c] <= ci < excl[c+1]
+   const unsigned long long my_count = a.list_count[lane * MM_LIST_STRIDE];
+   unsigned long long incl = my_count;
+#pragma unroll
+   for (int d = 1; d < 64; d <<= 1) {
+      const unsigned long long v = __shfl_up(incl, d);
+      incl += lane >= d ? v : 0ull;
+   }
+   const unsigned long long excl = incl - my_count;
+   unsigned long long ncand = __shfl(incl, 63);
+   if (__ballot(my_count > a.list_cap) != 0) {
+      ncand = ~0ull;                           // a list overflowed
+   }
+   if (blockIdx.x == 0 && threadIdx.x == 0) {
+      *a.total_out = ncand;
+   }
+   if (ncand > a.out_cap || ncand > a.max_candidates) {
       return;                                  // dense input: the host runs another engine
    }
    const uint64_t nwaves = (uint64_t)gridDim.x * MM_WAVES;
@@ -363,25 +403,44 @@ __device__ __forceinline__ void mm_resolve_body(const MmResolveArgs &a, const Mm
    unsigned long long walked = 0;
 
    for (uint64_t ci = (uint64_t)blockIdx.x * MM_WAVES + wave; ci < ncand; ci += nwaves) {
-      const uint64_t o = a.cand[ci];
+      const int list = __popcll(__ballot(excl <= ci)) - 1;
+      const uint64_t o = a.cand[(uint64_t)list * a.list_cap + (ci - __shfl(excl, list))];
       uint64_t b; uint32_t p; int64_t jc;
-      mm_locate(a.t.g, o, &b, &p, &jc);        // the filter only appends valid alignments
+      if (!mm_locate(a.t.g, o, &b, &p, &jc)) {
+         // SWAR survivor that is not an alignment of any domain (file tail, 16-bit odd boundary)
+         if (lane == 0) {
+            a.out[ci] = MM_NO_MATCH;
+         }
+         continue;
+      }
       const uint64_t start = mm_domain_start(a.t.g, b, p);
 
       uint32_t A = 1u << (uint32_t)(jc % D);
       int64_t hi = jc;
       int verdict = -1;                        // 1 visited, 0 not visited, -1 undecided
+      if (jc == 0) {
+         // first alignment of its domain: always visited, but is it a match?  (no window to
+         // stage in front of it: read the elements directly)
+         bool matched;
+         mm_step(a.t.plan, [&](int64_t k) { return mm_elem(a.t.g, start, k); }, 0, &matched);
+         verdict = matched ? 1 : 0;
+      }
       // Look-back windows grow 256 -> 2048 positions and end on multiples of their size:
       // a true match pulls every phase onto itself within a few keyword lengths (that is
       // what the bad-character rule is for), so the first short window usually settles
       // it; after the last step the frontier is tile aligned for mm_hard_resolve.
-      for (int step = 0; step < MM_FAST_STEPS && hi > 0; step++) {
+      for (int step = 0; step < MM_FAST_STEPS && hi > 0 && verdict < 0; step++) {
          const int64_t gran = (int64_t)(MM_TILE >> (MM_FAST_STEPS - 1 - step));
          const int64_t lo = ((hi - 1) / gran) * gran;
          MmPhaseMap<BITS> M;
-         mm_tile_map<BITS>(a.t, P, W, start, lo, (int)(hi - lo), (uint32_t)(lo % D), lane, M);
-         A = mm_pull_back<BITS>(A, D, M);
+         bool is_match = true;
+         mm_tile_map<BITS>(a.t, P, W, start, lo, (int)(hi - lo), (uint32_t)(lo % D), lane, M, step == 0 ? &is_match : nullptr);
          walked++;
+         if (!is_match) {
+            verdict = 0;                        // survived the SWAR conditions only
+            break;
+         }
+         A = mm_pull_back<BITS>(A, D, M);
          hi = lo;
          if (A == full || A == 0) {
             verdict = A ? 1 : 0;
