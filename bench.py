@@ -169,6 +169,15 @@ def main():
         assert (np.diff(offs.astype(np.int64)) > 0).all(), "gathered offsets are not ascending"
         filt = float(np.mean(filt_ms))
         achieved = shard / (filt * 1e-3) / 1e9
+        # HBM traffic per launch comes from PMC counters, which need their own rocprofv3 passes
+        # (profiles/README.md); scale the committed measurement to this run's shard size
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        if os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                pmc = json.load(f)
+            traffic = pmc["hbm_traffic_bytes_per_launch"] * shard / pmc["algorithmic_bytes_per_launch"]
+            traffic_src = "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per the gfx950 rule)"
         res = {
             "metric": "GB/s scanned (4 GiB synthetic ROM per GPU, 12-char 8-bit relative pattern)",
             "value": total * args.steps / elapsed / 1e9,
@@ -199,7 +208,9 @@ def main():
                 "peak": PEAK_HBM_GBS,
                 "unit": "GB/s",
                 "frac": achieved / PEAK_HBM_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
+                "algorithmic_bytes": shard,
                 "kernel_ms": filt,
                 "scan_device_ms": float(np.mean(tot_ms)),
             },

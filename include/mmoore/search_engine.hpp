@@ -1,0 +1,75 @@
+// search_engine.hpp -- SearchEngine<T>, the file-level driver of the mmoore API, backed by
+// the MI355X engine.
+//
+// Public surface = the reference's include/mmoore/search_engine.hpp:14-59 (SearchResult,
+// SearchConfig with the same fields and defaults, SearchStep, SearchEngine<T>::run).
+// What changed behind it: the thread-per-block dispatcher (src/core/search_engine.cpp:66-188)
+// is gone.  The file is streamed to HBM in block-aligned partitions and each partition is
+// scanned with the reference's block semantics (chain restart per block and per byte
+// alignment, (L-1)*sizeof(T) overlap) by the GPU; offsets are global byte offsets.
+//   * preferred_search_block_size keeps its meaning (it changes results in the reference too)
+//   * preferred_num_threads is accepted and ignored: it never changed results
+//   * block offsets are 64 bit (the reference multiplies in 32 bit, :241-242, and breaks
+//     above 4 GiB)
+//   * progress: (0, Initializing), (0, Searching), one (pct, Searching) per reference block,
+//     (100, GeneratingPreviews) -- blocks + 3 calls, monotone, all from the calling thread
+//   * abort: polled after every progress callback and between partitions; run() returns {}
+//   * a missing file throws std::runtime_error("File not found") before any callback
+#ifndef MMOORE_AMD_SEARCH_ENGINE_HPP
+#define MMOORE_AMD_SEARCH_ENGINE_HPP
+
+#include <atomic>
+#include <filesystem>
+#include <functional>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "mmoore/byteswap.hpp"
+#include "mmoore/monkey_moore.hpp"
+
+namespace mmoore {
+
+template <typename DataType>
+struct SearchResult {
+   uint64_t offset;                                                 // byte offset in the file
+   typename MonkeyMoore<DataType>::equivalency_map values_map;
+   std::string preview;                                             // filled when previews are requested
+};
+
+struct SearchConfig {
+   std::filesystem::path file_path;
+
+   bool is_relative_search = true;                 // false: value scan of reference_values
+   mmoore::Endianness endianness = Endianness::Little;
+
+   std::vector<CharType> keyword;
+   std::vector<CharType> custom_char_seq = {};
+   CharType wildcard = '*';
+
+   std::vector<short> reference_values = {};
+
+   int preferred_num_threads = std::thread::hardware_concurrency();
+   int preferred_search_block_size = 524288;
+   int preferred_preview_width = 50;
+};
+
+enum SearchStep { Initializing, Searching, GeneratingPreviews, Aborting };
+
+template <typename DataType>
+class SearchEngine {
+public:
+   using ProgressCallback = std::function<void(int, const SearchStep)>;
+
+   explicit SearchEngine(const SearchConfig &cfg) : config(cfg) {}
+
+   std::vector<SearchResult<DataType>> run(ProgressCallback on_progress, std::atomic<bool> &abort_flag,
+                                           bool generate_previews = false);
+
+private:
+   SearchConfig config;
+};
+
+} // namespace mmoore
+
+#endif

@@ -1,0 +1,188 @@
+// facade_tests.cpp -- the reference's Catch2 suites (tests/test_monkey_moore.cpp,
+// tests/test_search_engine.cpp) replayed against the MI355X facade through the SAME public
+// API (MonkeyMoore<T>, SearchEngine<T>).  Catch2 is not installed in the image, so this is a
+// plain executable; the vectors come from tests/golden/kat_*.json via gen_cases.py.
+// Needs a GPU.  Exit code 0 = all checks passed.
+#include <atomic>
+#include <unistd.h>
+#include <cstdio>
+#include <fstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "mmoore/monkey_moore.hpp"
+#include "mmoore/search_engine.hpp"
+#include "mmoore/text_utils.hpp"
+
+struct MatcherCase {
+   const char *name; int elem; std::vector<uint32_t> data; bool has_values; std::vector<short> values;
+   std::vector<char32_t> keyword; char32_t wildcard; std::vector<char32_t> seq; std::vector<uint64_t> expect;
+   std::vector<std::vector<std::pair<char32_t, uint32_t>>> maps;
+};
+struct EngineCase {
+   const char *name; int elem; std::vector<uint8_t> file; std::vector<char32_t> keyword; char32_t wildcard;
+   std::vector<char32_t> seq; bool big_endian; std::vector<int> block_sizes; std::vector<int> threads; int preview_width;
+   std::vector<uint64_t> expect; bool with_previews; std::vector<std::string> previews;
+};
+#include "cases.inc"
+
+static int failures = 0, checks = 0;
+#define CHECK(cond, ...) do { checks++; if (!(cond)) { failures++; std::printf("FAIL %s:%d: %s -- ", __FILE__, __LINE__, #cond); std::printf(__VA_ARGS__); std::printf("\n"); } } while (0)
+
+struct TempFile {
+   std::filesystem::path path;
+   explicit TempFile(const std::vector<uint8_t> &bytes)
+   {
+      path = std::filesystem::temp_directory_path() / ("mmoore_amd_blob_" + std::to_string(::getpid()) + ".bin");
+      std::ofstream f(path, std::ios::binary);
+      f.write(reinterpret_cast<const char *>(bytes.data()), static_cast<std::streamsize>(bytes.size()));
+   }
+   ~TempFile() { std::filesystem::remove(path); }
+};
+
+template <class Ty>
+static void run_matcher(const MatcherCase &c)
+{
+   std::vector<Ty> data(c.data.begin(), c.data.end());
+   std::vector<typename MonkeyMoore<Ty>::result_type> got;
+   if (c.has_values) {
+      MonkeyMoore<Ty> m(c.values);
+      got = m.search(data.data(), data.size());
+   }
+   else {
+      MonkeyMoore<Ty> m(c.keyword, c.wildcard, c.seq);
+      got = m.search(data.data(), data.size());
+   }
+   CHECK(got.size() == c.expect.size(), "%s: %zu results, expected %zu", c.name, got.size(), c.expect.size());
+   for (size_t i = 0; i < got.size() && i < c.expect.size(); i++) {
+      CHECK(got[i].first == c.expect[i], "%s: result %zu at %llu, expected %llu", c.name, i,
+            (unsigned long long)got[i].first, (unsigned long long)c.expect[i]);
+      if (i < c.maps.size()) {
+         CHECK(got[i].second.size() == c.maps[i].size(), "%s: map size %zu vs %zu", c.name, got[i].second.size(), c.maps[i].size());
+         for (auto &kv : c.maps[i]) {
+            auto it = got[i].second.find(kv.first);
+            CHECK(it != got[i].second.end() && it->second == static_cast<Ty>(kv.second), "%s: map entry U+%04X", c.name, (unsigned)kv.first);
+         }
+      }
+   }
+}
+
+template <class Ty>
+static void run_engine(const EngineCase &c)
+{
+   TempFile tmp(c.file);
+   for (int bs : c.block_sizes) {
+      for (int th : c.threads) {
+         mmoore::SearchConfig cfg;
+         cfg.file_path = tmp.path;
+         cfg.keyword = c.keyword;
+         cfg.wildcard = c.wildcard;
+         cfg.custom_char_seq = c.seq;
+         cfg.endianness = c.big_endian ? mmoore::Endianness::Big : mmoore::Endianness::Little;
+         cfg.preferred_num_threads = th;
+         cfg.preferred_search_block_size = bs;
+         cfg.preferred_preview_width = c.preview_width;
+         std::atomic<bool> abort{false};
+         mmoore::SearchEngine<Ty> engine(cfg);
+         auto got = engine.run([](int, const mmoore::SearchStep) {}, abort, c.with_previews);
+         CHECK(got.size() == c.expect.size(), "%s block %d: %zu results, expected %zu", c.name, bs, got.size(), c.expect.size());
+         for (size_t i = 0; i < got.size() && i < c.expect.size(); i++) {
+            CHECK(got[i].offset == c.expect[i], "%s block %d: offset %llu, expected %llu", c.name, bs,
+                  (unsigned long long)got[i].offset, (unsigned long long)c.expect[i]);
+            if (c.with_previews && i < c.previews.size()) {
+               CHECK(got[i].preview == c.previews[i], "%s: preview '%s' vs '%s'", c.name, got[i].preview.c_str(), c.previews[i].c_str());
+            }
+         }
+      }
+   }
+}
+
+int main()
+{
+   for (auto &c : matcher_cases) {
+      c.elem == 1 ? run_matcher<uint8_t>(c) : run_matcher<uint16_t>(c);
+   }
+   for (auto &c : engine_cases) {
+      c.elem == 1 ? run_engine<uint8_t>(c) : run_engine<uint16_t>(c);
+   }
+
+   // error handling (test_search_engine.cpp:350-360)
+   {
+      mmoore::SearchConfig cfg;
+      cfg.file_path = "path/to/inexistent/file";
+      std::atomic<bool> abort{false};
+      mmoore::SearchEngine<uint8_t> engine(cfg);
+      bool threw = false;
+      int calls = 0;
+      try {
+         engine.run([&](int, const mmoore::SearchStep) { calls++; }, abort);
+      }
+      catch (const std::runtime_error &) {
+         threw = true;
+      }
+      CHECK(threw && calls == 0, "missing file must throw before any callback");
+   }
+   // rejected keywords surface as std::runtime_error
+   {
+      bool threw = false;
+      try {
+         MonkeyMoore<uint8_t> m(std::vector<CharType>{0x3042, 0x41});
+      }
+      catch (const std::runtime_error &) {
+         threw = true;
+      }
+      CHECK(threw, "8-bit keyword with a delta beyond 255 must throw");
+   }
+   // progress reporting (test_search_engine.cpp:362-397)
+   {
+      TempFile tmp(std::vector<uint8_t>(128, 0));
+      mmoore::SearchConfig cfg;
+      cfg.file_path = tmp.path;
+      cfg.keyword = {'t', 'e', 'x', 't'};
+      cfg.preferred_num_threads = 1;
+      cfg.preferred_search_block_size = 16;
+      std::atomic<bool> abort{false};
+      std::vector<int> history;
+      mmoore::SearchEngine<uint8_t> engine(cfg);
+      engine.run([&](int pct, const mmoore::SearchStep) { history.push_back(pct); }, abort);
+      CHECK(history.size() == 11, "progress: %zu callbacks, expected 8 blocks + 3", history.size());
+      CHECK(!history.empty() && history.back() == 100, "progress must end at 100");
+      bool monotone = true;
+      for (size_t i = 1; i < history.size(); i++) {
+         monotone = monotone && history[i] >= history[i - 1];
+      }
+      CHECK(monotone, "progress must be monotone");
+   }
+   // abort (test_search_engine.cpp:399-427)
+   {
+      std::string text = "match#catch#batch#match#patch#hatch#match";
+      std::vector<uint8_t> bytes;
+      for (char ch : text) {
+         bytes.push_back(static_cast<uint8_t>(ch + 0x30));
+      }
+      TempFile tmp(bytes);
+      mmoore::SearchConfig cfg;
+      cfg.file_path = tmp.path;
+      cfg.keyword = {'m', 'a', 't', 'c', 'h'};
+      cfg.preferred_search_block_size = 5;
+      cfg.preferred_num_threads = 1;
+      std::atomic<bool> abort{false};
+      int calls = 0;
+      mmoore::SearchEngine<uint8_t> engine(cfg);
+      auto got = engine.run([&](int, const mmoore::SearchStep) { if (++calls >= 5) abort = true; }, abort, false);
+      CHECK(got.empty() && calls <= 5, "abort: %zu results after %d callbacks", got.size(), calls);
+   }
+   // text_utils (test_text_utils.cpp): spot checks of the helpers the harness uses
+   {
+      std::vector<char32_t> v = {'*', '*', 'a', '*', 'b'};
+      CHECK(find_last_index(v.begin(), v.end(), U'*') == 3, "find_last_index");
+      CHECK(find_last_index(v.begin(), v.end(), U'z') == -1, "find_last_index miss");
+      CHECK(count_prefix_length(v.begin(), v.end(), U'*') == 2, "count_prefix_length");
+      CHECK(is_ascii_upper(U'Q') && !is_ascii_upper(U'q') && !is_ascii_upper(0x3042), "is_ascii_upper");
+      CHECK(is_ascii_lower(U'q') && is_ascii_digit(U'7') && !is_ascii_digit(U'x'), "is_ascii_lower/digit");
+      CHECK(mmoore::swap_always<uint16_t>(0x1234) == 0x3412 && mmoore::swap_always<uint32_t>(0x11223344u) == 0x44332211u, "swap_always");
+   }
+   std::printf("%d checks, %d failures\n", checks, failures);
+   return failures ? 1 : 0;
+}
