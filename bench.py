@@ -100,8 +100,8 @@ def main():
     per_gpu = int(args.gib_per_gpu * (1 << 30)) // BLOCK * BLOCK
     total = per_gpu * world
     L = len(KEYWORD)
-    base = rank * per_gpu
-    shard = min(per_gpu + (L - 1), total - base)          # pattern-length overlap into the next partition
+    # block-aligned partition + pattern-length overlap into the next one
+    base, shard = mm.partition.shard_range(total, BLOCK, L, 1, rank, world)
 
     # HBM-resident shard owned by torch; the engine borrows the pointer and runs on torch's stream
     buf = torch.empty(shard + 32, dtype=torch.uint8, device=dev)
@@ -118,18 +118,8 @@ def main():
         if world == 1:
             return offs
         # RCCL gather of the per-GPU offset lists (already ascending, partitions in rank order)
-        n = torch.tensor([len(offs)], dtype=torch.int64, device=dev)
-        counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(counts, n)
-        counts = [int(c.item()) for c in counts]
-        mx = max(max(counts), 1)
-        mine = torch.zeros(mx, dtype=torch.int64, device=dev)
-        mine[: len(offs)] = torch.from_numpy(offs.astype(np.int64)).to(dev)
-        gathered = [torch.empty(mx, dtype=torch.int64, device=dev) for _ in range(world)] if rank == 0 else None
-        dist.gather(mine, gathered, dst=0)
-        if rank == 0:
-            return torch.cat([g[:c] for g, c in zip(gathered, counts)]).cpu().numpy().astype(np.uint64)
-        return offs
+        merged = mm.partition.gather_offsets(offs, rank, world, dev, dist)
+        return merged if rank == 0 else offs
 
     def fence():
         if world > 1:

@@ -1,0 +1,75 @@
+"""The N > 1 path on CPU: 2 processes, gloo.  Each rank takes its block-aligned partition
+(monkey-moore_amd/partition.py, the code bench.py uses), produces its offsets (with the
+oracle here -- there is no GPU in this suite) and the lists are gathered to rank 0, which
+must hold exactly the offsets of the whole ROM, ascending."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_package
+
+
+def _worker(rank, world, port, total, block, kw, elem, be, q):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from _oracle import Oracle
+    from conftest import load_package as lp
+    mm = lp()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        orc = Oracle()
+        plan = orc.plan(elem, kw)
+        spec_all = mm.synth.RomSpec(42, total, kw, elem, None, be, block, partitions=world, runs=False)
+        first, nbytes = mm.partition.shard_range(total, block, len(kw), elem, rank, world)
+        spec = mm.synth.RomSpec(42, total, kw, elem, None, be, block, base=first, nbytes=nbytes, partitions=world, runs=False)
+        rom = spec.host_rom()
+        assert (rom == spec_all.host_rom()[first:first + nbytes]).all()       # shard generation == slice of the whole
+        local = orc.engine(plan, rom, block, be) + np.uint64(first)
+        merged = mm.partition.gather_offsets(local, rank, world, torch.device("cpu"), dist)
+        if rank == 0:
+            want = orc.engine(plan, spec_all.host_rom(), block, be)
+            q.put((merged.tolist(), want.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("elem,kw,be", [(1, "relativesrch", False), (2, "textsrch", True)])
+def test_partition_and_gather_world2(elem, kw, be):
+    import torch.multiprocessing as mp
+    load_package()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    total, block = (6 << 20) + 4099, 65536
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, block, kw, elem, be, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, want = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == want
+    assert len(got) >= 6 and got == sorted(got)
+
+
+def test_shard_ranges_tile_the_rom():
+    mm = load_package()
+    total, block, L = (64 << 20) + 12345, 524288, 12
+    for world in (1, 2, 4, 8):
+        covered = 0
+        for r in range(world):
+            first, n = mm.partition.shard_range(total, block, L, 1, r, world)
+            assert first % block == 0 and first == covered
+            nxt = mm.partition.shard_range(total, block, L, 1, r + 1, world)[0] if r + 1 < world else total
+            assert first + n == min(nxt + L - 1, total)
+            covered = nxt
+        assert covered == total
