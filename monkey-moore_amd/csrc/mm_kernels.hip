@@ -367,87 +367,174 @@ __global__ __launch_bounds__(256) void mm_filter_u8(MmFilterArgs a)
 // --------------------------------------------------------------------------
 //
 // For every byte position u the element e(u) = 16 bits at bytes u,u+1 (file
-// endianness).  Hit when (e(u) - e(u-2)) mod 65536 == patA, candidate start
-// o = u - 2*iA.  Even and odd u are two SWAR streams over the same registers.
+// endianness; big endian = v_perm_b32 on the register).  Conditions
+//     (e(u)   - e(u-2)) mod 65536 == pat[0]        delta of keyword position iA
+//     (e(u-2) - e(u-4)) mod 65536 == pat[1]        delta of position iA-1 (NCOND == 2)
+// candidate start o = u - 2*iA.  Even and odd u are two SWAR streams (2 positions per
+// 32-bit op, v_pk_sub_u16) over the same registers: the ROM is read once for both of the
+// reference's byte alignments (search_engine.cpp:129-147 copies and scans the block twice).
+// The odd stream with two conditions looks 12 bytes back: r[0..2] are the three dwords in
+// front of the chunk, r[3..6] the chunk.
 
-__device__ __forceinline__ uint32_t mm_f16_hits(uint32_t cur, uint32_t prev, uint32_t patA)
+template <int NCOND>
+__device__ __forceinline__ uint32_t mm_f16_chunk(const uint32_t (&r)[7], bool be, const uint32_t (&pat)[4],
+                                                 uint32_t (&he)[4], uint32_t (&ho)[4])
 {
-   uint32_t d = mm_sub16x2(cur, mm_alignbit(cur, prev, 16));
-   return mm_haszero16(d ^ patA);
+   uint32_t ev[7], od[7], de[7], dd[7];
+#pragma unroll
+   for (int k = 0; k < 7; k++) {
+      ev[k] = be ? mm_bswap16x2(r[k]) : r[k];                       // elements at bytes 4k, 4k+2
+   }
+#pragma unroll
+   for (int k = 1; k < 7; k++) {
+      const uint32_t o = mm_alignbit(r[k], r[k - 1], 24);           // bytes 4k-1 .. 4k+2
+      od[k] = be ? mm_bswap16x2(o) : o;                              // elements at bytes 4k-1, 4k+1
+      de[k] = mm_sub16x2(ev[k], mm_alignbit(ev[k], ev[k - 1], 16)); // even deltas
+   }
+#pragma unroll
+   for (int k = 2; k < 7; k++) {
+      dd[k] = mm_sub16x2(od[k], mm_alignbit(od[k], od[k - 1], 16)); // odd deltas
+   }
+   uint32_t any = 0;
+#pragma unroll
+   for (int j = 0; j < 4; j++) {
+      const int k = j + 3;
+      uint32_t ze = de[k] ^ pat[0];
+      uint32_t zo = dd[k] ^ pat[0];
+      if (NCOND >= 2) {
+         ze |= mm_alignbit(de[k], de[k - 1], 16) ^ pat[1];
+         zo |= mm_alignbit(dd[k], dd[k - 1], 16) ^ pat[1];
+      }
+      he[j] = mm_haszero16(ze);
+      ho[j] = mm_haszero16(zo);
+      any |= he[j] | ho[j];
+   }
+   return any;
 }
 
-__global__ __launch_bounds__(256) void mm_filter_u16(MmFilterArgs a)
+// 16 flags of a chunk: bit 4*j + 2*odd + half
+__device__ __forceinline__ uint32_t mm_f16_pack(const uint32_t (&he)[4], const uint32_t (&ho)[4])
+{
+   uint32_t bits = 0;
+#pragma unroll
+   for (int j = 0; j < 4; j++) {
+      const uint32_t e = ((he[j] >> 15) & 1u) | ((he[j] >> 30) & 2u);
+      const uint32_t o = ((ho[j] >> 15) & 1u) | ((ho[j] >> 30) & 2u);
+      bits |= (e | (o << 2)) << (4 * j);
+   }
+   return bits;
+}
+
+__device__ __forceinline__ void mm_f16_survivors(const MmFilterArgs &a, uint64_t chunk0, uint32_t bits)
+{
+   while (__ballot(bits != 0) != 0) {
+      bool want = false;
+      uint64_t off = 0;
+      if (bits) {
+         const int bit = __ffs((int)bits) - 1;
+         bits &= bits - 1;
+         const int j = bit >> 2, odd = (bit >> 1) & 1, half = bit & 1;
+         const int64_t u = (int64_t)(chunk0 + 4 * j + 2 * half) - odd;
+         const int64_t o = u - 2 * (int64_t)a.iA;
+         if (a.verify ? mm_is_candidate(a.g, a.plan, o) : (o >= 0)) {
+            want = true;
+            off = (uint64_t)o;
+         }
+      }
+      mm_cand_append(a, want, off);
+   }
+}
+
+// bounds-checked version for the ragged end of the ROM
+template <int NCOND>
+__global__ __launch_bounds__(256) void mm_filter_u16_edge(MmFilterArgs a)
 {
    const uint64_t nchunks = (a.g.nbytes + 15) / 16;
    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-   constexpr int UNROLL = 2;
    const bool be = a.g.big_endian != 0;
-   const uint64_t iters = (nchunks + stride * UNROLL - 1) / (stride * UNROLL);
-
+   const uint64_t iters = (nchunks - a.edge_first + stride - 1) / stride;
+   const uint32_t *rom1 = reinterpret_cast<const uint32_t *>(a.g.rom);
    for (uint64_t it = 0; it < iters; it++) {
-      const uint64_t c0 = it * stride * UNROLL + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-      uint4 w[UNROLL];
-      uint2 back[UNROLL];
-      uint32_t he[UNROLL][4], ho[UNROLL][4];
+      const uint64_t c = a.edge_first + it * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+      uint32_t he[4] = {0, 0, 0, 0}, ho[4] = {0, 0, 0, 0};
       uint32_t any = 0;
-#pragma unroll
-      for (int u = 0; u < UNROLL; u++) {
-         uint64_t c = c0 + stride * u;
-         if (c < nchunks) {
-            w[u] = mm_load_chunk(a.g.rom, a.g.nbytes, c * 16);
-            back[u] = c ? *reinterpret_cast<const uint2 *>(a.g.rom + c * 16 - 8) : make_uint2(0, 0);
+      if (c < nchunks) {
+         const uint4 w = mm_load_chunk(a.g.rom, a.g.nbytes, c * 16);
+         uint32_t r[7] = {0, 0, 0, w.x, w.y, w.z, w.w};
+         if (c) {
+            r[0] = rom1[c * 4 - 3]; r[1] = rom1[c * 4 - 2]; r[2] = rom1[c * 4 - 1];
          }
-         else {
-            w[u] = make_uint4(0, 0, 0, 0);
-            back[u] = make_uint2(0, 0);
-         }
+         any = mm_f16_chunk<NCOND>(r, be, a.pat, he, ho);
       }
-#pragma unroll
-      for (int u = 0; u < UNROLL; u++) {
-         uint32_t r[6] = {back[u].x, back[u].y, w[u].x, w[u].y, w[u].z, w[u].w};
-         uint32_t ev[6], od[6];
-#pragma unroll
-         for (int k = 0; k < 6; k++) {
-            ev[k] = be ? mm_bswap16x2(r[k]) : r[k];                 // elements at bytes 4k, 4k+2
-         }
-#pragma unroll
-         for (int k = 1; k < 6; k++) {
-            uint32_t o = mm_alignbit(r[k], r[k - 1], 24);           // bytes 4k-1 .. 4k+2
-            od[k] = be ? mm_bswap16x2(o) : o;                        // elements at bytes 4k-1, 4k+1
-         }
-#pragma unroll
-         for (int k = 0; k < 4; k++) {
-            he[u][k] = mm_f16_hits(ev[k + 2], ev[k + 1], a.pat[0]);
-            ho[u][k] = mm_f16_hits(od[k + 2], od[k + 1], a.pat[0]);
-            any |= he[u][k] | ho[u][k];
-         }
+      if (__ballot(any != 0) != 0) {
+         mm_f16_survivors(a, c * 16, mm_f16_pack(he, ho));
       }
-      if (__ballot(any != 0) == 0) {
-         continue;
+   }
+}
+
+// span kernel: same streaming structure as mm_filter_u8 (4 KiB groups, two groups of
+// look-ahead, look-back through DPP wave_shr:1 / v_readlane instead of a second load)
+template <int NCOND>
+__global__ __launch_bounds__(256) void mm_filter_u16(MmFilterArgs a)
+{
+   constexpr int DEPTH = 2;
+   const uint32_t lane = threadIdx.x & 63;
+   const bool be = a.g.big_endian != 0;
+   const uint64_t wave = __builtin_amdgcn_readfirstlane((uint32_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+   const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+   const uint64_t gps = a.groups_per_span;
+   const uint4 *rom4 = reinterpret_cast<const uint4 *>(a.g.rom);
+   const uint32_t *rom1 = reinterpret_cast<const uint32_t *>(a.g.rom);
+
+   for (uint64_t g0 = wave * gps; g0 < a.ngroups; g0 += nwaves * gps) {
+      const uint64_t g1 = g0 + gps < a.ngroups ? g0 + gps : a.ngroups;
+      // the three dwords in front of the span (wave uniform)
+      uint32_t c1 = 0, c2 = 0, c3 = 0;
+      if (g0) {
+         c1 = rom1[g0 * 1024 - 3]; c2 = rom1[g0 * 1024 - 2]; c3 = rom1[g0 * 1024 - 1];
       }
+      uint4 w[DEPTH + 1][4];
 #pragma unroll
-      for (int u = 0; u < UNROLL; u++) {
-         uint64_t c = c0 + stride * u;
+      for (int d = 0; d < DEPTH; d++) {
+         const uint64_t gg = g0 + d < g1 ? g0 + d : g1 - 1;
+         const uint4 *p = rom4 + gg * 256 + lane;
+         w[d][0] = p[0]; w[d][1] = p[64]; w[d][2] = p[128]; w[d][3] = p[192];
+      }
+      for (uint64_t g = g0; g < g1; g += DEPTH + 1) {
 #pragma unroll
-         for (int k = 0; k < 4; k++) {
+         for (int s = 0; s <= DEPTH; s++) {
+            constexpr int RING = DEPTH + 1;
+            const int slot_new = (s + DEPTH) % RING;
+            const uint64_t gn = g + s + DEPTH < g1 ? g + s + DEPTH : g1 - 1;
+            const uint4 *pn = rom4 + gn * 256 + lane;
+            w[slot_new][0] = pn[0]; w[slot_new][1] = pn[64]; w[slot_new][2] = pn[128]; w[slot_new][3] = pn[192];
+            if (g + s < g1) {
+               uint32_t he[4][4], ho[4][4];
+               uint32_t any = 0;
 #pragma unroll
-            for (int par = 0; par < 2; par++) {
-               uint32_t h = (c < nchunks) ? (par ? ho[u][k] : he[u][k]) : 0u;
-               while (__ballot(h != 0) != 0) {
-                  bool want = false;
-                  uint64_t off = 0;
-                  if (h) {
-                     int bit = __ffs((int)h) - 1;
-                     h &= h - 1;
-                     // bit 15 -> low half, bit 31 -> high half
-                     int64_t ubyte = (int64_t)(c * 16 + 4 * k + ((bit >> 4) << 1)) - (par ? 1 : 0);
-                     int64_t o = ubyte - 2 * (int64_t)a.iA;
-                     if (mm_is_candidate(a.g, a.plan, o)) {
-                        want = true;
-                        off = (uint64_t)o;
-                     }
+               for (int u = 0; u < 4; u++) {
+                  // dwords -3..-1 of this chunk: lane l-1's y, z, w; lane 0 keeps the carries
+                  const uint32_t k1 = u == 0 ? c1 : __builtin_amdgcn_readlane(w[s][u - 1].y, 63);
+                  const uint32_t k2 = u == 0 ? c2 : __builtin_amdgcn_readlane(w[s][u - 1].z, 63);
+                  const uint32_t k3 = u == 0 ? c3 : __builtin_amdgcn_readlane(w[s][u - 1].w, 63);
+                  uint32_t r[7];
+                  r[0] = __builtin_amdgcn_update_dpp(k1, w[s][u].y, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                  r[1] = __builtin_amdgcn_update_dpp(k2, w[s][u].z, 0x138, 0xf, 0xf, false);
+                  r[2] = __builtin_amdgcn_update_dpp(k3, w[s][u].w, 0x138, 0xf, 0xf, false);
+                  r[3] = w[s][u].x; r[4] = w[s][u].y; r[5] = w[s][u].z; r[6] = w[s][u].w;
+                  any |= mm_f16_chunk<NCOND>(r, be, a.pat, he[u], ho[u]);
+               }
+               c1 = __builtin_amdgcn_readlane(w[s][3].y, 63);
+               c2 = __builtin_amdgcn_readlane(w[s][3].z, 63);
+               c3 = __builtin_amdgcn_readlane(w[s][3].w, 63);
+               if (__ballot(any != 0) != 0) {
+#pragma unroll 1
+                  for (int u = 0; u < 4; u++) {
+                     const uint32_t bits = u == 0 ? mm_f16_pack(he[0], ho[0])
+                                                  : (u == 1 ? mm_f16_pack(he[1], ho[1])
+                                                            : (u == 2 ? mm_f16_pack(he[2], ho[2]) : mm_f16_pack(he[3], ho[3])));
+                     mm_f16_survivors(a, (g + s) * 4096 + (uint64_t)u * 1024 + lane * 16, bits);
                   }
-                  mm_cand_append(a, want, off);
                }
             }
          }
@@ -637,17 +724,6 @@ __global__ __launch_bounds__(256) void mm_pattern_fill(uint8_t *rom, uint64_t fi
 
 namespace mm {
 
-static int filter_grid(uint64_t nbytes, int threads_per_chunk_group)
-{
-   uint64_t nchunks = (nbytes + 15) / 16;
-   uint64_t blocks = (nchunks + (uint64_t)256 * threads_per_chunk_group - 1) / ((uint64_t)256 * threads_per_chunk_group);
-   uint64_t cap = 256 * 8;                     // 256 CUs x 8 resident workgroups
-   if (blocks > cap) {
-      blocks = cap;
-   }
-   return (int)(blocks ? blocks : 1);
-}
-
 bool choose_filter(const mmh_plan_desc &pl, FilterChoice *fc)
 {
    const int L = (int)pl.L;
@@ -655,7 +731,7 @@ bool choose_filter(const mmh_plan_desc &pl, FilterChoice *fc)
    const uint32_t rep = pl.elem_bytes == 1 ? 0x01010101u : 0x00010001u;
    // position i can serve as a condition when it is a literal compared with its left neighbour
    auto adjacent = [&](int i) { return i >= 1 && pl.cmp_mask[i] != 0 && pl.bridge[i] == -1; };
-   const int want = pl.elem_bytes == 1 ? 4 : 1;
+   const int want = pl.elem_bytes == 1 ? 4 : 2;
    fc->ncond = 0;
    for (int nc = want; nc >= 1 && fc->ncond == 0; nc--) {
       for (int i = L - 1; i >= nc; --i) {
@@ -692,21 +768,38 @@ static void launch_filter_u8(hipStream_t st, const MmFilterArgs &a, const MmGeom
    }
 }
 
+template <int NCOND>
+static void launch_filter_u16(hipStream_t st, const MmFilterArgs &a, const MmGeom &g)
+{
+   if (a.ngroups) {
+      uint64_t spans = (a.ngroups + a.groups_per_span - 1) / a.groups_per_span;
+      uint64_t blocks = (spans + 3) / 4;
+      if (blocks > 256 * 8) {
+         blocks = 256 * 8;
+      }
+      hipLaunchKernelGGL(mm_filter_u16<NCOND>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+   }
+   if (a.edge_first * 16 < g.nbytes) {
+      hipLaunchKernelGGL(mm_filter_u16_edge<NCOND>, dim3(1), dim3(256), 0, st, a);
+   }
+}
+
 void launch_filter(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc,
                    uint64_t *cand, unsigned long long *ctrl, uint64_t cand_cap)
 {
    MmFilterArgs a;
    a.g = g; a.plan = pl; a.iA = fc.iA; a.ncond = fc.ncond;
-   a.verify = (pl.elem_bytes == 1 && fc.ncond == 4) ? 0u : 1u;
+   // enough SWAR conditions -> practically every survivor is real -> mm_resolve verifies it
+   a.verify = ((pl.elem_bytes == 1 && fc.ncond == 4) || (pl.elem_bytes == 2 && fc.ncond == 2)) ? 0u : 1u;
    for (int k = 0; k < 4; k++) {
       a.pat[k] = fc.pat[k];
    }
    a.cand = cand; a.list_count = ctrl + MM_CTRL_LISTS; a.list_cap = cand_cap / MM_CAND_LISTS;
-   a.ngroups = 0; a.groups_per_span = 16; a.edge_first = 0;
+   // whole 4 KiB groups go to the span kernel, the ragged end to the bounds-checked one
+   a.ngroups = g.nbytes / 4096;
+   a.groups_per_span = 16;
+   a.edge_first = a.ngroups * 256;
    if (pl.elem_bytes == 1) {
-      // whole 4 KiB groups go to the span kernel, the ragged end to the bounds-checked one
-      a.ngroups = g.nbytes / 4096;
-      a.edge_first = a.ngroups * 256;
       switch (fc.ncond) {
       case 4: launch_filter_u8<4>(st, a, g); break;
       case 3: launch_filter_u8<3>(st, a, g); break;
@@ -714,9 +807,11 @@ void launch_filter(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, con
       default: launch_filter_u8<1>(st, a, g); break;
       }
    }
+   else if (fc.ncond == 2) {
+      launch_filter_u16<2>(st, a, g);
+   }
    else {
-      int grid = filter_grid(g.nbytes, 2);
-      hipLaunchKernelGGL(mm_filter_u16, dim3(grid), dim3(256), 0, st, a);
+      launch_filter_u16<1>(st, a, g);
    }
 }
 

@@ -1,0 +1,22 @@
+"""Dev probe: stage timings of the BASELINE configs at full size (no oracle check)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from __graft_entry__ import load_package
+mm = load_package()
+eng = mm.Engine(0)
+cfgs = [("C2 u8 L12 4GiB", 4 << 30, "relativesrch", 1, None, False),
+        ("C3 u8 L16 3wc 4GiB", 4 << 30, "re*ative*ear*hxy", 1, ord("*"), False),
+        ("C4 u16 LE L8 8GiB", 8 << 30, "textsrch", 2, None, False),
+        ("C4' u16 BE L8 8GiB", 8 << 30, "textsrch", 2, None, True)]
+for name, n, kw, elem, wc, be in cfgs:
+    spec = mm.synth.RomSpec(42, n, kw, elem, wc, be)
+    eng.alloc(n)
+    spec.apply_device(eng)
+    plan = mm.plan_relative(elem, kw, wc or 0)
+    f, t = [], []
+    for i in range(60):
+        r = eng.scan(plan, block_bytes=524288, big_endian=be)
+        tm = eng.timings(); f.append(tm["filter_ms"]); t.append(tm["total_ms"])
+    k = 20
+    print("%-22s matches %6d  filter %.3f ms (%.0f GB/s)  total %.3f ms (%.0f GB/s)  %s %s" % (
+        name, len(r), sum(f[-k:]) / k, n / (sum(f[-k:]) / k) / 1e6, sum(t[-k:]) / k, n / (sum(t[-k:]) / k) / 1e6, eng.timings(), eng.counters()))
