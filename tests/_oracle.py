@@ -226,3 +226,25 @@ class Ref:
         finally:
             if tmp:
                 os.unlink(tmp)
+
+
+def oracle_engine_parallel(oracle, plan, rom, block_size, big_endian=False, workers=None):
+    """Oracle engine over a big ROM using several host cores: the ROM is cut on block
+    boundaries (every block x alignment is an independent chain), each slice --
+    with its (L-1)*S bytes of overlap -- goes through mmo_engine on its own thread
+    (ctypes releases the GIL), offsets are shifted and concatenated."""
+    from concurrent.futures import ThreadPoolExecutor
+    n = rom.size
+    nblocks = -(-n // block_size)
+    workers = workers or min(os.cpu_count() or 1, 64)
+    per = max(1, -(-nblocks // workers))
+    overlap = (plan.keyword_len - 1) * plan.elem_bytes
+
+    def run(b0):
+        first = b0 * block_size
+        end = min((b0 + per) * block_size + overlap, n)
+        return oracle.engine(plan, rom[first:end], block_size, big_endian) + np.uint64(first)
+
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        parts = list(ex.map(run, range(0, nblocks, per)))
+    return np.concatenate(parts) if parts else np.zeros(0, np.uint64)

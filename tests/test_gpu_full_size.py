@@ -1,0 +1,61 @@
+"""BASELINE.json's GPU configurations at their full sizes, bit-exact against the oracle
+(which is run over all host cores on block-aligned slices), plus size-independent
+properties.  Needs a real MI355X and ~10 GiB of host memory."""
+import numpy as np
+import pytest
+
+from _oracle import oracle_engine_parallel
+
+pytestmark = pytest.mark.gpu
+
+BLOCK = 524288
+
+
+def _download(eng, n, piece=1 << 30):
+    rom = np.empty(n, np.uint8)
+    for first in range(0, n, piece):
+        k = min(piece, n - first)
+        rom[first:first + k] = eng.download(first, k)
+    return rom
+
+
+def _full_config(mm, oracle, eng, nbytes, keyword, elem, wildcard=None, be=False):
+    spec = mm.synth.RomSpec(42, nbytes, keyword, elem, wildcard, be, BLOCK)
+    eng.alloc(nbytes)
+    spec.apply_device(eng)
+    wc = wildcard or 0
+    plan = mm.plan_relative(elem, keyword, wc)
+    got = eng.scan(plan, block_bytes=BLOCK, big_endian=be)
+    ctr = eng.counters()
+    rom = _download(eng, nbytes)
+    want = oracle_engine_parallel(oracle, oracle.plan(elem, keyword, wc), rom, BLOCK, be)
+    assert got.tolist() == want.tolist()
+    assert len(got) >= nbytes >> 20                      # at least the one plant per MiB
+    assert ctr["path"] != 1                              # the filter + resolver path, not the fallback
+    return got, rom, plan
+
+
+def test_c2_4gib_12char(mm, gpu_engine, oracle):
+    got, rom, plan = _full_config(mm, oracle, gpu_engine, 4 << 30, "relativesrch", 1)
+    # idempotence + base offset linearity: the same ROM scanned again with a base reports base + offsets
+    again = gpu_engine.scan(plan, block_bytes=BLOCK, base_offset=1 << 36)
+    assert (again - np.uint64(1 << 36)).tolist() == got.tolist()
+    # partition property (what the multi-GPU path relies on): scanning the two halves as
+    # block-aligned shards with overlap reproduces the whole
+    half = (4 << 30) // 2
+    parts = []
+    for first, n in ((0, half + 11), (half, half)):
+        gpu_engine.upload(rom[first:first + n])
+        parts.append(gpu_engine.scan(plan, block_bytes=BLOCK, base_offset=first))
+    assert np.concatenate(parts).tolist() == got.tolist()
+
+
+def test_c3_4gib_16char_3_wildcards(mm, gpu_engine, oracle):
+    _full_config(mm, oracle, gpu_engine, 4 << 30, "re*ative*ear*hxy", 1, wildcard=ord("*"))
+
+
+def test_c4_8gib_16bit_le(mm, gpu_engine, oracle):
+    got, rom, plan = _full_config(mm, oracle, gpu_engine, 8 << 30, "textsrch", 2)
+    # the 16-bit odd-boundary rule: no reported offset is k*B - 1
+    assert not np.any((got % np.uint64(BLOCK)) == np.uint64(BLOCK - 1))
+    assert np.any(got % np.uint64(2) == 1)               # odd alignments are found
