@@ -117,15 +117,18 @@ int mmh_rom_fill(mmh_ctx *ctx, uint64_t first_byte, uint64_t nbytes, int value, 
 int mmh_scan(mmh_ctx *ctx, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian,
              uint64_t base_offset, uint64_t *out, uint64_t cap, uint64_t *out_count);
 
-/* Engine selection for tests: 0 = auto (filter + certificate resolver, dense
- * fallback), 1 = force the sequential per-domain chain kernel. */
+/* Engine selection (tests / cross-checks): 0 = auto -- streaming filter + per-candidate
+ * resolvers, falling back to the forward "dense" engine for inputs they do not suit;
+ * 1 = force the sequential one-lane-per-domain chain kernel; 2 = force the dense engine.
+ * All three produce identical results. */
 int mmh_set_engine(mmh_ctx *ctx, int engine);
 
 /* Per-stage device timings of the last mmh_scan, in milliseconds (HIP events on
  * the scan's stream): [0] filter kernel, [1] resolve, [2] sort+copy, [3] total. */
 int mmh_last_timings(mmh_ctx *ctx, float *ms4);
 /* Counters of the last scan: [0] candidates, [1] matches, [2] resolver tiles walked,
- * [3] path taken (0 filter + resolver, 1 sequential engine, 2 filter + resolver + hard resolver). */
+ * [3] path taken (0 filter + resolver, 1 sequential engine, 2 filter + resolver + hard resolver,
+ * 3 dense engine). */
 int mmh_last_counters(mmh_ctx *ctx, uint64_t *c4);
 
 #ifdef __cplusplus

@@ -75,6 +75,8 @@ struct mmh_ctx {
    uint32_t *d_hard_slot = nullptr;
    uint8_t *d_scratch = nullptr;    // tile maps of hard candidates
    uint32_t *d_partials = nullptr;  // rank sort partial counts
+   uint8_t *d_dense = nullptr;      // dense engine: tile maps, super-tile maps, entry phases (one allocation)
+   size_t dense_bytes = 0;
    uint64_t *h_result = nullptr;    // pinned: [kHeaderWords counters][kMaxRankSort ordered matches], written by the device
 
    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -192,6 +194,7 @@ extern "C" void mmh_destroy(mmh_ctx *c)
    if (c->d_hard_slot) (void)hipFree(c->d_hard_slot);
    if (c->d_scratch) (void)hipFree(c->d_scratch);
    if (c->d_partials) (void)hipFree(c->d_partials);
+   if (c->d_dense) (void)hipFree(c->d_dense);
    if (c->h_result) (void)hipHostFree(c->h_result);
    for (auto &e : c->ev) {
       if (e) (void)hipEventDestroy(e);
@@ -212,7 +215,7 @@ extern "C" int mmh_set_stream(mmh_ctx *c, void *hip_stream)
 
 extern "C" int mmh_set_engine(mmh_ctx *c, int engine)
 {
-   if (!c || engine < 0 || engine > 1) {
+   if (!c || engine < 0 || engine > 2) {
       mmh_set_error("mmh_set_engine: bad argument");
       return MMH_E_ARG;
    }
@@ -383,6 +386,79 @@ int run_pipeline(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, const mm:
    return MMH_OK;
 }
 
+// The candidate-free forward engine (mm_dense.h).  Matches land in MM_CAND_LISTS device
+// lists; they are fetched and ordered on the host (dense results are long lists anyway).
+int run_dense(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, uint64_t base_offset, std::vector<uint64_t> *found,
+              bool *grew)
+{
+   hipStream_t st = c->stream;
+   *grew = false;
+   found->clear();
+   const mm::DenseGeom dg = mm::dense_geom(g);
+   if (dg.tpd == 0) {
+      std::memset(c->timings, 0, sizeof(c->timings));
+      return MMH_OK;                              // no alignment fits anywhere
+   }
+   auto round = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+   const size_t need = round(dg.maps_bytes) + round(dg.supmaps_bytes) + round(dg.supentry_bytes) + round(dg.entry_bytes);
+   if (need > c->dense_bytes) {
+      if (c->d_dense) {
+         HIP_TRY(hipFree(c->d_dense));
+         c->d_dense = nullptr;
+         c->dense_bytes = 0;
+      }
+      HIP_TRY(hipMalloc(&c->d_dense, need));
+      c->dense_bytes = need;
+   }
+   mm::DenseBuffers db;
+   db.maps = c->d_dense;
+   db.supmaps = db.maps + round(dg.maps_bytes);
+   db.supentry = db.supmaps + round(dg.supmaps_bytes);
+   db.entry = db.supentry + round(dg.supentry_bytes);
+   db.out = c->d_out; db.out_cap = c->out_cap; db.ctrl = c->d_ctrl;
+
+   HIP_TRY(hipMemsetAsync(c->d_ctrl, 0, mm::ctrl_bytes(), st));
+   HIP_TRY(hipEventRecord(c->ev[0], st));
+   mm::launch_dense(st, g, pl, dg, db, base_offset);
+   HIP_TRY(hipGetLastError());
+   HIP_TRY(hipEventRecord(c->ev[3], st));
+   std::vector<unsigned long long> ctrl(mm::ctrl_bytes() / sizeof(unsigned long long));
+   HIP_TRY(hipMemcpyAsync(ctrl.data(), c->d_ctrl, mm::ctrl_bytes(), hipMemcpyDeviceToHost, st));
+   HIP_TRY(hipStreamSynchronize(st));
+   c->timings[0] = 0;
+   c->timings[2] = 0;
+   (void)hipEventElapsedTime(&c->timings[1], c->ev[0], c->ev[3]);
+   c->timings[3] = c->timings[1];
+
+   const uint64_t list_cap = c->out_cap / MM_CAND_LISTS;
+   uint64_t most = 0, total = 0;
+   for (int l = 0; l < MM_CAND_LISTS; l++) {
+      const uint64_t n = ctrl[MM_CTRL_LISTS + l * MM_LIST_STRIDE];
+      most = std::max(most, n);
+      total += n;
+   }
+   if (most > list_cap) {
+      // some list overflowed: size every list for the fullest one and run again
+      int rc = ensure_workspace(c, (most + most / 8 + 1024) * MM_CAND_LISTS);
+      if (rc != MMH_OK) {
+         return rc;
+      }
+      *grew = true;
+      return MMH_OK;
+   }
+   found->resize(total);
+   uint64_t at = 0;
+   for (int l = 0; l < MM_CAND_LISTS; l++) {
+      const uint64_t n = ctrl[MM_CTRL_LISTS + l * MM_LIST_STRIDE];
+      if (n) {
+         HIP_TRY(hipMemcpy(found->data() + at, c->d_out + (uint64_t)l * list_cap, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+         at += n;
+      }
+   }
+   std::sort(found->begin(), found->end());       // search_engine.cpp:193-197
+   return MMH_OK;
+}
+
 } // namespace
 
 extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian,
@@ -428,20 +504,37 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
    }
 
    mm::FilterChoice fc;
-   bool have_filter = mm::choose_filter(*plan, &fc);
-   bool sequential = c->engine == 1 || !have_filter;
-   // dense candidate sets go to the sequential engine: it is linear in the ROM
-   // size, the per-candidate resolver is not
+   const bool have_filter = mm::choose_filter(*plan, &fc);
+   // engine 0: filter + per-candidate resolvers; inputs they do not suit (no SWAR key in the
+   // pattern, candidate sets too dense, prefixes too long) go to the forward "dense" engine,
+   // whose cost is linear in the ROM.  1 / 2 force the sequential / dense engine (tests).
+   enum { FAST, SEQUENTIAL, DENSE } mode = c->engine == 1 ? SEQUENTIAL : (c->engine == 2 || !have_filter) ? DENSE : FAST;
    const uint32_t max_candidates = g.whole ? 262144u : 16384u;
 
    Outcome oc;
-   for (int attempt = 0; attempt < 4; attempt++) {
-      rc = run_pipeline(c, g, *plan, fc, sequential, base_offset, max_candidates, &oc);
+   std::vector<uint64_t> long_list;
+   bool host_list = false;
+   for (int attempt = 0; attempt < 6; attempt++) {
+      if (mode == DENSE) {
+         bool grew = false;
+         rc = run_dense(c, g, *plan, base_offset, &long_list, &grew);
+         if (rc != MMH_OK) {
+            return rc;
+         }
+         if (grew) {
+            continue;
+         }
+         oc = Outcome();
+         oc.matches = long_list.size();
+         host_list = true;
+         break;
+      }
+      rc = run_pipeline(c, g, *plan, fc, mode == SEQUENTIAL, base_offset, max_candidates, &oc);
       if (rc != MMH_OK) {
          return rc;
       }
-      if (!sequential && (oc.candidates > c->out_cap || oc.candidates > max_candidates || oc.hard_overflow)) {
-         sequential = true;                       // too dense / too long for the per-candidate resolvers
+      if (mode == FAST && (oc.candidates > c->out_cap || oc.candidates > max_candidates || oc.hard_overflow)) {
+         mode = DENSE;                            // too dense / too long for the per-candidate resolvers
          continue;
       }
       if (oc.listed > c->out_cap) {
@@ -456,18 +549,18 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
 
    // lists too long for the device rank sort: fetch, drop the "not a match" slots and
    // order on the host, as search_engine.cpp:193-197 does
-   std::vector<uint64_t> long_list;
-   if (!oc.sorted_on_device) {
+   if (!host_list && !oc.sorted_on_device) {
       long_list.resize(oc.listed);
       HIP_TRY(hipMemcpy(long_list.data(), c->d_out, oc.listed * sizeof(uint64_t), hipMemcpyDeviceToHost));
       long_list.erase(std::remove(long_list.begin(), long_list.end(), ~0ull), long_list.end());
       std::sort(long_list.begin(), long_list.end());
       oc.matches = long_list.size();
+      host_list = true;
    }
    c->counters[0] = oc.candidates;
    c->counters[1] = oc.matches;
    c->counters[2] = oc.tiles;
-   c->counters[3] = sequential ? 1 : (oc.hard ? 2 : 0);
+   c->counters[3] = mode == SEQUENTIAL ? 1 : (mode == DENSE ? 3 : (oc.hard ? 2 : 0));
 
    *out_count = oc.matches;
    if (oc.matches > cap) {
@@ -478,11 +571,11 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
    if (oc.matches == 0) {
       return MMH_OK;
    }
-   if (oc.sorted_on_device) {
-      std::memcpy(out, c->h_result + kHeaderWords, oc.matches * sizeof(uint64_t));
+   if (host_list) {
+      std::memcpy(out, long_list.data(), oc.matches * sizeof(uint64_t));
    }
    else {
-      std::memcpy(out, long_list.data(), oc.matches * sizeof(uint64_t));
+      std::memcpy(out, c->h_result + kHeaderWords, oc.matches * sizeof(uint64_t));
    }
    return MMH_OK;
 }

@@ -42,6 +42,22 @@ size_t hard_scratch_bytes();
 size_t hard_cap();
 size_t ctrl_bytes();
 size_t rank_partials_bytes(uint32_t max_n);
+// the candidate-free forward engine (mm_dense.h): sizes and buffers
+struct DenseGeom {
+   uint64_t ndom;
+   uint32_t tpd;
+   uint32_t nsup;
+   size_t maps_bytes, supmaps_bytes, supentry_bytes, entry_bytes;
+};
+struct DenseBuffers {
+   uint8_t *maps, *supmaps, *supentry, *entry;
+   uint64_t *out;            // MM_CAND_LISTS lists of out_cap / MM_CAND_LISTS values
+   uint64_t out_cap;
+   unsigned long long *ctrl; // list counters at MM_CTRL_LISTS
+};
+DenseGeom dense_geom(const MmGeom &g);
+void launch_dense(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const DenseGeom &dg, const DenseBuffers &db,
+                  uint64_t base_offset);
 void launch_chain_seq(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, uint64_t *out,
                       unsigned long long *out_count, uint64_t out_cap, uint64_t base_offset);
 // orders the ctrl[count_index] keys of `in` into host_result[8..] (pinned host memory) and

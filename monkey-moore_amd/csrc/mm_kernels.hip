@@ -23,6 +23,8 @@
 // No MFMA anywhere: the path is integer byte comparison (BASELINE.json).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "mm_internal.h"
 #include "mm_kernels.h"
 
@@ -543,6 +545,7 @@ __global__ __launch_bounds__(256) void mm_filter_u16(MmFilterArgs a)
 }
 
 #include "mm_tiles.h"
+#include "mm_dense.h"
 
 // --------------------------------------------------------------------------
 // sequential engine: one lane per domain, exact by construction
@@ -857,6 +860,43 @@ size_t hard_scratch_bytes() { return (size_t)MM_HARD_CAP * MM_HARD_MAX_TILES * M
 size_t hard_cap() { return MM_HARD_CAP; }
 size_t ctrl_bytes() { return MM_CTRL_DONE * sizeof(uint64_t) + MM_HARD_CAP * sizeof(unsigned int); }
 size_t rank_partials_bytes(uint32_t max_n) { return (size_t)MM_RANK_SLICES * max_n * sizeof(uint32_t); }
+
+DenseGeom dense_geom(const MmGeom &g)
+{
+   DenseGeom d;
+   d.ndom = g.whole ? 1 : g.nblocks * g.S;
+   int64_t most = 0;
+   for (uint32_t p = 0; p < (g.whole ? 1u : g.S); p++) {
+      int64_t nv = mm_domain_nv(g, 0, p);                 // block 0 is the largest kind of block
+      most = nv > most ? nv : most;
+   }
+   d.tpd = (uint32_t)((most + MM_TILE - 1) / MM_TILE);
+   d.nsup = (d.tpd + MM_SUPER - 1) / MM_SUPER;
+   d.maps_bytes = (size_t)d.ndom * d.tpd * MM_MAXD;
+   d.supmaps_bytes = (size_t)d.ndom * d.nsup * MM_MAXD;
+   d.supentry_bytes = (size_t)d.ndom * d.nsup;
+   d.entry_bytes = (size_t)d.ndom * d.tpd;
+   return d;
+}
+
+void launch_dense(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const DenseGeom &dg, const DenseBuffers &db,
+                  uint64_t base_offset)
+{
+   MmDenseArgs a;
+   a.t = tile_args(g, pl);
+   a.ndom = dg.ndom; a.tpd = dg.tpd; a.nsup = dg.nsup;
+   a.maps = db.maps; a.supmaps = db.supmaps; a.supentry = db.supentry; a.entry = db.entry;
+   a.out = db.out; a.list_count = db.ctrl + MM_CTRL_LISTS; a.list_cap = db.out_cap / MM_CAND_LISTS;
+   a.base_offset = base_offset;
+   const uint64_t ntiles = dg.ndom * dg.tpd;
+   const unsigned tile_blocks = (unsigned)std::min<uint64_t>((ntiles + MM_WAVES - 1) / MM_WAVES, 4096);
+   const unsigned sup_blocks = (unsigned)std::min<uint64_t>(dg.ndom * dg.nsup, 16384);
+   hipLaunchKernelGGL(mm_dense_maps, dim3(tile_blocks), dim3(64 * MM_WAVES), 0, st, a);
+   hipLaunchKernelGGL(mm_dense_super<0>, dim3(sup_blocks), dim3(64), 0, st, a);
+   hipLaunchKernelGGL(mm_dense_entries, dim3((unsigned)std::min<uint64_t>(dg.ndom, 16384)), dim3(64), 0, st, a);
+   hipLaunchKernelGGL(mm_dense_super<1>, dim3(sup_blocks), dim3(64), 0, st, a);
+   hipLaunchKernelGGL(mm_dense_emit, dim3(tile_blocks), dim3(64 * MM_WAVES), 0, st, a);
+}
 
 void launch_chain_seq(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, uint64_t *out,
                       unsigned long long *out_count, uint64_t out_cap, uint64_t base_offset)

@@ -173,7 +173,10 @@ __device__ __forceinline__ int mm_stage_tile(const MmTileArgs &a, MmWaveLds &W, 
    const uint64_t src0 = start + (uint64_t)lo * S;
    // one element more than the tile's own compares need: the caller may evaluate the
    // compare loop AT position npos (the candidate) as well
-   const int nstage = (npos + (int)a.plan.L) * S;
+   int nstage = (npos + (int)a.plan.L) * S;
+   if (src0 + (uint64_t)nstage > a.g.nbytes) {
+      nstage = (int)(a.g.nbytes - src0);       // never read past the dword that holds the ROM's last byte
+   }
    const int mis = (int)(((uintptr_t)(a.g.rom + src0)) & 3);
    const uint32_t *s4 = reinterpret_cast<const uint32_t *>(a.g.rom + src0 - mis);
    const int nw = (nstage + mis + 3) >> 2;

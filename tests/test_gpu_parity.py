@@ -16,13 +16,16 @@ def _mm_plan(mm, c):
 
 
 def _scan_both(eng, plan, **kw):
-    """auto engine (filter + resolver) and the sequential engine must agree."""
+    """auto engine (filter + resolvers), the sequential engine and the dense engine must agree."""
     eng.set_engine(0)
     fast = eng.scan(plan, **kw)
     eng.set_engine(1)
     seq = eng.scan(plan, **kw)
+    eng.set_engine(2)
+    dense = eng.scan(plan, **kw)
     eng.set_engine(0)
     assert fast.tolist() == seq.tolist()
+    assert dense.tolist() == seq.tolist()
     return fast
 
 
@@ -89,7 +92,15 @@ def _spec_case(mm, oracle, eng, nbytes, keyword, elem, wildcard=None, be=False, 
         want = oracle.engine(oplan, rom, block, be)
         got = eng.scan(plan, block_bytes=block, big_endian=be)
     assert got.tolist() == want.tolist()
-    return got, eng.counters()
+    ctr = eng.counters()
+    eng.set_engine(2)                                         # the dense engine on the same ROM
+    if whole:
+        dense = eng.scan(plan)
+    else:
+        dense = eng.scan(plan, block_bytes=block, big_endian=be)
+    eng.set_engine(0)
+    assert dense.tolist() == want.tolist()
+    return got, ctr
 
 
 def test_c2_shape_16mib(mm, gpu_engine, oracle):
@@ -146,6 +157,7 @@ def test_dense_matches_constant_data(mm, gpu_engine, oracle):
     got = gpu_engine.scan(plan, block_bytes=4096)
     assert got.tolist() == oracle.engine(oplan, data, 4096).tolist()
     assert len(got) > n // 3
+    assert gpu_engine.counters()["path"] == 3              # too dense for per-candidate work: dense engine
     small = data[:20000]
     gpu_engine.upload(small)
     assert gpu_engine.scan(plan).tolist() == oracle.search(oplan, small).tolist()

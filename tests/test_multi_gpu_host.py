@@ -12,7 +12,7 @@ import pytest
 from conftest import ROOT, load_package
 
 
-def _worker(rank, world, port, total, block, kw, elem, be, q):
+def _worker(rank, world, port, total, block, kw, elem, be, q, width=None):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     sys.path.insert(0, ROOT)
     import torch
@@ -20,6 +20,8 @@ def _worker(rank, world, port, total, block, kw, elem, be, q):
     from _oracle import Oracle
     from conftest import load_package as lp
     mm = lp()
+    if width:
+        mm.partition.GATHER_WIDTH = width            # force the long-list (two collective) path
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -40,8 +42,9 @@ def _worker(rank, world, port, total, block, kw, elem, be, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("elem,kw,be", [(1, "relativesrch", False), (2, "textsrch", True)])
-def test_partition_and_gather_world2(elem, kw, be):
+@pytest.mark.parametrize("elem,kw,be,width", [(1, "relativesrch", False, None), (2, "textsrch", True, None),
+                                               (1, "relativesrch", False, 4)])
+def test_partition_and_gather_world2(elem, kw, be, width):
     import torch.multiprocessing as mp
     load_package()
     with socket.socket() as s:
@@ -50,7 +53,7 @@ def test_partition_and_gather_world2(elem, kw, be):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     total, block = (6 << 20) + 4099, 65536
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, block, kw, elem, be, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, block, kw, elem, be, q, width)) for r in range(2)]
     for p in procs:
         p.start()
     got, want = q.get(timeout=300)
