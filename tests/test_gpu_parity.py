@@ -183,3 +183,86 @@ def test_base_offset_and_capacity(mm, gpu_engine, oracle):
     want = oracle.engine(oplan, rom, 524288)
     got = gpu_engine.scan(plan, block_bytes=524288, base_offset=1 << 40, cap=1)   # forces the CAPACITY retry
     assert (got - np.uint64(1 << 40)).tolist() == want.tolist()
+
+
+def _random_rom_with_plants(rng, n, elem, kw_vals, be, nplants=40):
+    hi = 256 if elem == 1 else 65536
+    d = rng.integers(0, hi, n // elem).astype(np.int64)
+    L = len(kw_vals)
+    lits = [v for v in kw_vals if v is not None]
+    for _ in range(nplants):
+        pos = int(rng.integers(0, d.size - L))
+        sh = int(rng.integers(-min(lits), hi - max(lits)))
+        for j, v in enumerate(kw_vals):
+            if v is not None:
+                d[pos + j] = v + sh
+    arr = d.astype(np.uint8 if elem == 1 else (">u2" if be else "<u2"))
+    return arr.view(np.uint8)
+
+
+@pytest.mark.parametrize("L", [2, 3, 17, 24, 32])
+def test_keyword_lengths(mm, gpu_engine, oracle, L):
+    # L-1 > 16 takes the byte-packed phase maps, L = 2 the degenerate single phase
+    rng = np.random.default_rng(100 + L)
+    kw = [int(c) for c in rng.integers(97, 123, L)]
+    rom = _random_rom_with_plants(rng, 4 << 20, 1, kw, False)
+    gpu_engine.upload(rom)
+    plan, oplan = mm.plan_relative(1, kw), oracle.plan(1, kw)
+    want = oracle.engine(oplan, rom, 524288)
+    assert _scan_both(gpu_engine, plan, block_bytes=524288).tolist() == want.tolist()
+    assert len(want) >= 20 or L == 2
+    assert gpu_engine.scan(plan).tolist() == oracle.search(oplan, rom).tolist()
+    with pytest.raises(mm.MMError):
+        mm.plan_relative(1, [97 + (i % 5) for i in range(33)])   # longer than MMH_MAX_KEYWORD: refused, loudly
+
+
+def test_pattern_without_swar_key_uses_dense_engine(mm, gpu_engine, oracle):
+    # no two adjacent literals -> nothing for the streaming filter to key on
+    rng = np.random.default_rng(7)
+    kw = "a*c*e*g"
+    vals = [None if ch == "*" else ord(ch) for ch in kw]
+    rom = _random_rom_with_plants(rng, 2 << 20, 1, vals, False)
+    gpu_engine.upload(rom)
+    plan, oplan = mm.plan_relative(1, kw, ord("*")), oracle.plan(1, kw, ord("*"))
+    got = gpu_engine.scan(plan, block_bytes=65536)
+    assert gpu_engine.counters()["path"] == 3
+    assert got.tolist() == oracle.engine(oplan, rom, 65536).tolist()
+    assert len(got) >= 10
+
+
+def test_hard_candidates(mm, gpu_engine, oracle):
+    # 'abcde' never leaves its residue class (every jump is 4): no look-back window
+    # can certify a candidate, so they all go through mm_hard_resolve ...
+    rng = np.random.default_rng(9)
+    kw = [ord(c) for c in "abcde"]
+    rom = _random_rom_with_plants(rng, 8 << 20, 1, kw, False, nplants=24)
+    gpu_engine.upload(rom)
+    plan, oplan = mm.plan_relative(1, "abcde"), oracle.plan(1, "abcde")
+    got = gpu_engine.scan(plan, block_bytes=4 << 20)
+    assert gpu_engine.counters()["path"] == 2
+    assert got.tolist() == oracle.engine(oplan, rom, 4 << 20).tolist()
+    # ... and when a prefix is longer than it maps (whole-buffer chain over 32 MiB), through the dense engine
+    rom = _random_rom_with_plants(rng, 32 << 20, 1, kw, False, nplants=24)
+    gpu_engine.upload(rom)
+    got = gpu_engine.scan(plan)
+    assert gpu_engine.counters()["path"] == 3
+    assert got.tolist() == oracle.search(oplan, rom).tolist()
+    assert len(got) >= 4
+
+
+def test_value_scan_and_custom_sequence_at_scale(mm, gpu_engine, oracle):
+    rng = np.random.default_rng(21)
+    values = [60, 61, 62, 63, 64, 71, 40]
+    rom = _random_rom_with_plants(rng, 4 << 20, 2, values, True)
+    gpu_engine.upload(rom)
+    plan, oplan = mm.plan_value_scan(2, values), oracle.plan_values(2, values)
+    assert _scan_both(gpu_engine, plan, block_bytes=524288, big_endian=True).tolist() == oracle.engine(oplan, rom, 524288, True).tolist()
+    seq = "aiueobcdfghjklmnpqrstvwxyz"
+    kw = "matchbox"
+    vals = [seq.index(c) for c in kw]
+    rom = _random_rom_with_plants(rng, 4 << 20, 1, vals, False)
+    gpu_engine.upload(rom)
+    plan, oplan = mm.plan_relative(1, kw, 0, seq), oracle.plan(1, kw, 0, seq)
+    want = oracle.engine(oplan, rom, 524288)
+    assert _scan_both(gpu_engine, plan, block_bytes=524288).tolist() == want.tolist()
+    assert len(want) >= 20
