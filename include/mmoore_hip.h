@@ -123,8 +123,9 @@ int mmh_scan(mmh_ctx *ctx, const mmh_plan_desc *plan, uint64_t block_bytes, int 
  * All three produce identical results. */
 int mmh_set_engine(mmh_ctx *ctx, int engine);
 
-/* Per-stage device timings of the last mmh_scan, in milliseconds (HIP events on
- * the scan's stream): [0] filter kernel, [1] resolve, [2] sort+copy, [3] total. */
+/* Device timings of the last mmh_scan, in milliseconds (HIP events on the scan's
+ * stream): [0] streaming filter kernel(s), [1] everything behind it (resolvers, ordering,
+ * publication of the results), [2] unused (0), [3] total. */
 int mmh_last_timings(mmh_ctx *ctx, float *ms4);
 /* Counters of the last scan: [0] candidates, [1] matches, [2] resolver tiles walked,
  * [3] path taken (0 filter + resolver, 1 sequential engine, 2 filter + resolver + hard resolver,

@@ -181,10 +181,12 @@ class Engine:
     def scan(self, plan, block_bytes=0, big_endian=False, base_offset=0, cap=1 << 16):
         """Returns ascending np.uint64 offsets (element indices when block_bytes == 0)."""
         while True:
-            out = np.empty(cap, np.uint64)
+            out = getattr(self, "_out", None)
+            if out is None or out.size < cap:
+                out = self._out = np.empty(cap, np.uint64)       # reused across scans
             n = C.c_uint64(0)
             rc = lib().mmh_scan(self._h, C.byref(plan), block_bytes, int(big_endian), base_offset,
-                                out.ctypes.data_as(C.POINTER(C.c_uint64)), cap, C.byref(n))
+                                out.ctypes.data_as(C.POINTER(C.c_uint64)), out.size, C.byref(n))
             if rc == MMH_E_CAPACITY:
                 cap = int(n.value) + 16
                 continue
@@ -194,7 +196,7 @@ class Engine:
     def timings(self):
         t = (C.c_float * 4)()
         _check(lib().mmh_last_timings(self._h, t))
-        return dict(filter_ms=t[0], resolve_ms=t[1], sort_copy_ms=t[2], total_ms=t[3])
+        return dict(filter_ms=t[0], post_filter_ms=t[1], total_ms=t[3])
 
     def counters(self):
         c = (C.c_uint64 * 4)()

@@ -60,9 +60,9 @@ void launch_dense(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, cons
                   uint64_t base_offset);
 void launch_chain_seq(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, uint64_t *out,
                       unsigned long long *out_count, uint64_t out_cap, uint64_t base_offset);
-// orders the ctrl[count_index] keys of `in` into host_result[8..] (pinned host memory) and
-// publishes the counters in host_result[0..8); see mm_rank_scatter
-void launch_rank_sort(hipStream_t st, const uint64_t *in, const unsigned long long *ctrl, int count_index, uint64_t cap,
+// orders the ctrl[count_index] keys of `in` into host_result[8..] (pinned host memory),
+// publishes the counters in host_result[0..8) and leaves ctrl zeroed; see mm_rank_scatter
+void launch_rank_sort(hipStream_t st, const uint64_t *in, unsigned long long *ctrl, int count_index, uint64_t cap,
                       uint32_t max_n, uint32_t *partials, uint64_t *host_result);
 void launch_synth(hipStream_t st, uint8_t *rom, uint64_t nbytes, uint64_t seed, uint64_t base_offset);
 void launch_pattern_fill(hipStream_t st, uint8_t *rom, uint64_t first, uint64_t nbytes, int value, int ramp);

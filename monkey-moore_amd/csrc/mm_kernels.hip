@@ -646,10 +646,11 @@ __global__ __launch_bounds__(256) void mm_rank_count(const uint64_t *in, const u
 // chain) sort behind everything else, so their common rank IS the number of matches:
 // it is published as host_result[6] = rank + 1 (the host zeroes that word before the
 // scan; 0 afterwards means "every key is a match").
-__global__ __launch_bounds__(256) void mm_rank_scatter(const uint64_t *in, const unsigned long long *ctrl, int count_index,
+__global__ __launch_bounds__(256) void mm_rank_scatter(const uint64_t *in, unsigned long long *ctrl, int count_index,
                                                        uint64_t cap, uint32_t max_n, const uint32_t *partials,
-                                                       uint64_t *host_result)
+                                                       uint64_t *host_result, uint32_t ctrl_words)
 {
+   __shared__ int last_block;
    const unsigned long long n64 = ctrl[count_index];
    if (blockIdx.x == 0 && threadIdx.x < 8 && threadIdx.x != 6) {
       unsigned long long v = ctrl[threadIdx.x];            // counters travel with the results
@@ -661,22 +662,35 @@ __global__ __launch_bounds__(256) void mm_rank_scatter(const uint64_t *in, const
       }
       host_result[threadIdx.x] = v;
    }
-   if (n64 > cap || n64 > max_n) {
-      return;
-   }
-   const uint32_t n = (uint32_t)n64;
-   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-      uint32_t r = 0;
+   if (n64 <= cap && n64 <= max_n) {
+      const uint32_t n = (uint32_t)n64;
+      for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+         uint32_t r = 0;
 #pragma unroll
-      for (int s = 0; s < MM_RANK_SLICES; s++) {
-         r += partials[s * max_n + i];
+         for (int s = 0; s < MM_RANK_SLICES; s++) {
+            r += partials[s * max_n + i];
+         }
+         const uint64_t key = in[i];
+         if (key == MM_NO_MATCH) {
+            host_result[6] = (uint64_t)r + 1;
+         }
+         else {
+            host_result[8 + r] = key;
+         }
       }
-      const uint64_t key = in[i];
-      if (key == MM_NO_MATCH) {
-         host_result[6] = (uint64_t)r + 1;
-      }
-      else {
-         host_result[8 + r] = key;
+   }
+   // The last block to get here leaves the control block zeroed for the next scan (this is
+   // the last kernel of a scan), which saves a memset launch + its stream gap per scan.
+   // (No fence needed: every block has consumed the ctrl words it reads before it takes
+   // its ticket, and nothing else is ordered against the zeroing.)
+   __syncthreads();
+   if (threadIdx.x == 0) {
+      last_block = atomicAdd(ctrl + MM_CTRL_TICKET, 1ull) == gridDim.x - 1;
+   }
+   __syncthreads();
+   if (last_block) {
+      for (uint32_t k = threadIdx.x; k < ctrl_words; k += blockDim.x) {
+         ctrl[k] = 0;
       }
    }
 }
@@ -911,13 +925,13 @@ void launch_chain_seq(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, 
    hipLaunchKernelGGL(mm_chain_seq, dim3((unsigned)blocks), dim3(64), 0, st, a);
 }
 
-void launch_rank_sort(hipStream_t st, const uint64_t *in, const unsigned long long *ctrl, int count_index, uint64_t cap,
+void launch_rank_sort(hipStream_t st, const uint64_t *in, unsigned long long *ctrl, int count_index, uint64_t cap,
                       uint32_t max_n, uint32_t *partials, uint64_t *host_result)
 {
    hipLaunchKernelGGL(mm_rank_count, dim3(16, MM_RANK_SLICES), dim3(256), 0, st, in, ctrl + count_index, cap, max_n,
                       partials);
    hipLaunchKernelGGL(mm_rank_scatter, dim3(64), dim3(256), 0, st, in, ctrl, count_index, cap, max_n, partials,
-                      host_result);
+                      host_result, (uint32_t)(ctrl_bytes() / sizeof(unsigned long long)));
 }
 
 void launch_synth(hipStream_t st, uint8_t *rom, uint64_t nbytes, uint64_t seed, uint64_t base_offset)

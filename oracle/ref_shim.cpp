@@ -14,6 +14,8 @@
 
 #include <atomic>
 #include <cstring>
+#include <limits>
+#include <random>
 #include <string>
 #include <thread>
 #include <vector>
@@ -209,5 +211,28 @@ void mmref_progress_info(int *calls, int *last, int *monotone)
 }
 
 int mmref_hardware_concurrency() { return (int)std::thread::hardware_concurrency(); }
+
+// The input of the reference's own benchmark (benchmarks/bench_search.cpp:11-22 describes it:
+// std::mt19937 seeded with 42, one uniform_int_distribution<unsigned>(0, max(DataType)) draw
+// per element).  Re-stated here so that tests can run MonkeyMoore<T>::search of the compiled
+// reference and the GPU engine on exactly that buffer.
+void mmref_bench_data(int elem_bytes, uint64_t nbytes, void *out)
+{
+   std::mt19937 rng(42);
+   if (elem_bytes == 1) {
+      std::uniform_int_distribution<unsigned int> dist(0, std::numeric_limits<uint8_t>::max());
+      uint8_t *p = static_cast<uint8_t *>(out);
+      for (uint64_t i = 0; i < nbytes; i++) {
+         p[i] = static_cast<uint8_t>(dist(rng));
+      }
+   }
+   else {
+      std::uniform_int_distribution<unsigned int> dist(0, std::numeric_limits<uint16_t>::max());
+      uint16_t *p = static_cast<uint16_t *>(out);
+      for (uint64_t i = 0; i < nbytes / 2; i++) {
+         p[i] = static_cast<uint16_t>(dist(rng));
+      }
+   }
+}
 
 } // extern "C"

@@ -156,6 +156,13 @@ class Ref:
     def _err(self):
         return RuntimeError(self.lib.mmref_last_error().decode())
 
+    def bench_data(self, elem_bytes, nbytes):
+        """The reference benchmark's input buffer (bench_search.cpp:11-22), as raw bytes."""
+        self.lib.mmref_bench_data.argtypes = [C.c_int, C.c_uint64, C.c_void_p]
+        buf = np.empty(nbytes, np.uint8)
+        self.lib.mmref_bench_data(elem_bytes, nbytes, buf.ctypes.data)
+        return buf
+
     def search(self, elem_bytes, keyword, data, wildcard=0, char_seq=None):
         kw = codepoints(keyword)
         seq = codepoints(char_seq) if char_seq is not None else np.zeros(0, np.uint32)

@@ -266,3 +266,25 @@ def test_value_scan_and_custom_sequence_at_scale(mm, gpu_engine, oracle):
     want = oracle.engine(oplan, rom, 524288)
     assert _scan_both(gpu_engine, plan, block_bytes=524288).tolist() == want.tolist()
     assert len(want) >= 20
+
+
+@pytest.mark.parametrize("elem", [1, 2])
+def test_c1_reference_benchmark_input_vs_compiled_reference(mm, gpu_engine, elem):
+    """BASELINE config C1: the reference's own benchmark (bench_search.cpp) -- mt19937(42)
+    data, keyword abcde and its three wildcard variants -- GPU whole-buffer scan against
+    MonkeyMoore<T>::search of the COMPILED REFERENCE (oracle/_ref, prebuilt) on the same bytes."""
+    from _oracle import Ref
+    if not Ref.available():
+        pytest.skip("oracle/_ref/libmmref.so was not shipped")
+    ref = Ref()
+    n = 16 << 20
+    raw = ref.bench_data(elem, n)
+    data = raw.view(np.uint8 if elem == 1 else "<u2")
+    gpu_engine.upload(raw)
+    total = 0
+    for kw, wc in (("abcde", 0), ("*bcde", ord("*")), ("ab*de", ord("*")), ("abcd*", ord("*")), ("monkey", 0)):
+        want = ref.search(elem, kw, data, wc)
+        got = gpu_engine.scan(mm.plan_relative(elem, kw, wc))
+        assert got.tolist() == want.tolist(), kw
+        total += len(want)
+    assert total == (2 if elem == 1 else 0)   # what the reference finds in its own benchmark buffer

@@ -8,6 +8,16 @@
 extern "C" void mmh_set_error(const char *, ...) {}
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <int MODE>
+__device__ __forceinline__ uint4 ld(const uint4 *p)
+{
+   if (MODE == 3) {
+      u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+      return make_uint4(v.x, v.y, v.z, v.w);
+   }
+   return *p;
+}
 // variant: MODE 0 = full compute, 1 = loads + trivial xor (no SWAR), 2 = SWAR but no dpp/readlane carry
 template <int MODE, int DEPTH>
 __global__ __launch_bounds__(256) void filt_var(MmFilterArgs a, uint32_t *sink)
@@ -26,7 +36,7 @@ __global__ __launch_bounds__(256) void filt_var(MmFilterArgs a, uint32_t *sink)
       for (int d = 0; d < DEPTH; d++) {
          const uint64_t gg = g0 + d < g1 ? g0 + d : g1 - 1;
          const uint4 *p = rom4 + gg * 256 + lane;
-         w[d][0] = p[0]; w[d][1] = p[64]; w[d][2] = p[128]; w[d][3] = p[192];
+         w[d][0] = ld<MODE>(p); w[d][1] = ld<MODE>(p + 64); w[d][2] = ld<MODE>(p + 128); w[d][3] = ld<MODE>(p + 192);
       }
       for (uint64_t g = g0; g < g1; g += DEPTH + 1) {
 #pragma unroll
@@ -35,7 +45,7 @@ __global__ __launch_bounds__(256) void filt_var(MmFilterArgs a, uint32_t *sink)
             const int slot_new = (s + DEPTH) % (DEPTH + 1);
             const uint64_t gn = g + s + DEPTH < g1 ? g + s + DEPTH : g1 - 1;
             const uint4 *pn = rom4 + gn * 256 + lane;
-            w[slot_new][0] = pn[0]; w[slot_new][1] = pn[64]; w[slot_new][2] = pn[128]; w[slot_new][3] = pn[192];
+            w[slot_new][0] = ld<MODE>(pn); w[slot_new][1] = ld<MODE>(pn + 64); w[slot_new][2] = ld<MODE>(pn + 128); w[slot_new][3] = ld<MODE>(pn + 192);
             if (g + s < g1) {
                if (MODE == 1) {
 #pragma unroll
@@ -44,10 +54,11 @@ __global__ __launch_bounds__(256) void filt_var(MmFilterArgs a, uint32_t *sink)
                else {
                   uint32_t h[4][4];
                   uint32_t any = 0;
+                  constexpr int CM = MODE == 3 ? 0 : MODE;
 #pragma unroll
                   for (int u = 0; u < 4; u++) {
-                     uint32_t c = MODE == 2 ? 0u : (u == 0 ? carry : __builtin_amdgcn_readlane(w[s][u - 1].w, 63));
-                     if (MODE == 2) {
+                     uint32_t c = CM == 2 ? 0u : (u == 0 ? carry : __builtin_amdgcn_readlane(w[s][u - 1].w, 63));
+                     if (CM == 2) {
                         uint32_t back = w[s][u].w << 8;
                         uint32_t dbprev = mm_bytesub(back, back << 8);
                         h[u][0] = mm_f8_hits<2>(w[s][u].x, back, dbprev, a.pat);
@@ -92,14 +103,14 @@ int main(int argc, char **argv)
    uint8_t *rom; CK(hipMalloc(&rom, n + 64));
    mm::launch_synth(0, rom, n, 42, 0);
    uint32_t *sink; CK(hipMalloc(&sink, 64));
-   uint64_t *cand; unsigned long long *cnt; CK(hipMalloc(&cand, 8 << 20)); CK(hipMalloc(&cnt, 64));
+   uint64_t *cand; unsigned long long *cnt; CK(hipMalloc(&cand, 8 << 20)); CK(hipMalloc(&cnt, 65536));
    mmh_plan_desc pl; uint32_t kw[12]; const char *k = "relativesrch";
    for (int i = 0; i < 12; i++) kw[i] = k[i];
    mmh_plan_relative(1, kw, 12, 0, nullptr, 0, &pl);
    MmGeom g; g.rom = rom; g.nbytes = n; g.block_bytes = 524288; g.nblocks = n / 524288; g.S = 1; g.L = 12; g.big_endian = 0; g.whole = 0;
    mm::FilterChoice fc; mm::choose_filter(pl, &fc);
    MmFilterArgs a; a.g = g; a.plan = pl; for (int q = 0; q < 4; q++) a.pat[q] = fc.pat[q]; a.iA = fc.iA; a.ncond = fc.ncond;
-   a.cand = cand; a.cand_count = cnt; a.cand_cap = 1 << 20; a.ngroups = n / 4096; a.edge_first = a.ngroups * 256;
+   a.cand = cand; a.list_count = cnt; a.list_cap = (1 << 20) / MM_CAND_LISTS; a.verify = 0; a.ngroups = n / 4096; a.edge_first = a.ngroups * 256;
    CK(hipDeviceSynchronize());
    char nm[128];
    for (int gps : {4, 16, 64}) for (int grid : {1024, 2048, 4096}) {
@@ -165,6 +176,15 @@ int main(int argc, char **argv)
       timeit(nm, n, [&] { hipLaunchKernelGGL((filt_var<1, 2>), dim3(grid), dim3(256), 0, 0, a, sink); });
       snprintf(nm, sizeof nm, "variant swar-no-carry depth1 grid %d", grid);
       timeit(nm, n, [&] { hipLaunchKernelGGL((filt_var<2, 1>), dim3(grid), dim3(256), 0, 0, a, sink); });
+   }
+   a.groups_per_span = 16;
+   for (int grid : {2048}) {
+      snprintf(nm, sizeof nm, "variant full nt-loads depth2 grid %d", grid);
+      timeit(nm, n, [&] { hipLaunchKernelGGL((filt_var<3, 2>), dim3(grid), dim3(256), 0, 0, a, sink); });
+      snprintf(nm, sizeof nm, "variant full nt-loads depth3 grid %d", grid);
+      timeit(nm, n, [&] { hipLaunchKernelGGL((filt_var<3, 3>), dim3(grid), dim3(256), 0, 0, a, sink); });
+      snprintf(nm, sizeof nm, "variant full depth3 grid %d", grid);
+      timeit(nm, n, [&] { hipLaunchKernelGGL((filt_var<0, 3>), dim3(grid), dim3(256), 0, 0, a, sink); });
    }
    a.groups_per_span = 48;
    for (int grid : {2048}) {
