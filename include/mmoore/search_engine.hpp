@@ -30,30 +30,46 @@
 
 namespace mmoore {
 
+// One match.  Member order and types are those of the reference so that aggregate
+// initialisation ({offset, map, preview}) in existing tests keeps working.
 template <typename DataType>
 struct SearchResult {
-   uint64_t offset;                                                 // byte offset in the file
+   // where the match starts, as a BYTE offset from the beginning of the file (also for
+   // 16-bit searches; odd offsets occur)
+   uint64_t offset;
+   // symbol -> element value for this particular match ('A'/'a' bases for ASCII keywords,
+   // every symbol for custom sequences, empty for value scans)
    typename MonkeyMoore<DataType>::equivalency_map values_map;
-   std::string preview;                                             // filled when previews are requested
+   // the bytes around the match decoded through values_map; empty unless requested
+   std::string preview;
 };
 
+// What to search for and how.  Same fields and defaults as the reference.
 struct SearchConfig {
    std::filesystem::path file_path;
 
-   bool is_relative_search = true;                 // false: value scan of reference_values
+   // true: relative search for `keyword`; false: value scan of `reference_values`
+   bool is_relative_search = true;
+   // byte order of 16-bit elements in the file (ignored for 8-bit searches)
    mmoore::Endianness endianness = Endianness::Little;
 
-   std::vector<CharType> keyword;
-   std::vector<CharType> custom_char_seq = {};
-   CharType wildcard = '*';
+   std::vector<CharType> keyword;                  // UTF-32 code points
+   std::vector<CharType> custom_char_seq = {};     // optional alphabet: symbols are valued by their index in it
+   CharType wildcard = '*';                        // matches any element
 
    std::vector<short> reference_values = {};
 
+   // accepted for compatibility, not used: the GPU engine has no worker threads and the
+   // value never influenced results
    int preferred_num_threads = std::thread::hardware_concurrency();
+   // the reference's block size in bytes; it DOES influence results (the skip chain
+   // restarts at every block), so it is honoured exactly
    int preferred_search_block_size = 524288;
+   // elements of context shown in a preview
    int preferred_preview_width = 50;
 };
 
+// phase reported to the progress callback
 enum SearchStep { Initializing, Searching, GeneratingPreviews, Aborting };
 
 template <typename DataType>
