@@ -127,6 +127,9 @@ int mmh_set_engine(mmh_ctx *ctx, int engine);
  * stream): [0] streaming filter kernel(s), [1] everything behind it (resolvers, ordering,
  * publication of the results), [2] unused (0), [3] total. */
 int mmh_last_timings(mmh_ctx *ctx, float *ms4);
+/* The same for the most recent scans (up to 64 are kept), oldest first: streaming-kernel
+ * and total device time of each.  Elapsed times are computed here, not during the scans. */
+int mmh_timing_history(mmh_ctx *ctx, float *filter_ms, float *total_ms, int cap, int *count);
 /* Counters of the last scan: [0] candidates, [1] matches, [2] resolver tiles walked,
  * [3] path taken (0 filter + resolver, 1 sequential engine, 2 filter + resolver + hard resolver,
  * 3 dense engine). */

@@ -26,6 +26,7 @@ EXPORTS = [
     "mmh_last_error", "mmh_plan_relative", "mmh_plan_value_scan", "mmh_device_count", "mmh_create", "mmh_destroy",
     "mmh_set_stream", "mmh_rom_upload", "mmh_rom_attach", "mmh_rom_download", "mmh_rom_alloc", "mmh_rom_synth",
     "mmh_rom_poke", "mmh_rom_fill", "mmh_scan", "mmh_set_engine", "mmh_last_timings", "mmh_last_counters",
+    "mmh_timing_history",
 ]
 
 
@@ -77,6 +78,7 @@ def lib():
         L.mmh_scan.argtypes = [C.c_void_p, C.POINTER(PlanDesc), C.c_uint64, C.c_int, C.c_uint64, u64p, C.c_uint64, u64p]
         L.mmh_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.mmh_last_counters.argtypes = [C.c_void_p, u64p]
+        L.mmh_timing_history.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
         _lib = L
     return _lib
 
@@ -197,6 +199,12 @@ class Engine:
         t = (C.c_float * 4)()
         _check(lib().mmh_last_timings(self._h, t))
         return dict(filter_ms=t[0], post_filter_ms=t[1], total_ms=t[3])
+
+    def timing_history(self, n=64):
+        """(filter_ms, total_ms) arrays of the last <= n scans, oldest first."""
+        f, t, k = (C.c_float * n)(), (C.c_float * n)(), C.c_int(0)
+        _check(lib().mmh_timing_history(self._h, f, t, n, C.byref(k)))
+        return np.array(f[: k.value]), np.array(t[: k.value])
 
     def counters(self):
         c = (C.c_uint64 * 4)()

@@ -79,11 +79,16 @@ struct mmh_ctx {
    size_t dense_bytes = 0;
    uint64_t *h_result = nullptr;    // pinned: [kHeaderWords counters][kMaxRankSort ordered matches], written by the device
 
-   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+   // Ring of event triples {scan start, behind the streaming kernel, scan end}: elapsed
+   // times are only computed when somebody asks (mmh_last_timings / mmh_timing_history),
+   // never on the scan's own critical path.
+   static constexpr int kRing = 64;
+   hipEvent_t ring[kRing][3] = {};
+   bool ring_has_filter[kRing] = {};
+   uint64_t scans_recorded = 0;     // slot of scan k is k % kRing
+   hipEvent_t *ev = nullptr;        // the current scan's triple
    bool ctrl_clean = false;         // the previous scan's last kernel left d_ctrl zeroed
-   bool timings_pending = false;    // ev[] hold the last scan; elapsed times not computed yet
    int engine = 0;
-   float timings[4] = {0, 0, 0, 0};
    uint64_t counters[4] = {0, 0, 0, 0};
 };
 
@@ -112,12 +117,22 @@ int ensure_workspace(mmh_ctx *c, uint64_t out_cap)
       HIP_TRY(hipMalloc(&c->d_out, out_cap * sizeof(uint64_t)));
       c->out_cap = out_cap;
    }
-   for (auto &e : c->ev) {
-      if (!e) {
-         HIP_TRY(hipEventCreate(&e));
+   for (auto &triple : c->ring) {
+      for (auto &e : triple) {
+         if (!e) {
+            HIP_TRY(hipEventCreate(&e));
+         }
       }
    }
    return MMH_OK;
+}
+
+// next slot of the event ring
+void begin_scan_events(mmh_ctx *c, bool has_filter)
+{
+   const int slot = (int)(c->scans_recorded % mmh_ctx::kRing);
+   c->ev = c->ring[slot];
+   c->ring_has_filter[slot] = has_filter;
 }
 
 void release_rom(mmh_ctx *c)
@@ -198,8 +213,10 @@ extern "C" void mmh_destroy(mmh_ctx *c)
    if (c->d_partials) (void)hipFree(c->d_partials);
    if (c->d_dense) (void)hipFree(c->d_dense);
    if (c->h_result) (void)hipHostFree(c->h_result);
-   for (auto &e : c->ev) {
-      if (e) (void)hipEventDestroy(e);
+   for (auto &triple : c->ring) {
+      for (auto &e : triple) {
+         if (e) (void)hipEventDestroy(e);
+      }
    }
    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
    delete c;
@@ -362,6 +379,7 @@ int run_pipeline(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, const mm:
    c->ctrl_clean = false;
    // Only two events inside a scan (around the streaming kernel): every hipEventRecord
    // between dependent kernels costs ~6 us of stream time on this stack.
+   begin_scan_events(c, !sequential);
    HIP_TRY(hipEventRecord(c->ev[0], st));
    if (!sequential) {
       mm::launch_filter(st, g, pl, fc, c->d_cand, c->d_ctrl, c->cand_cap);
@@ -375,8 +393,9 @@ int run_pipeline(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, const mm:
    }
    mm::launch_rank_sort(st, c->d_out, c->d_ctrl, count_index, c->out_cap, kMaxRankSort, c->d_partials, c->h_result);
    HIP_TRY(hipGetLastError());
-   HIP_TRY(hipEventRecord(c->ev[3], st));
+   HIP_TRY(hipEventRecord(c->ev[2], st));
    HIP_TRY(hipStreamSynchronize(st));
+   c->scans_recorded++;
 
    oc->candidates = c->h_result[0];
    oc->listed = c->h_result[count_index];
@@ -386,7 +405,6 @@ int run_pipeline(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, const mm:
    oc->sorted_on_device = oc->listed <= kMaxRankSort && oc->listed <= c->out_cap;
    oc->matches = c->h_result[6] ? c->h_result[6] - 1 : oc->listed;
    c->ctrl_clean = true;                        // mm_rank_scatter's last block re-zeroed it
-   c->timings_pending = true;                   // elapsed times are computed when asked for
    return MMH_OK;
 }
 
@@ -400,7 +418,6 @@ int run_dense(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, uint64_t bas
    found->clear();
    const mm::DenseGeom dg = mm::dense_geom(g);
    if (dg.tpd == 0) {
-      std::memset(c->timings, 0, sizeof(c->timings));
       return MMH_OK;                              // no alignment fits anywhere
    }
    auto round = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
@@ -423,18 +440,16 @@ int run_dense(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, uint64_t bas
 
    HIP_TRY(hipMemsetAsync(c->d_ctrl, 0, mm::ctrl_bytes(), st));
    c->ctrl_clean = false;
-   c->timings_pending = false;
+   begin_scan_events(c, false);
    HIP_TRY(hipEventRecord(c->ev[0], st));
+   HIP_TRY(hipEventRecord(c->ev[1], st));
    mm::launch_dense(st, g, pl, dg, db, base_offset);
    HIP_TRY(hipGetLastError());
-   HIP_TRY(hipEventRecord(c->ev[3], st));
+   HIP_TRY(hipEventRecord(c->ev[2], st));
    std::vector<unsigned long long> ctrl(mm::ctrl_bytes() / sizeof(unsigned long long));
    HIP_TRY(hipMemcpyAsync(ctrl.data(), c->d_ctrl, mm::ctrl_bytes(), hipMemcpyDeviceToHost, st));
    HIP_TRY(hipStreamSynchronize(st));
-   c->timings[0] = 0;
-   c->timings[2] = 0;
-   (void)hipEventElapsedTime(&c->timings[1], c->ev[0], c->ev[3]);
-   c->timings[3] = c->timings[1];
+   c->scans_recorded++;
 
    const uint64_t list_cap = c->out_cap / MM_CAND_LISTS;
    uint64_t most = 0, total = 0;
@@ -505,8 +520,6 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
    }
    std::memset(c->counters, 0, sizeof(c->counters));
    if (g.nbytes == 0) {
-      c->timings_pending = false;
-      std::memset(c->timings, 0, sizeof(c->timings));
       return MMH_OK;
    }
 
@@ -587,21 +600,50 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
    return MMH_OK;
 }
 
+namespace {
+// timings of scan number k (it must still be in the ring)
+void scan_timings(mmh_ctx *c, uint64_t k, float *ms4)
+{
+   const int slot = (int)(k % mmh_ctx::kRing);
+   hipEvent_t *e = c->ring[slot];
+   ms4[0] = ms4[1] = ms4[2] = ms4[3] = 0;
+   (void)hipEventElapsedTime(&ms4[3], e[0], e[2]);
+   if (c->ring_has_filter[slot]) {
+      (void)hipEventElapsedTime(&ms4[0], e[0], e[1]);
+   }
+   ms4[1] = ms4[3] - ms4[0];                    // everything behind the streaming kernel
+}
+} // namespace
+
 extern "C" int mmh_last_timings(mmh_ctx *c, float *ms4)
 {
    if (!c || !ms4) {
       mmh_set_error("mmh_last_timings: bad argument");
       return MMH_E_ARG;
    }
-   if (c->timings_pending) {
-      // [1] = everything behind the streaming kernel (resolvers + ordering), [2] unused
-      (void)hipEventElapsedTime(&c->timings[0], c->ev[0], c->ev[1]);
-      (void)hipEventElapsedTime(&c->timings[1], c->ev[1], c->ev[3]);
-      (void)hipEventElapsedTime(&c->timings[3], c->ev[0], c->ev[3]);
-      c->timings[2] = 0;
-      c->timings_pending = false;
+   if (c->scans_recorded == 0) {
+      std::memset(ms4, 0, 4 * sizeof(float));
+      return MMH_OK;
    }
-   std::memcpy(ms4, c->timings, sizeof(c->timings));
+   scan_timings(c, c->scans_recorded - 1, ms4);
+   return MMH_OK;
+}
+
+extern "C" int mmh_timing_history(mmh_ctx *c, float *filter_ms, float *total_ms, int cap, int *count)
+{
+   if (!c || !filter_ms || !total_ms || !count || cap < 0) {
+      mmh_set_error("mmh_timing_history: bad argument");
+      return MMH_E_ARG;
+   }
+   const uint64_t have = std::min<uint64_t>(c->scans_recorded, mmh_ctx::kRing);
+   const int n = (int)std::min<uint64_t>(have, (uint64_t)cap);
+   for (int i = 0; i < n; i++) {
+      float t[4];
+      scan_timings(c, c->scans_recorded - n + i, t);
+      filter_ms[i] = t[0];
+      total_ms[i] = t[3];
+   }
+   *count = n;
    return MMH_OK;
 }
 
