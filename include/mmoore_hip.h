@@ -134,6 +134,11 @@ int mmh_timing_history(mmh_ctx *ctx, float *filter_ms, float *total_ms, int cap,
  * [3] path taken (0 filter + resolver, 1 sequential engine, 2 filter + resolver + hard resolver,
  * 3 dense engine). */
 int mmh_last_counters(mmh_ctx *ctx, uint64_t *c4);
+/* How the streaming filter keys on a plan (host only, no device needed; tests and tuning):
+ * info[0] number of SWAR conditions (0 = none: the dense engine runs), [1] anchor keyword
+ * position, [2] kernel shape id, [3] 1 when survivors are verified inside the filter kernel,
+ * [4+2k], [5+2k] keyword position and gap (1 adjacent, 2 over one wildcard) of condition k < 4. */
+int mmh_filter_shape(const mmh_plan_desc *plan, uint32_t *info12);
 
 #ifdef __cplusplus
 }

@@ -26,7 +26,7 @@ EXPORTS = [
     "mmh_last_error", "mmh_plan_relative", "mmh_plan_value_scan", "mmh_device_count", "mmh_create", "mmh_destroy",
     "mmh_set_stream", "mmh_rom_upload", "mmh_rom_attach", "mmh_rom_download", "mmh_rom_alloc", "mmh_rom_synth",
     "mmh_rom_poke", "mmh_rom_fill", "mmh_scan", "mmh_set_engine", "mmh_last_timings", "mmh_last_counters",
-    "mmh_timing_history",
+    "mmh_timing_history", "mmh_filter_shape",
 ]
 
 
@@ -78,6 +78,7 @@ def lib():
         L.mmh_scan.argtypes = [C.c_void_p, C.POINTER(PlanDesc), C.c_uint64, C.c_int, C.c_uint64, u64p, C.c_uint64, u64p]
         L.mmh_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.mmh_last_counters.argtypes = [C.c_void_p, u64p]
+        L.mmh_filter_shape.argtypes = [C.POINTER(PlanDesc), C.POINTER(C.c_uint32)]
         L.mmh_timing_history.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
         _lib = L
     return _lib
@@ -114,6 +115,16 @@ def plan_value_scan(elem_bytes, values):
     d = PlanDesc()
     _check(lib().mmh_plan_value_scan(elem_bytes, _p(v, C.c_int16), len(v), C.byref(d)))
     return d
+
+
+def filter_shape(plan):
+    """How the streaming filter keys on a plan (host only): number of SWAR conditions, anchor,
+    kernel shape, where survivors are verified, (keyword position, gap) of every condition."""
+    info = (C.c_uint32 * 12)()
+    _check(lib().mmh_filter_shape(C.byref(plan), info))
+    n = info[0]
+    return {"ncond": n, "anchor": info[1], "shape": info[2], "verify_in_filter": bool(info[3]),
+            "conditions": [(info[4 + 2 * k], info[5 + 2 * k]) for k in range(n)]}
 
 
 def device_count():

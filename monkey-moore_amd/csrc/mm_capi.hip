@@ -647,6 +647,25 @@ extern "C" int mmh_timing_history(mmh_ctx *c, float *filter_ms, float *total_ms,
    return MMH_OK;
 }
 
+extern "C" int mmh_filter_shape(const mmh_plan_desc *plan, uint32_t *info12)
+{
+   if (!plan || !info12 || plan->L < 2 || plan->L > MMH_MAX_KEYWORD || (plan->elem_bytes != 1 && plan->elem_bytes != 2)) {
+      mmh_set_error("mmh_filter_shape: bad argument");
+      return MMH_E_ARG;
+   }
+   std::memset(info12, 0, 12 * sizeof(uint32_t));
+   mm::FilterChoice fc;
+   if (mm::choose_filter(*plan, &fc)) {
+      info12[0] = fc.ncond; info12[1] = fc.iA; info12[2] = fc.shape;
+      info12[3] = mm::filter_verifies(*plan, fc) ? 1u : 0u;
+      for (uint32_t k = 0; k < fc.ncond; k++) {
+         info12[4 + 2 * k] = fc.pos[k];
+         info12[5 + 2 * k] = fc.gap[k];
+      }
+   }
+   return MMH_OK;
+}
+
 extern "C" int mmh_last_counters(mmh_ctx *c, uint64_t *c4)
 {
    if (!c || !c4) {

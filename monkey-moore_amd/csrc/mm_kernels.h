@@ -9,12 +9,18 @@
 namespace mm {
 
 struct FilterChoice {
-   uint32_t ncond;   // 0 = no usable SWAR condition (pattern has no two adjacent literals)
-   uint32_t iA;      // keyword position whose delta is condition 0
-   uint32_t pat[4];  // condition k = delta of position iA-k, replicated over the SWAR lanes
+   uint32_t ncond;     // 0 = no usable SWAR condition (no literal with a literal one or two to its left)
+   uint32_t iA;        // keyword position whose delta is condition 0 (the anchor)
+   uint32_t pat[4];    // expected delta of condition k, replicated over the SWAR lanes
+   uint32_t pos[4];    // keyword position of condition k (pos[0] = iA)
+   uint32_t shift[4];  // iA - pos[k]
+   uint32_t gap[4];    // 1 = compared with the left neighbour, 2 = over one wildcard
+   uint32_t shape;     // kernel instantiation (MM_F8_* / MM_F16_* in mm_kernels.hip)
 };
 
 bool choose_filter(const mmh_plan_desc &pl, FilterChoice *fc);
+// true: the filter kernel runs the full compare loop on its survivors; false: mm_resolve does
+bool filter_verifies(const mmh_plan_desc &pl, const FilterChoice &fc);
 
 void launch_filter(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc,
                    uint64_t *cand, unsigned long long *ctrl, uint64_t cand_cap);

@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <utility>
 
 #include "mm_internal.h"
 #include "mm_kernels.h"
@@ -187,6 +188,7 @@ struct MmFilterArgs {
    MmGeom g;
    mmh_plan_desc plan;
    uint32_t pat[4];        // condition k, replicated over the SWAR lanes
+   uint32_t sh[4];         // 8-bit shapes with run-time shifts: v_alignbit amount 32 - 8 s_k of condition k
    uint32_t iA;            // keyword index of the element whose delta is pat[0]
    uint32_t ncond;
    uint32_t verify;        // 1: run the full compare loop on survivors here; 0: leave it to mm_resolve
@@ -218,34 +220,47 @@ __device__ __forceinline__ uint4 mm_load_chunk(const uint8_t *rom, uint64_t nbyt
    return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// hit flags (bit 7 of a byte) of one dword; dbprev = byte deltas of the previous dword
-template <int NCOND>
-__device__ __forceinline__ uint32_t mm_f8_hits(uint32_t w, uint32_t wprev, uint32_t &dbprev, const uint32_t (&pat)[4])
+// SHAPE of an 8-bit filter: bits 0-2 = number of conditions NC (1..4); bits 4-7 = MASK2, bit k
+// set when condition k compares over a wildcard (gap 2: x[t-s] - x[t-s-2]) instead of with the
+// left neighbour (gap 1); bit 8 = the byte shifts s_k come from the kernel arguments (any
+// 1..3 with s_k + gap_k <= 4) instead of being k.  SHAPE = NC is the contiguous run of
+// adjacent literals (no wildcard between the last NC+1 keyword symbols used).
+#define MM_F8_NC(shape) ((shape) & 7)
+#define MM_F8_MASK2(shape) (((shape) >> 4) & 15)
+#define MM_F8_RT(shape) (((shape) >> 8) & 1)
+
+// hit flags (bit 7 of a byte) of one dword; p1 / p2 = gap-1 / gap-2 byte deltas of the previous dword
+template <int SHAPE>
+__device__ __forceinline__ uint32_t mm_f8_hits(uint32_t w, uint32_t wprev, uint32_t &p1, uint32_t &p2,
+                                               const uint32_t (&pat)[4], const uint32_t (&sh)[4])
 {
-   const uint32_t db = mm_bytesub(w, mm_alignbit(w, wprev, 24));
-   uint32_t z = db ^ pat[0];
-   if (NCOND >= 2) {
-      z |= mm_alignbit(db, dbprev, 24) ^ pat[1];
+   constexpr int NC = MM_F8_NC(SHAPE), M2 = MM_F8_MASK2(SHAPE);
+   constexpr bool RT = MM_F8_RT(SHAPE) != 0;
+   const uint32_t d1 = M2 != (1 << NC) - 1 ? mm_bytesub(w, mm_alignbit(w, wprev, 24)) : 0u;
+   const uint32_t d2 = M2 != 0 ? mm_bytesub(w, mm_alignbit(w, wprev, 16)) : 0u;
+   uint32_t z = ((M2 & 1) ? d2 : d1) ^ pat[0];
+#pragma unroll
+   for (int k = 1; k < NC; k++) {
+      const bool two = ((M2 >> k) & 1) != 0;
+      const uint32_t amount = RT ? sh[k] : (uint32_t)(32 - 8 * k);
+      z |= mm_alignbit(two ? d2 : d1, two ? p2 : p1, amount) ^ pat[k];
    }
-   if (NCOND >= 3) {
-      z |= mm_alignbit(db, dbprev, 16) ^ pat[2];
-   }
-   if (NCOND >= 4) {
-      z |= mm_alignbit(db, dbprev, 8) ^ pat[3];
-   }
-   dbprev = db;
+   p1 = d1;
+   p2 = d2;
    return mm_haszero8(z);
 }
 
 // hit flags of a 16-byte chunk; `back` = the dword in front of it
-template <int NCOND>
-__device__ __forceinline__ uint32_t mm_f8_chunk(const uint4 &w, uint32_t back, const uint32_t (&pat)[4], uint32_t (&h)[4])
+template <int SHAPE>
+__device__ __forceinline__ uint32_t mm_f8_chunk(const uint4 &w, uint32_t back, const uint32_t (&pat)[4],
+                                                const uint32_t (&sh)[4], uint32_t (&h)[4])
 {
-   uint32_t dbprev = mm_bytesub(back, back << 8);      // deltas of bytes -3..-1 (byte -4's is not needed)
-   h[0] = mm_f8_hits<NCOND>(w.x, back, dbprev, pat);
-   h[1] = mm_f8_hits<NCOND>(w.y, w.x, dbprev, pat);
-   h[2] = mm_f8_hits<NCOND>(w.z, w.y, dbprev, pat);
-   h[3] = mm_f8_hits<NCOND>(w.w, w.z, dbprev, pat);
+   uint32_t p1 = mm_bytesub(back, back << 8);       // gap-1 deltas of bytes -3..-1 (byte -4's is not needed)
+   uint32_t p2 = mm_bytesub(back, back << 16);      // gap-2 deltas of bytes -2..-1 (s + gap <= 4)
+   h[0] = mm_f8_hits<SHAPE>(w.x, back, p1, p2, pat, sh);
+   h[1] = mm_f8_hits<SHAPE>(w.y, w.x, p1, p2, pat, sh);
+   h[2] = mm_f8_hits<SHAPE>(w.z, w.y, p1, p2, pat, sh);
+   h[3] = mm_f8_hits<SHAPE>(w.w, w.z, p1, p2, pat, sh);
    return h[0] | h[1] | h[2] | h[3];
 }
 
@@ -280,7 +295,7 @@ __device__ __forceinline__ void mm_f8_survivors(const MmFilterArgs &a, uint64_t 
 
 // bounds-checked version for the ragged end of the ROM (everything behind the last
 // whole 4 KiB group): one chunk per lane per iteration, look-back by a second load
-template <int NCOND>
+template <int SHAPE>
 __global__ __launch_bounds__(256) void mm_filter_u8_edge(MmFilterArgs a)
 {
    const uint64_t nchunks = (a.g.nbytes + 15) / 16;
@@ -294,7 +309,7 @@ __global__ __launch_bounds__(256) void mm_filter_u8_edge(MmFilterArgs a)
       if (c < nchunks) {
          const uint4 w = mm_load_chunk(a.g.rom, a.g.nbytes, c * 16);
          const uint32_t back = c ? *reinterpret_cast<const uint32_t *>(a.g.rom + c * 16 - 4) : 0u;
-         any = mm_f8_chunk<NCOND>(w, back, a.pat, h);
+         any = mm_f8_chunk<SHAPE>(w, back, a.pat, a.sh, h);
       }
       if (__ballot(any != 0) != 0) {
          mm_f8_survivors(a, c * 16, mm_f8_pack(h));
@@ -309,7 +324,7 @@ __global__ __launch_bounds__(256) void mm_filter_u8_edge(MmFilterArgs a)
 // ~4 % of the read bandwidth on the table).  The dword in front of a lane's
 // chunk comes from the neighbouring lane (DPP wave_shr:1), lane 0 takes it from
 // lane 63 of the previous piece (v_readlane) -- no second memory access.
-template <int NCOND>
+template <int SHAPE>
 __global__ __launch_bounds__(256) void mm_filter_u8(MmFilterArgs a)
 {
    constexpr int DEPTH = 2;
@@ -347,7 +362,7 @@ __global__ __launch_bounds__(256) void mm_filter_u8(MmFilterArgs a)
                   // last dword of the previous 16 bytes: lane l-1's w.w; lane 0 keeps c
                   const uint32_t c = u == 0 ? carry : __builtin_amdgcn_readlane(w[s][u - 1].w, 63);
                   const uint32_t back = __builtin_amdgcn_update_dpp(c, w[s][u].w, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-                  any |= mm_f8_chunk<NCOND>(w[s][u], back, a.pat, h[u]);
+                  any |= mm_f8_chunk<SHAPE>(w[s][u], back, a.pat, a.sh, h[u]);
                }
                carry = __builtin_amdgcn_readlane(w[s][3].w, 63);
                if (__ballot(any != 0) != 0) {
@@ -378,11 +393,24 @@ __global__ __launch_bounds__(256) void mm_filter_u8(MmFilterArgs a)
 // The odd stream with two conditions looks 12 bytes back: r[0..2] are the three dwords in
 // front of the chunk, r[3..6] the chunk.
 
-template <int NCOND>
+// SHAPE of a 16-bit filter: bits 0-2 = number of conditions NC (1..2); bit 4 = condition 0
+// compares over a wildcard (gap 2: e(u) - e(u-4)); bits 5-6 = kind of condition 1:
+//     0  e(u-2) - e(u-4)   keyword position iA-1, gap 1 (the contiguous shape above)
+//     1  e(u-2) - e(u-6)   position iA-1, gap 2 (position iA-2 is a wildcard)
+//     2  e(u-4) - e(u-6)   position iA-2, gap 1 (position iA-1 is a wildcard; condition 0 has gap 2)
+// All of them stay inside the 12 bytes of look-back of the odd stream.
+#define MM_F16_NC(shape) ((shape) & 7)
+#define MM_F16_G0(shape) (((shape) >> 4) & 1)
+#define MM_F16_K1(shape) (((shape) >> 5) & 3)
+
+template <int SHAPE>
 __device__ __forceinline__ uint32_t mm_f16_chunk(const uint32_t (&r)[7], bool be, const uint32_t (&pat)[4],
                                                  uint32_t (&he)[4], uint32_t (&ho)[4])
 {
-   uint32_t ev[7], od[7], de[7], dd[7];
+   constexpr int NC = MM_F16_NC(SHAPE), K1 = MM_F16_K1(SHAPE);
+   constexpr bool G0 = MM_F16_G0(SHAPE) != 0;
+   constexpr bool NEED1 = !G0 || (NC >= 2 && K1 != 1), NEED2 = G0 || (NC >= 2 && K1 == 1);
+   uint32_t ev[7], od[7], de[7], dd[7], de2[7], dd2[7];
 #pragma unroll
    for (int k = 0; k < 7; k++) {
       ev[k] = be ? mm_bswap16x2(r[k]) : r[k];                       // elements at bytes 4k, 4k+2
@@ -391,21 +419,33 @@ __device__ __forceinline__ uint32_t mm_f16_chunk(const uint32_t (&r)[7], bool be
    for (int k = 1; k < 7; k++) {
       const uint32_t o = mm_alignbit(r[k], r[k - 1], 24);           // bytes 4k-1 .. 4k+2
       od[k] = be ? mm_bswap16x2(o) : o;                              // elements at bytes 4k-1, 4k+1
-      de[k] = mm_sub16x2(ev[k], mm_alignbit(ev[k], ev[k - 1], 16)); // even deltas
+      de[k] = NEED1 ? mm_sub16x2(ev[k], mm_alignbit(ev[k], ev[k - 1], 16)) : 0u;   // even deltas, gap 1
+      de2[k] = NEED2 ? mm_sub16x2(ev[k], ev[k - 1]) : 0u;                           // gap 2
    }
 #pragma unroll
    for (int k = 2; k < 7; k++) {
-      dd[k] = mm_sub16x2(od[k], mm_alignbit(od[k], od[k - 1], 16)); // odd deltas
+      dd[k] = NEED1 ? mm_sub16x2(od[k], mm_alignbit(od[k], od[k - 1], 16)) : 0u;   // odd deltas, gap 1
+      dd2[k] = NEED2 ? mm_sub16x2(od[k], od[k - 1]) : 0u;                           // gap 2
    }
    uint32_t any = 0;
 #pragma unroll
    for (int j = 0; j < 4; j++) {
       const int k = j + 3;
-      uint32_t ze = de[k] ^ pat[0];
-      uint32_t zo = dd[k] ^ pat[0];
-      if (NCOND >= 2) {
-         ze |= mm_alignbit(de[k], de[k - 1], 16) ^ pat[1];
-         zo |= mm_alignbit(dd[k], dd[k - 1], 16) ^ pat[1];
+      uint32_t ze = (G0 ? de2[k] : de[k]) ^ pat[0];
+      uint32_t zo = (G0 ? dd2[k] : dd[k]) ^ pat[0];
+      if (NC >= 2) {
+         if (K1 == 0) {
+            ze |= mm_alignbit(de[k], de[k - 1], 16) ^ pat[1];
+            zo |= mm_alignbit(dd[k], dd[k - 1], 16) ^ pat[1];
+         }
+         else if (K1 == 1) {
+            ze |= mm_alignbit(de2[k], de2[k - 1], 16) ^ pat[1];
+            zo |= mm_alignbit(dd2[k], dd2[k - 1], 16) ^ pat[1];
+         }
+         else {
+            ze |= de[k - 1] ^ pat[1];
+            zo |= dd[k - 1] ^ pat[1];
+         }
       }
       he[j] = mm_haszero16(ze);
       ho[j] = mm_haszero16(zo);
@@ -448,7 +488,7 @@ __device__ __forceinline__ void mm_f16_survivors(const MmFilterArgs &a, uint64_t
 }
 
 // bounds-checked version for the ragged end of the ROM
-template <int NCOND>
+template <int SHAPE>
 __global__ __launch_bounds__(256) void mm_filter_u16_edge(MmFilterArgs a)
 {
    const uint64_t nchunks = (a.g.nbytes + 15) / 16;
@@ -466,7 +506,7 @@ __global__ __launch_bounds__(256) void mm_filter_u16_edge(MmFilterArgs a)
          if (c) {
             r[0] = rom1[c * 4 - 3]; r[1] = rom1[c * 4 - 2]; r[2] = rom1[c * 4 - 1];
          }
-         any = mm_f16_chunk<NCOND>(r, be, a.pat, he, ho);
+         any = mm_f16_chunk<SHAPE>(r, be, a.pat, he, ho);
       }
       if (__ballot(any != 0) != 0) {
          mm_f16_survivors(a, c * 16, mm_f16_pack(he, ho));
@@ -476,7 +516,7 @@ __global__ __launch_bounds__(256) void mm_filter_u16_edge(MmFilterArgs a)
 
 // span kernel: same streaming structure as mm_filter_u8 (4 KiB groups, two groups of
 // look-ahead, look-back through DPP wave_shr:1 / v_readlane instead of a second load)
-template <int NCOND>
+template <int SHAPE>
 __global__ __launch_bounds__(256) void mm_filter_u16(MmFilterArgs a)
 {
    constexpr int DEPTH = 2;
@@ -524,7 +564,7 @@ __global__ __launch_bounds__(256) void mm_filter_u16(MmFilterArgs a)
                   r[1] = __builtin_amdgcn_update_dpp(k2, w[s][u].z, 0x138, 0xf, 0xf, false);
                   r[2] = __builtin_amdgcn_update_dpp(k3, w[s][u].w, 0x138, 0xf, 0xf, false);
                   r[3] = w[s][u].x; r[4] = w[s][u].y; r[5] = w[s][u].z; r[6] = w[s][u].w;
-                  any |= mm_f16_chunk<NCOND>(r, be, a.pat, he[u], ho[u]);
+                  any |= mm_f16_chunk<SHAPE>(r, be, a.pat, he[u], ho[u]);
                }
                c1 = __builtin_amdgcn_readlane(w[s][3].y, 63);
                c2 = __builtin_amdgcn_readlane(w[s][3].z, 63);
@@ -741,35 +781,97 @@ __global__ __launch_bounds__(256) void mm_pattern_fill(uint8_t *rom, uint64_t fi
 
 namespace mm {
 
+// Picks the SWAR conditions of a plan: an anchor position iA (condition 0) and up to three
+// more literal positions to its left, each compared with its left neighbour (gap 1) or, over
+// one wildcard, with the literal two to the left (gap 2 = bridge -2 of the plan).  Condition k
+// sits s_k = iA - position positions behind the anchor; the look-back of the kernels allows
+//     8-bit : s_k + gap_k <= 4                       (one dword in front of a chunk)
+//     16-bit: (s,gap) of condition 1 in {(1,1),(1,2),(2,1)}   (see mm_f16_chunk)
+// Among the anchors the one with the most conditions wins; ties go to the contiguous run of
+// adjacent literals (compile-time shifts), then to the rightmost anchor.
 bool choose_filter(const mmh_plan_desc &pl, FilterChoice *fc)
 {
    const int L = (int)pl.L;
-   const uint32_t emask = pl.elem_bytes == 1 ? 0xFFu : 0xFFFFu;
-   const uint32_t rep = pl.elem_bytes == 1 ? 0x01010101u : 0x00010001u;
-   // position i can serve as a condition when it is a literal compared with its left neighbour
-   auto adjacent = [&](int i) { return i >= 1 && pl.cmp_mask[i] != 0 && pl.bridge[i] == -1; };
-   const int want = pl.elem_bytes == 1 ? 4 : 2;
-   fc->ncond = 0;
-   for (int nc = want; nc >= 1 && fc->ncond == 0; nc--) {
-      for (int i = L - 1; i >= nc; --i) {
-         bool ok = true;
-         for (int k = 0; k < nc; k++) {
-            ok = ok && adjacent(i - k);
+   const bool u8 = pl.elem_bytes == 1;
+   const uint32_t emask = u8 ? 0xFFu : 0xFFFFu;
+   const uint32_t rep = u8 ? 0x01010101u : 0x00010001u;
+   auto gap_of = [&](int i) -> int {
+      if (i < 1 || pl.cmp_mask[i] == 0) {
+         return 0;
+      }
+      const int g = -(int)pl.bridge[i];
+      return (g == 1 || g == 2) && i - g >= 0 ? g : 0;
+   };
+   const int want = u8 ? 4 : 2;
+   FilterChoice best;
+   best.ncond = 0;
+   bool best_contiguous = false;
+   for (int A = L - 1; A >= 1; --A) {
+      const int g0 = gap_of(A);
+      if (!g0) {
+         continue;
+      }
+      FilterChoice c;
+      c.ncond = 1; c.iA = (uint32_t)A; c.shape = 0;
+      c.pos[0] = (uint32_t)A; c.shift[0] = 0; c.gap[0] = (uint32_t)g0;
+      for (int i = A - 1; i >= 1 && (int)c.ncond < want; --i) {
+         const int g = gap_of(i), s = A - i;
+         if (!g) {
+            continue;
          }
-         if (ok) {
-            fc->ncond = (uint32_t)nc;
-            fc->iA = (uint32_t)i;
-            for (int k = 0; k < 4; k++) {
-               fc->pat[k] = k < nc ? ((uint32_t)pl.expected[i - k] & emask) * rep : 0u;
-            }
-            break;
+         const bool fits = u8 ? (s + g <= 4) : ((s == 1 && g <= 2) || (s == 2 && g == 1));
+         if (fits) {
+            c.pos[c.ncond] = (uint32_t)i; c.shift[c.ncond] = (uint32_t)s; c.gap[c.ncond] = (uint32_t)g;
+            c.ncond++;
          }
       }
+      bool contiguous = true;
+      for (uint32_t k = 0; k < c.ncond; k++) {
+         contiguous = contiguous && c.shift[k] == k && c.gap[k] == 1;
+      }
+      if (c.ncond > best.ncond || (c.ncond == best.ncond && contiguous && !best_contiguous)) {
+         best = c;
+         best_contiguous = contiguous;
+      }
    }
-   return fc->ncond != 0;
+   if (best.ncond == 0) {
+      fc->ncond = 0;
+      return false;
+   }
+   *fc = best;
+   uint32_t mask2 = 0;
+   for (uint32_t k = 0; k < 4; k++) {
+      const bool used = k < fc->ncond;
+      fc->pat[k] = used ? ((uint32_t)pl.expected[fc->pos[k]] & emask) * rep : 0u;
+      if (!used) {
+         fc->pos[k] = 0; fc->shift[k] = 0; fc->gap[k] = 0;
+      }
+      else if (fc->gap[k] == 2) {
+         mask2 |= 1u << k;
+      }
+   }
+   if (u8) {
+      fc->shape = fc->ncond | (best_contiguous ? 0u : (mask2 << 4) | 0x100u);
+   }
+   else {
+      uint32_t kind = 0;
+      if (fc->ncond == 2) {
+         kind = fc->shift[1] == 2 ? 2u : (fc->gap[1] == 2 ? 1u : 0u);
+      }
+      fc->shape = fc->ncond | ((mask2 & 1u) << 4) | (kind << 5);
+   }
+   return true;
 }
 
-template <int NCOND>
+// Enough SWAR conditions -> few enough false survivors (2^-24 / 2^-32 of the positions) that
+// mm_resolve, which stages the bytes anyway, verifies them; otherwise the compare loop runs in
+// the filter kernel (it stalls the stream, so only where survivors would swamp the resolver).
+bool filter_verifies(const mmh_plan_desc &pl, const FilterChoice &fc)
+{
+   return !((pl.elem_bytes == 1 && fc.ncond >= 3) || (pl.elem_bytes == 2 && fc.ncond == 2));
+}
+
+template <int SHAPE>
 static void launch_filter_u8(hipStream_t st, const MmFilterArgs &a, const MmGeom &g)
 {
    if (a.ngroups) {
@@ -778,14 +880,14 @@ static void launch_filter_u8(hipStream_t st, const MmFilterArgs &a, const MmGeom
       if (blocks > 256 * 8) {
          blocks = 256 * 8;
       }
-      hipLaunchKernelGGL(mm_filter_u8<NCOND>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(mm_filter_u8<SHAPE>, dim3((unsigned)blocks), dim3(256), 0, st, a);
    }
    if (a.edge_first * 16 < g.nbytes) {
-      hipLaunchKernelGGL(mm_filter_u8_edge<NCOND>, dim3(1), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(mm_filter_u8_edge<SHAPE>, dim3(1), dim3(256), 0, st, a);
    }
 }
 
-template <int NCOND>
+template <int SHAPE>
 static void launch_filter_u16(hipStream_t st, const MmFilterArgs &a, const MmGeom &g)
 {
    if (a.ngroups) {
@@ -794,11 +896,19 @@ static void launch_filter_u16(hipStream_t st, const MmFilterArgs &a, const MmGeo
       if (blocks > 256 * 8) {
          blocks = 256 * 8;
       }
-      hipLaunchKernelGGL(mm_filter_u16<NCOND>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(mm_filter_u16<SHAPE>, dim3((unsigned)blocks), dim3(256), 0, st, a);
    }
    if (a.edge_first * 16 < g.nbytes) {
-      hipLaunchKernelGGL(mm_filter_u16_edge<NCOND>, dim3(1), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(mm_filter_u16_edge<SHAPE>, dim3(1), dim3(256), 0, st, a);
    }
+}
+
+// run-time-shift shapes of NC conditions: one instantiation per gap mask
+template <int NC, int... M2>
+static bool launch_filter_u8_masks(uint32_t mask2, std::integer_sequence<int, M2...>, hipStream_t st, const MmFilterArgs &a,
+                                   const MmGeom &g)
+{
+   return ((mask2 == (uint32_t)M2 ? (launch_filter_u8<NC | (M2 << 4) | 0x100>(st, a, g), true) : false) || ...);
 }
 
 void launch_filter(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc,
@@ -806,29 +916,48 @@ void launch_filter(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, con
 {
    MmFilterArgs a;
    a.g = g; a.plan = pl; a.iA = fc.iA; a.ncond = fc.ncond;
-   // enough SWAR conditions -> practically every survivor is real -> mm_resolve verifies it
-   a.verify = ((pl.elem_bytes == 1 && fc.ncond == 4) || (pl.elem_bytes == 2 && fc.ncond == 2)) ? 0u : 1u;
+   a.verify = filter_verifies(pl, fc) ? 1u : 0u;
    for (int k = 0; k < 4; k++) {
       a.pat[k] = fc.pat[k];
+      a.sh[k] = 32u - 8u * fc.shift[k];
    }
    a.cand = cand; a.list_count = ctrl + MM_CTRL_LISTS; a.list_cap = cand_cap / MM_CAND_LISTS;
    // whole 4 KiB groups go to the span kernel, the ragged end to the bounds-checked one
    a.ngroups = g.nbytes / 4096;
    a.groups_per_span = 16;
    a.edge_first = a.ngroups * 256;
+   const uint32_t shape = fc.shape;
    if (pl.elem_bytes == 1) {
-      switch (fc.ncond) {
-      case 4: launch_filter_u8<4>(st, a, g); break;
-      case 3: launch_filter_u8<3>(st, a, g); break;
-      case 2: launch_filter_u8<2>(st, a, g); break;
-      default: launch_filter_u8<1>(st, a, g); break;
+      const uint32_t mask2 = MM_F8_MASK2(shape);
+      if (!MM_F8_RT(shape)) {
+         switch (fc.ncond) {
+         case 4: launch_filter_u8<4>(st, a, g); break;
+         case 3: launch_filter_u8<3>(st, a, g); break;
+         case 2: launch_filter_u8<2>(st, a, g); break;
+         default: launch_filter_u8<1>(st, a, g); break;
+         }
+      }
+      else {
+         switch (fc.ncond) {
+         case 4: launch_filter_u8_masks<4>(mask2, std::make_integer_sequence<int, 16>(), st, a, g); break;
+         case 3: launch_filter_u8_masks<3>(mask2, std::make_integer_sequence<int, 8>(), st, a, g); break;
+         case 2: launch_filter_u8_masks<2>(mask2, std::make_integer_sequence<int, 4>(), st, a, g); break;
+         default: launch_filter_u8_masks<1>(mask2, std::make_integer_sequence<int, 2>(), st, a, g); break;
+         }
       }
    }
-   else if (fc.ncond == 2) {
-      launch_filter_u16<2>(st, a, g);
-   }
    else {
-      launch_filter_u16<1>(st, a, g);
+      switch (shape) {
+      case 1: launch_filter_u16<1>(st, a, g); break;
+      case 1 | 16: launch_filter_u16<1 | 16>(st, a, g); break;
+      case 2: launch_filter_u16<2>(st, a, g); break;
+      case 2 | 32: launch_filter_u16<2 | 32>(st, a, g); break;
+      case 2 | 16 | 64: launch_filter_u16<2 | 16 | 64>(st, a, g); break;
+      default:
+         // (gap-2 anchor with an adjacent second condition cannot occur: position iA-1 would be a wildcard)
+         launch_filter_u16<1>(st, a, g);
+         break;
+      }
    }
 }
 

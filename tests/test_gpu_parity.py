@@ -217,9 +217,9 @@ def test_keyword_lengths(mm, gpu_engine, oracle, L):
 
 
 def test_pattern_without_swar_key_uses_dense_engine(mm, gpu_engine, oracle):
-    # no two adjacent literals -> nothing for the streaming filter to key on
+    # no literal with a literal one or two places to its left -> nothing for the streaming filter to key on
     rng = np.random.default_rng(7)
-    kw = "a*c*e*g"
+    kw = "a**d**g"
     vals = [None if ch == "*" else ord(ch) for ch in kw]
     rom = _random_rom_with_plants(rng, 2 << 20, 1, vals, False)
     gpu_engine.upload(rom)
@@ -228,6 +228,38 @@ def test_pattern_without_swar_key_uses_dense_engine(mm, gpu_engine, oracle):
     assert gpu_engine.counters()["path"] == 3
     assert got.tolist() == oracle.engine(oplan, rom, 65536).tolist()
     assert len(got) >= 10
+
+
+def _wildcard_shapes(L):
+    # every placement of wildcards over an L-symbol keyword that leaves >= 2 literals
+    out = []
+    for mask in range(1 << L):
+        kw = "".join("*" if (mask >> i) & 1 else "abcdefghijkl"[(i * 5) % 12] for i in range(L))
+        if L - bin(mask).count("1") >= 2:
+            out.append(kw)
+    return out
+
+
+@pytest.mark.parametrize("elem,be", [(1, False), (2, False), (2, True)])
+def test_every_wildcard_placement(mm, gpu_engine, oracle, elem, be):
+    # Sweeps the SWAR condition shapes of the streaming filter (adjacent and over-a-wildcard
+    # deltas, run-time shifts, 1..4 conditions; choose_filter in mm_kernels.hip) through the
+    # span kernel: ROMs of whole 4 KiB groups plus a ragged tail, matches planted all over.
+    rng = np.random.default_rng(2024 + elem + int(be))
+    paths = set()
+    for n, kw in enumerate(_wildcard_shapes(6) + ["ab*de*gh", "abc*efgh*jkl", "a*c*e*g", "*b*d*f*h", "ab**ef*hi"]):
+        vals = [None if ch == "*" else ord(ch) for ch in kw]
+        rom = _random_rom_with_plants(rng, (96 << 10) + 4 * (n % 7) + 2, elem, vals, be)
+        gpu_engine.upload(rom)
+        plan, oplan = mm.plan_relative(elem, kw, ord("*")), oracle.plan(elem, kw, ord("*"))
+        got = gpu_engine.scan(plan, block_bytes=16384, big_endian=be)
+        paths.add(gpu_engine.counters()["path"])
+        want = oracle.engine(oplan, rom, 16384, big_endian=be)
+        assert got.tolist() == want.tolist(), kw
+        assert len(want) >= 3, kw
+        # whole-buffer mode reads the bytes as little-endian elements whatever they were written as
+        assert gpu_engine.scan(plan).tolist() == oracle.search(oplan, rom if elem == 1 else rom.view("<u2")).tolist(), kw
+    assert 0 in paths or 2 in paths
 
 
 def test_hard_candidates(mm, gpu_engine, oracle):

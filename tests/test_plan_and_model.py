@@ -101,3 +101,53 @@ def test_models_against_reference_engine_vectors(mm):
         assert _model.chain_seq(pl, rom, g) == c["expect"], c
         if idx % 2 == 0:
             assert _model.fast_path(pl, rom, g, tile=16, seg=4) == c["expect"], c
+
+
+@pytest.mark.parametrize("elem,kw,conds,verify", [
+    # (keyword position, gap) of the SWAR conditions the streaming filter keys on
+    (1, "relativesrch", [(11, 1), (10, 1), (9, 1), (8, 1)], False),     # BASELINE C2: the contiguous shape
+    (1, "abcde", [(4, 1), (3, 1), (2, 1), (1, 1)], False),
+    (1, "ab*de", [(4, 1), (3, 2), (1, 1)], False),                      # bench_search.cpp Wildcard/Middle
+    (1, "*bcde", [(4, 1), (3, 1), (2, 1)], False),
+    (1, "abcd*", [(3, 1), (2, 1), (1, 1)], False),
+    (1, "re*ative*ear*hxy", [(7, 1), (6, 1), (5, 1), (4, 1)], False),   # BASELINE C3
+    (1, "a*c*e*g", [(6, 2), (4, 2)], True),
+    (1, "a**d**g", [], None),
+    (2, "textsrch", [(7, 1), (6, 1)], False),                           # BASELINE C4
+    (2, "ab*de", [(4, 1), (3, 2)], False),
+    (2, "abc*e", [(2, 1), (1, 1)], False),                              # ties go to the contiguous run
+    (2, "*bc*e", [(4, 2), (2, 1)], False),
+    (2, "a*c*e", [(4, 2)], True),
+])
+def test_filter_conditions_chosen(mm, elem, kw, conds, verify):
+    info = mm.filter_shape(mm.plan_relative(elem, kw, ord("*")))
+    assert info["conditions"] == conds
+    assert info["ncond"] == len(conds)
+    if conds:
+        assert info["anchor"] == conds[0][0]
+        assert info["verify_in_filter"] == verify
+
+
+def test_filter_conditions_are_necessary_for_a_match(mm, oracle):
+    """Each chosen condition (position i, gap g, expected delta of the plan) must hold at every
+    match the oracle reports: the filter may only over-approximate the reference."""
+    rng = np.random.default_rng(99)
+    for elem in (1, 2):
+        for kw in ("ab*de", "a*c*e*g", "abc*efgh*jkl", "*b*d*f*h", "zyxwv", "ab**ef*hi"):
+            plan = mm.plan_relative(elem, kw, ord("*"))
+            info = mm.filter_shape(plan)
+            assert info["ncond"] >= 1
+            hi = 256 if elem == 1 else 65536
+            d = rng.integers(0, hi, 4096).astype(np.int64)
+            for pos in range(8, 4000, 97):
+                sh = int(rng.integers(-90, hi - 130))
+                for j, ch in enumerate(kw):
+                    if ch != "*":
+                        d[pos + j] = ord(ch) + sh
+            data = d.astype(np.uint8 if elem == 1 else np.uint16)
+            hits = oracle.search(oracle.plan(elem, kw, ord("*")), data)
+            assert len(hits) >= 10
+            for h in hits:
+                for i, g in info["conditions"]:
+                    delta = (int(data[h + i]) - int(data[h + i - g])) % hi
+                    assert delta == plan.expected[i] % hi, (kw, i, g)
