@@ -97,6 +97,20 @@ int mmh_rom_upload(mmh_ctx *ctx, const void *host, uint64_t nbytes);
 int mmh_rom_attach(mmh_ctx *ctx, const void *device_ptr, uint64_t nbytes);
 int mmh_rom_download(mmh_ctx *ctx, uint64_t first_byte, void *host, uint64_t nbytes);
 
+/* ROM straight from a file: bytes [file_offset, file_offset + nbytes) of `path` become the
+ * context's ROM.  `threads` readers (0 = automatic, at most 16) pread() 4 MiB pieces into
+ * pinned staging and queue each piece's host-to-device copy behind its read, so file reads
+ * and PCIe transfers overlap.  Replaces the workers' per-block ifstream reads of
+ * src/core/search_engine.cpp:120-145.  MMH_E_ARG: cannot open / short read. */
+int mmh_rom_load_file(mmh_ctx *ctx, const char *path, uint64_t file_offset, uint64_t nbytes, int threads);
+/* wall time, size and reader count of the last mmh_rom_load_file */
+int mmh_last_load_stats(mmh_ctx *ctx, double *seconds, uint64_t *bytes, int *threads);
+/* Packed copy of bytes_each bytes at each of n ROM byte offsets into host_out (n * bytes_each
+ * bytes; positions behind the ROM read as 0): the elements under every match, from which the
+ * host builds the equivalency maps of src/core/monkey_moore.cpp:374-393 without keeping its
+ * own copy of the file. */
+int mmh_rom_gather(mmh_ctx *ctx, const uint64_t *rom_offsets, uint64_t n, uint32_t bytes_each, void *host_out);
+
 /* Synthetic ROM (bench/tests): fill the attached/owned ROM [first_byte, +nbytes)
  * with splitmix64 words indexed by (rom_base_offset + byte) / 8, on the device. */
 int mmh_rom_alloc(mmh_ctx *ctx, uint64_t nbytes);

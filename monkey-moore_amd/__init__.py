@@ -26,7 +26,7 @@ EXPORTS = [
     "mmh_last_error", "mmh_plan_relative", "mmh_plan_value_scan", "mmh_device_count", "mmh_create", "mmh_destroy",
     "mmh_set_stream", "mmh_rom_upload", "mmh_rom_attach", "mmh_rom_download", "mmh_rom_alloc", "mmh_rom_synth",
     "mmh_rom_poke", "mmh_rom_fill", "mmh_scan", "mmh_set_engine", "mmh_last_timings", "mmh_last_counters",
-    "mmh_timing_history", "mmh_filter_shape",
+    "mmh_timing_history", "mmh_filter_shape", "mmh_rom_load_file", "mmh_last_load_stats", "mmh_rom_gather",
 ]
 
 
@@ -79,6 +79,9 @@ def lib():
         L.mmh_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.mmh_last_counters.argtypes = [C.c_void_p, u64p]
         L.mmh_filter_shape.argtypes = [C.POINTER(PlanDesc), C.POINTER(C.c_uint32)]
+        L.mmh_rom_load_file.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_int]
+        L.mmh_last_load_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double), u64p, C.POINTER(C.c_int)]
+        L.mmh_rom_gather.argtypes = [C.c_void_p, u64p, C.c_uint64, C.c_uint32, C.c_void_p]
         L.mmh_timing_history.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
         _lib = L
     return _lib
@@ -182,6 +185,20 @@ class Engine:
     def download(self, first_byte, nbytes):
         out = np.empty(nbytes, np.uint8)
         _check(lib().mmh_rom_download(self._h, first_byte, out.ctypes.data, nbytes))
+        return out
+
+    def load_file(self, path, file_offset, nbytes, threads=0):
+        """ROM <- bytes [file_offset, file_offset + nbytes) of a file (parallel readers + overlapped copies)."""
+        _check(lib().mmh_rom_load_file(self._h, os.fsencode(path), file_offset, nbytes, threads))
+        s, b, t = C.c_double(0), C.c_uint64(0), C.c_int(0)
+        _check(lib().mmh_last_load_stats(self._h, C.byref(s), C.byref(b), C.byref(t)))
+        return {"seconds": s.value, "bytes": b.value, "threads": t.value}
+
+    def gather(self, rom_offsets, bytes_each):
+        """bytes_each bytes at every ROM offset, as an (n, bytes_each) uint8 array."""
+        offs = np.ascontiguousarray(rom_offsets, dtype=np.uint64)
+        out = np.zeros((offs.size, bytes_each), np.uint8)
+        _check(lib().mmh_rom_gather(self._h, _p(offs, C.c_uint64), offs.size, bytes_each, out.ctypes.data))
         return out
 
     def set_stream(self, hip_stream):

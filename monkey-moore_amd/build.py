@@ -37,11 +37,11 @@ def _run(cmd):
 
 def build_capi(force=False):
     os.makedirs(LIB_DIR, exist_ok=True)
-    srcs = [os.path.join(CSRC, f) for f in ("mm_kernels.hip", "mm_capi.hip", "mm_plan.cpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("mm_kernels.hip", "mm_capi.hip", "mm_ingest.hip", "mm_plan.cpp")]
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "mmoore_hip.h")]
     if force or _newer(CAPI_SO, deps):
         _run([HIPCC, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
-              "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-x", "hip", srcs[0], srcs[1], srcs[2],
+              "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-x", "hip", *srcs, "-pthread",
               "-o", CAPI_SO])
     return CAPI_SO
 

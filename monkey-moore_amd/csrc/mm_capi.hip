@@ -14,6 +14,7 @@
 #include <string>
 #include <vector>
 
+#include "mm_context.h"
 #include "mm_internal.h"
 #include "mm_kernels.h"
 
@@ -55,43 +56,6 @@ extern "C" void mmh_set_error(const char *fmt, ...)
 
 extern "C" const char *mmh_last_error(void) { return g_error.c_str(); }
 
-struct mmh_ctx {
-   int device = 0;
-   hipStream_t own_stream = nullptr;
-   hipStream_t stream = nullptr;
-
-   uint8_t *rom = nullptr;
-   uint64_t rom_bytes = 0;
-   uint64_t rom_alloc = 0;          // > 0 when the library owns the buffer
-
-   uint64_t *d_cand = nullptr;      // candidate byte offsets
-   uint64_t cand_cap = 0;
-   uint64_t *d_out = nullptr;       // unordered matches
-   uint64_t out_cap = 0;
-   unsigned long long *d_ctrl = nullptr;   // counters + arrival tickets, zeroed per scan (mm::ResolveBuffers)
-   uint64_t *d_hard_off = nullptr;
-   uint64_t *d_hard_hi = nullptr;
-   uint32_t *d_hard_set = nullptr;
-   uint32_t *d_hard_slot = nullptr;
-   uint8_t *d_scratch = nullptr;    // tile maps of hard candidates
-   uint32_t *d_partials = nullptr;  // rank sort partial counts
-   uint8_t *d_dense = nullptr;      // dense engine: tile maps, super-tile maps, entry phases (one allocation)
-   size_t dense_bytes = 0;
-   uint64_t *h_result = nullptr;    // pinned: [kHeaderWords counters][kMaxRankSort ordered matches], written by the device
-
-   // Ring of event triples {scan start, behind the streaming kernel, scan end}: elapsed
-   // times are only computed when somebody asks (mmh_last_timings / mmh_timing_history),
-   // never on the scan's own critical path.
-   static constexpr int kRing = 64;
-   hipEvent_t ring[kRing][3] = {};
-   bool ring_has_filter[kRing] = {};
-   uint64_t scans_recorded = 0;     // slot of scan k is k % kRing
-   hipEvent_t *ev = nullptr;        // the current scan's triple
-   bool ctrl_clean = false;         // the previous scan's last kernel left d_ctrl zeroed
-   int engine = 0;
-   uint64_t counters[4] = {0, 0, 0, 0};
-};
-
 namespace {
 
 int ensure_workspace(mmh_ctx *c, uint64_t out_cap)
@@ -126,6 +90,12 @@ int ensure_workspace(mmh_ctx *c, uint64_t out_cap)
    }
    return MMH_OK;
 }
+
+} // namespace
+
+int mmh_workspace(mmh_ctx *c) { return ensure_workspace(c, std::max<uint64_t>(c->out_cap, kInitialCap)); }
+
+namespace {
 
 // next slot of the event ring
 void begin_scan_events(mmh_ctx *c, bool has_filter)
@@ -218,6 +188,9 @@ extern "C" void mmh_destroy(mmh_ctx *c)
          if (e) (void)hipEventDestroy(e);
       }
    }
+   for (void *p : c->ingest.staging) (void)hipHostFree(p);
+   for (hipEvent_t e : c->ingest.events) (void)hipEventDestroy(e);
+   for (hipStream_t t : c->ingest.streams) (void)hipStreamDestroy(t);
    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
    delete c;
 }

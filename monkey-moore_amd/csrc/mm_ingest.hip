@@ -1,0 +1,231 @@
+// mm_ingest.hip -- getting a file into HBM, and match bytes back out of it.
+//
+// The reference's workers each read their own blocks with an ifstream and scan them in
+// place (src/core/search_engine.cpp:120-145); with the scan on the GPU the file has to cross
+// PCIe instead.  One reader cannot feed a PCIe 5 x16 link from the page cache (a single
+// pread() stream copies at a few GB/s), so mmh_rom_load_file runs several readers, each
+// filling pinned 4 MiB pieces and queueing the host-to-device copy of a piece right behind
+// its read: reads, copies of different readers and the DMA engines all overlap.
+//
+// mmh_rom_gather is the way back: the elements under every match (for the equivalency maps,
+// monkey_moore.cpp:374-393) are packed by one small kernel and copied out in one piece, so
+// that the host never needs its own copy of the file.
+#include <hip/hip_runtime.h>
+
+#include <errno.h>
+#include <fcntl.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "mm_context.h"
+#include "mm_internal.h"
+#include "mm_kernels.h"
+
+namespace {
+
+bool ingest_resources(mmh_ctx *c, int threads, std::string *err)
+{
+   MmIngest &in = c->ingest;
+   auto fail = [&](const char *what, hipError_t e) {
+      *err = std::string(what) + ": " + hipGetErrorString(e);
+      return false;
+   };
+   while ((int)in.streams.size() < threads) {
+      hipStream_t s = nullptr;
+      hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+      if (e != hipSuccess) {
+         return fail("hipStreamCreate", e);
+      }
+      in.streams.push_back(s);
+   }
+   while ((int)in.staging.size() < 2 * threads) {
+      void *p = nullptr;
+      hipError_t e = hipHostMalloc(&p, MmIngest::kPiece, hipHostMallocDefault);
+      if (e != hipSuccess) {
+         return fail("hipHostMalloc (ingest staging)", e);
+      }
+      in.staging.push_back(p);
+      hipEvent_t ev = nullptr;
+      e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+      if (e != hipSuccess) {
+         return fail("hipEventCreate", e);
+      }
+      in.events.push_back(ev);
+   }
+   return true;
+}
+
+} // namespace
+
+extern "C" int mmh_rom_load_file(mmh_ctx *c, const char *path, uint64_t file_offset, uint64_t nbytes, int threads)
+{
+   if (!c || !path || threads < 0) {
+      mmh_set_error("mmh_rom_load_file: bad argument");
+      return MMH_E_ARG;
+   }
+   const auto t0 = std::chrono::steady_clock::now();
+   int rc = mmh_rom_alloc(c, nbytes);
+   if (rc != MMH_OK) {
+      return rc;
+   }
+   // the padding memset of mmh_rom_alloc runs on the scan stream; the copies do not
+   if (hipStreamSynchronize(c->stream) != hipSuccess) {
+      mmh_set_error("mmh_rom_load_file: stream synchronisation failed");
+      return MMH_E_DEVICE;
+   }
+   const uint64_t piece = MmIngest::kPiece;
+   const uint64_t npieces = (nbytes + piece - 1) / piece;
+   if (threads == 0) {
+      const unsigned hw = std::thread::hardware_concurrency();
+      threads = (int)std::min<unsigned>(16, hw ? hw : 1);
+   }
+   threads = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)threads, npieces));
+   std::string err;
+   if (!ingest_resources(c, threads, &err)) {
+      mmh_set_error("%s", err.c_str());
+      return MMH_E_DEVICE;
+   }
+   const int probe = open(path, O_RDONLY);
+   if (probe < 0) {
+      mmh_set_error("mmh_rom_load_file: cannot open %s: %s", path, strerror(errno));
+      return MMH_E_ARG;
+   }
+   close(probe);
+
+   std::atomic<uint64_t> next{0};
+   std::atomic<bool> failed{false};
+   std::mutex err_lock;
+   MmIngest &in = c->ingest;
+   auto reader = [&](int t) {
+      auto give_up = [&](const std::string &why) {
+         std::lock_guard<std::mutex> hold(err_lock);
+         if (!failed.exchange(true)) {
+            err = why;
+         }
+      };
+      if (hipSetDevice(c->device) != hipSuccess) {
+         return give_up("hipSetDevice failed in a reader thread");
+      }
+      const int fd = open(path, O_RDONLY);
+      if (fd < 0) {
+         return give_up(std::string("cannot open ") + path + ": " + strerror(errno));
+      }
+      bool used[2] = {false, false};
+      for (unsigned turn = 0; !failed; turn++) {
+         const uint64_t k = next.fetch_add(1);
+         if (k >= npieces) {
+            break;
+         }
+         const int slot = 2 * t + (int)(turn & 1);
+         if (used[turn & 1] && hipEventSynchronize(in.events[slot]) != hipSuccess) {
+            give_up("hipEventSynchronize failed");
+            break;
+         }
+         const uint64_t at = k * piece;
+         const uint64_t len = std::min(piece, nbytes - at);
+         uint8_t *dst = static_cast<uint8_t *>(in.staging[slot]);
+         uint64_t got = 0;
+         while (got < len) {
+            const ssize_t r = pread(fd, dst + got, len - got, (off_t)(file_offset + at + got));
+            if (r < 0 && errno == EINTR) {
+               continue;
+            }
+            if (r <= 0) {
+               give_up(r == 0 ? std::string("short read from ") + path : std::string("read error on ") + path + ": " + strerror(errno));
+               break;
+            }
+            got += (uint64_t)r;
+         }
+         if (got < len) {
+            break;
+         }
+         if (hipMemcpyAsync(c->rom + at, dst, len, hipMemcpyHostToDevice, in.streams[t]) != hipSuccess ||
+             hipEventRecord(in.events[slot], in.streams[t]) != hipSuccess) {
+            give_up("host-to-device copy failed");
+            break;
+         }
+         used[turn & 1] = true;
+      }
+      if (hipStreamSynchronize(in.streams[t]) != hipSuccess) {
+         give_up("hipStreamSynchronize failed in a reader thread");
+      }
+      close(fd);
+   };
+   std::vector<std::thread> pool;
+   for (int t = 1; t < threads; t++) {
+      pool.emplace_back(reader, t);
+   }
+   reader(0);
+   for (auto &th : pool) {
+      th.join();
+   }
+   in.last_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+   in.last_bytes = nbytes;
+   in.last_threads = threads;
+   if (failed) {
+      mmh_set_error("mmh_rom_load_file: %s", err.c_str());
+      return err.find("short read") != std::string::npos || err.find("cannot open") != std::string::npos ? MMH_E_ARG : MMH_E_DEVICE;
+   }
+   return MMH_OK;
+}
+
+extern "C" int mmh_last_load_stats(mmh_ctx *c, double *seconds, uint64_t *bytes, int *threads)
+{
+   if (!c || !seconds || !bytes || !threads) {
+      mmh_set_error("mmh_last_load_stats: bad argument");
+      return MMH_E_ARG;
+   }
+   *seconds = c->ingest.last_seconds;
+   *bytes = c->ingest.last_bytes;
+   *threads = c->ingest.last_threads;
+   return MMH_OK;
+}
+
+extern "C" int mmh_rom_gather(mmh_ctx *c, const uint64_t *offsets, uint64_t n, uint32_t bytes_each, void *host_out)
+{
+   if (!c || (n && (!offsets || !host_out)) || bytes_each == 0) {
+      mmh_set_error("mmh_rom_gather: bad argument");
+      return MMH_E_ARG;
+   }
+   if (!c->rom) {
+      mmh_set_error("mmh_rom_gather: no ROM attached");
+      return MMH_E_STATE;
+   }
+   if (n == 0) {
+      return MMH_OK;
+   }
+   int rc = mmh_workspace(c);
+   if (rc != MMH_OK) {
+      return rc;
+   }
+   // scan workspace doubles as staging: d_out takes the offsets, d_cand the packed bytes
+   const uint64_t batch = std::min<uint64_t>(c->out_cap, c->cand_cap * sizeof(uint64_t) / bytes_each);
+   if (batch == 0) {
+      mmh_set_error("mmh_rom_gather: %u bytes per offset is too much", bytes_each);
+      return MMH_E_ARG;
+   }
+   uint8_t *out = static_cast<uint8_t *>(host_out);
+   for (uint64_t first = 0; first < n; first += batch) {
+      const uint64_t m = std::min(batch, n - first);
+      if (hipMemcpyAsync(c->d_out, offsets + first, m * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+         mmh_set_error("mmh_rom_gather: offset upload failed");
+         return MMH_E_DEVICE;
+      }
+      mm::launch_gather(c->stream, c->rom, c->rom_bytes, c->d_out, m, bytes_each, reinterpret_cast<uint8_t *>(c->d_cand));
+      if (hipGetLastError() != hipSuccess ||
+          hipMemcpyAsync(out + first * bytes_each, c->d_cand, m * bytes_each, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+          hipStreamSynchronize(c->stream) != hipSuccess) {
+         mmh_set_error("mmh_rom_gather: device gather failed");
+         return MMH_E_DEVICE;
+      }
+   }
+   return MMH_OK;
+}

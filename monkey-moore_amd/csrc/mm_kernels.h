@@ -71,6 +71,8 @@ void launch_chain_seq(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, 
 void launch_rank_sort(hipStream_t st, const uint64_t *in, unsigned long long *ctrl, int count_index, uint64_t cap,
                       uint32_t max_n, uint32_t *partials, uint64_t *host_result);
 void launch_synth(hipStream_t st, uint8_t *rom, uint64_t nbytes, uint64_t seed, uint64_t base_offset);
+void launch_gather(hipStream_t st, const uint8_t *rom, uint64_t nbytes, const uint64_t *offsets, uint64_t n, uint32_t each,
+                   uint8_t *out);
 void launch_pattern_fill(hipStream_t st, uint8_t *rom, uint64_t first, uint64_t nbytes, int value, int ramp);
 
 } // namespace mm

@@ -775,6 +775,18 @@ __global__ __launch_bounds__(256) void mm_pattern_fill(uint8_t *rom, uint64_t fi
    }
 }
 
+// packed copy of `each` bytes at every one of n ROM offsets (bytes behind the ROM read as 0)
+__global__ __launch_bounds__(256) void mm_gather(const uint8_t *rom, uint64_t nbytes, const uint64_t *offsets, uint64_t n,
+                                                 uint32_t each, uint8_t *out)
+{
+   const uint64_t total = n * each;
+   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+      const uint64_t at = offsets[i / each] + i % each;
+      out[i] = at < nbytes ? rom[at] : (uint8_t)0;
+   }
+}
+
 // --------------------------------------------------------------------------
 // launch wrappers (called from mm_capi.hip)
 // --------------------------------------------------------------------------
@@ -1066,6 +1078,16 @@ void launch_rank_sort(hipStream_t st, const uint64_t *in, unsigned long long *ct
 void launch_synth(hipStream_t st, uint8_t *rom, uint64_t nbytes, uint64_t seed, uint64_t base_offset)
 {
    hipLaunchKernelGGL(mm_synth_fill, dim3(2048), dim3(256), 0, st, rom, nbytes, seed, base_offset);
+}
+
+void launch_gather(hipStream_t st, const uint8_t *rom, uint64_t nbytes, const uint64_t *offsets, uint64_t n, uint32_t each,
+                   uint8_t *out)
+{
+   const uint64_t total = n * each;
+   const unsigned blocks = (unsigned)std::min<uint64_t>((total + 255) / 256, 4096);
+   if (blocks) {
+      hipLaunchKernelGGL(mm_gather, dim3(blocks), dim3(256), 0, st, rom, nbytes, offsets, n, each, out);
+   }
 }
 
 void launch_pattern_fill(hipStream_t st, uint8_t *rom, uint64_t first, uint64_t nbytes, int value, int ramp)

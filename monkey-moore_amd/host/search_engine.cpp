@@ -148,23 +148,24 @@ std::vector<mmoore::SearchResult<DataType>> mmoore::SearchEngine<DataType>::run(
       throw std::runtime_error("Failed to open file: " + config.file_path.string());
    }
    mmh_ctx *ctx = thread_context();
-   std::vector<uint8_t> host;
-   std::vector<uint64_t> offsets(4096);
+   std::vector<uint64_t> offsets(4096), rom_offsets;
+   std::vector<uint8_t> under;                              // the elements under every match of a partition
    const int big_endian = config.endianness == Endianness::Big ? 1 : 0;
+   const uint32_t match_bytes = st.plan.L * static_cast<uint32_t>(sizeof(DataType));
+   const std::string path = config.file_path.string();
+   file.close();
 
    for (uint64_t first_block = 0; first_block < num_blocks; first_block += blocks_per_partition) {
       const uint64_t nblk = std::min(blocks_per_partition, num_blocks - first_block);
       const uint64_t base = first_block * block;                                 // 64-bit, unlike the reference
       const uint64_t want = std::min(nblk * block + overlap, file_size - base);  // pattern-length overlap
-      host.resize(want);
-      file.clear();
-      file.seekg(static_cast<std::streamoff>(base), std::ios::beg);
-      file.read(reinterpret_cast<char *>(host.data()), static_cast<std::streamsize>(want));
-      if (static_cast<uint64_t>(file.gcount()) != want) {
-         throw std::runtime_error("Short read from " + config.file_path.string());
-      }
-      if (mmh_rom_upload(ctx, host.data(), want) != MMH_OK) {
-         throw_last_error("uploading a file partition failed");
+      // file -> HBM through parallel readers and overlapped copies (mm_ingest.hip); no host copy is kept
+      if (mmh_rom_load_file(ctx, path.c_str(), base, want, 0) != MMH_OK) {
+         const std::string why = mmh_last_error();
+         if (why.find("short read") != std::string::npos) {
+            throw std::runtime_error("Short read from " + path);
+         }
+         throw_last_error("streaming a file partition to the GPU failed");
       }
       uint64_t count = 0;
       for (;;) {
@@ -178,8 +179,18 @@ std::vector<mmoore::SearchResult<DataType>> mmoore::SearchEngine<DataType>::run(
          }
          break;
       }
+      if (count && !st.value_scan) {
+         rom_offsets.resize(count);
+         for (uint64_t i = 0; i < count; i++) {
+            rom_offsets[i] = offsets[i] - base;
+         }
+         under.resize(count * match_bytes);
+         if (mmh_rom_gather(ctx, rom_offsets.data(), count, match_bytes, under.data()) != MMH_OK) {
+            throw_last_error("fetching the matched elements failed");
+         }
+      }
       for (uint64_t i = 0; i < count; i++) {
-         const uint8_t *at = host.data() + (offsets[i] - base);
+         const uint8_t *at = st.value_scan ? nullptr : under.data() + i * match_bytes;
          const Endianness order = config.endianness;
          auto elem = [at, order](int k) { return element_at<DataType>(at + static_cast<size_t>(k) * sizeof(DataType), order); };
          results.push_back({offsets[i], build_values_map<DataType>(st, elem), std::string()});

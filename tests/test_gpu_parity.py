@@ -320,3 +320,30 @@ def test_c1_reference_benchmark_input_vs_compiled_reference(mm, gpu_engine, elem
         assert got.tolist() == want.tolist(), kw
         total += len(want)
     assert total == (2 if elem == 1 else 0)   # what the reference finds in its own benchmark buffer
+
+
+def test_rom_from_file_and_gather(mm, gpu_engine, oracle, tmp_path):
+    # mmh_rom_load_file (parallel readers, overlapped copies) against the bytes of the file, at
+    # offsets and sizes that are not multiples of the 4 MiB staging piece; mmh_rom_gather against numpy
+    rng = np.random.default_rng(77)
+    kw = "relativesrch"
+    data = _random_rom_with_plants(rng, (21 << 20) + 12345, 1, [ord(c) for c in kw], False, nplants=200)
+    path = tmp_path / "rom.bin"
+    data.tofile(path)
+    for off, n, threads in [(0, data.size, 0), (4099, (9 << 20) + 7, 3), (data.size - 100, 100, 1), (5, 0, 2)]:
+        stats = gpu_engine.load_file(str(path), off, n, threads)
+        assert stats["bytes"] == n
+        if n:
+            assert gpu_engine.download(0, n).tobytes() == data[off:off + n].tobytes()
+    gpu_engine.load_file(str(path), 0, data.size)
+    plan, oplan = mm.plan_relative(1, kw), oracle.plan(1, kw)
+    got = gpu_engine.scan(plan, block_bytes=524288)
+    assert got.tolist() == oracle.engine(oplan, data, 524288).tolist() and len(got) >= 150
+    under = gpu_engine.gather(got, len(kw))
+    assert under.tolist() == [data[o:o + len(kw)].tolist() for o in got.tolist()]
+    tail = gpu_engine.gather([data.size - 3], 8)           # bytes behind the ROM read as zero
+    assert tail[0].tolist() == data[-3:].tolist() + [0] * 5
+    with pytest.raises(mm.MMError):
+        gpu_engine.load_file(str(tmp_path / "missing.bin"), 0, 16)
+    with pytest.raises(mm.MMError):
+        gpu_engine.load_file(str(path), data.size - 10, 100)  # runs off the end of the file: short read
