@@ -36,13 +36,25 @@ def _run(cmd):
 
 
 def build_capi(force=False):
+    """libmmoore_hip.so: every csrc translation unit to its own object (in parallel), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIB_DIR, exist_ok=True)
-    srcs = [os.path.join(CSRC, f) for f in ("mm_kernels.hip", "mm_capi.hip", "mm_ingest.hip", "mm_plan.cpp")]
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "mmoore_hip.h")]
-    if force or _newer(CAPI_SO, deps):
-        _run([HIPCC, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
-              "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-x", "hip", *srcs, "-pthread",
-              "-o", CAPI_SO])
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    units = ("mm_kernels.hip", "mm_capi.hip", "mm_ingest.hip", "mm_sort.hip", "mm_plan.cpp")
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(ROOT, "include", "mmoore_hip.h")]
+    flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+
+    def compile_unit(name):
+        src, obj = os.path.join(CSRC, name), os.path.join(obj_dir, name + ".o")
+        if force or _newer(obj, [src] + headers):
+            _run([HIPCC, *flags, "-x", "hip", "-c", src, "-o", obj])
+        return obj
+
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        objs = list(pool.map(compile_unit, units))
+    if force or _newer(CAPI_SO, objs):
+        _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", *objs, "-pthread", "-o", CAPI_SO])
     return CAPI_SO
 
 

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -182,6 +183,9 @@ extern "C" void mmh_destroy(mmh_ctx *c)
    if (c->d_scratch) (void)hipFree(c->d_scratch);
    if (c->d_partials) (void)hipFree(c->d_partials);
    if (c->d_dense) (void)hipFree(c->d_dense);
+   if (c->d_sort_in) (void)hipFree(c->d_sort_in);
+   if (c->d_sort_out) (void)hipFree(c->d_sort_out);
+   if (c->d_sort_tmp) (void)hipFree(c->d_sort_tmp);
    if (c->h_result) (void)hipHostFree(c->h_result);
    for (auto &triple : c->ring) {
       for (auto &e : triple) {
@@ -381,6 +385,50 @@ int run_pipeline(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, const mm:
    return MMH_OK;
 }
 
+int grow(uint64_t **buf, uint64_t *cap, uint64_t need)
+{
+   if (need > *cap) {
+      if (*buf) {
+         HIP_TRY(hipFree(*buf));
+         *buf = nullptr;
+         *cap = 0;
+      }
+      const uint64_t want = need + need / 4 + 1024;
+      HIP_TRY(hipMalloc(buf, want * sizeof(uint64_t)));
+      *cap = want;
+   }
+   return MMH_OK;
+}
+
+// n keys in device memory -> ascending in host memory, "not a match" slots (~0) dropped
+int sort_to_host(mmh_ctx *c, const uint64_t *keys, uint64_t n, std::vector<uint64_t> *sorted)
+{
+   sorted->clear();
+   if (n == 0) {
+      return MMH_OK;
+   }
+   int rc = grow(&c->d_sort_out, &c->sort_out_cap, n);
+   if (rc != MMH_OK) {
+      return rc;
+   }
+   const size_t tmp = mm::sort_temp_bytes(n);
+   if (tmp > c->sort_tmp_bytes) {
+      if (c->d_sort_tmp) {
+         HIP_TRY(hipFree(c->d_sort_tmp));
+         c->d_sort_tmp = nullptr;
+         c->sort_tmp_bytes = 0;
+      }
+      HIP_TRY(hipMalloc(&c->d_sort_tmp, tmp + tmp / 4));
+      c->sort_tmp_bytes = tmp + tmp / 4;
+   }
+   HIP_TRY(mm::sort_keys(c->stream, keys, c->d_sort_out, n, c->d_sort_tmp, c->sort_tmp_bytes));
+   sorted->resize(n);
+   HIP_TRY(hipMemcpyAsync(sorted->data(), c->d_sort_out, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+   HIP_TRY(hipStreamSynchronize(c->stream));
+   sorted->erase(std::lower_bound(sorted->begin(), sorted->end(), ~0ull), sorted->end());
+   return MMH_OK;
+}
+
 // The candidate-free forward engine (mm_dense.h).  Matches land in MM_CAND_LISTS device
 // lists; they are fetched and ordered on the host (dense results are long lists anyway).
 int run_dense(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, uint64_t base_offset, std::vector<uint64_t> *found,
@@ -440,17 +488,20 @@ int run_dense(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, uint64_t bas
       *grew = true;
       return MMH_OK;
    }
-   found->resize(total);
+   // pack the lists, then order them the way search_engine.cpp:193-197 does -- on the device
+   int rc = grow(&c->d_sort_in, &c->sort_in_cap, total);
+   if (rc != MMH_OK) {
+      return rc;
+   }
    uint64_t at = 0;
    for (int l = 0; l < MM_CAND_LISTS; l++) {
       const uint64_t n = ctrl[MM_CTRL_LISTS + l * MM_LIST_STRIDE];
       if (n) {
-         HIP_TRY(hipMemcpy(found->data() + at, c->d_out + (uint64_t)l * list_cap, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+         HIP_TRY(hipMemcpyAsync(c->d_sort_in + at, c->d_out + (uint64_t)l * list_cap, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
          at += n;
       }
    }
-   std::sort(found->begin(), found->end());       // search_engine.cpp:193-197
-   return MMH_OK;
+   return sort_to_host(c, c->d_sort_in, total, found);
 }
 
 } // namespace
@@ -502,7 +553,14 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
    // pattern, candidate sets too dense, prefixes too long) go to the forward "dense" engine,
    // whose cost is linear in the ROM.  1 / 2 force the sequential / dense engine (tests).
    enum { FAST, SEQUENTIAL, DENSE } mode = c->engine == 1 ? SEQUENTIAL : (c->engine == 2 || !have_filter) ? DENSE : FAST;
-   const uint32_t max_candidates = g.whole ? 262144u : 16384u;
+   // More candidates than this and the forward engine (cost linear in the ROM: ~6 ms per GiB)
+   // is the better deal: the resolvers take ~2-10 ns per candidate (measured: 65 K candidates
+   // of a 3-symbol keyword on 4 GiB add 0.14 ms, against 23 ms for the forward engine).
+   // Lists beyond kMaxRankSort entries are ordered by the radix sort of mm_sort.hip.
+   uint32_t max_candidates = 262144u;
+   if (const char *knob = getenv("MMOORE_MAX_CANDIDATES")) {
+      max_candidates = (uint32_t)std::min<unsigned long long>(strtoull(knob, nullptr, 10), c->cand_cap / 2);
+   }
 
    Outcome oc;
    std::vector<uint64_t> long_list;
@@ -540,13 +598,13 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
       break;
    }
 
-   // lists too long for the device rank sort: fetch, drop the "not a match" slots and
-   // order on the host, as search_engine.cpp:193-197 does
+   // lists too long for the rank kernels: radix sort on the device, "not a match" slots dropped
+   // (search_engine.cpp:193-197 does a std::sort)
    if (!host_list && !oc.sorted_on_device) {
-      long_list.resize(oc.listed);
-      HIP_TRY(hipMemcpy(long_list.data(), c->d_out, oc.listed * sizeof(uint64_t), hipMemcpyDeviceToHost));
-      long_list.erase(std::remove(long_list.begin(), long_list.end(), ~0ull), long_list.end());
-      std::sort(long_list.begin(), long_list.end());
+      rc = sort_to_host(c, c->d_out, oc.listed, &long_list);
+      if (rc != MMH_OK) {
+         return rc;
+      }
       oc.matches = long_list.size();
       host_list = true;
    }

@@ -41,6 +41,12 @@ struct mmh_ctx {
    uint32_t *d_partials = nullptr;  // rank sort partial counts
    uint8_t *d_dense = nullptr;      // dense engine: tile maps, super-tile maps, entry phases (one allocation)
    size_t dense_bytes = 0;
+   uint64_t *d_sort_in = nullptr;   // long lists: contiguous keys (dense engine), ordered keys, rocPRIM scratch
+   uint64_t sort_in_cap = 0;
+   uint64_t *d_sort_out = nullptr;
+   uint64_t sort_out_cap = 0;
+   void *d_sort_tmp = nullptr;
+   size_t sort_tmp_bytes = 0;
    uint64_t *h_result = nullptr;    // pinned: [kHeaderWords counters][kMaxRankSort ordered matches], written by the device
 
    // Ring of event triples {scan start, behind the streaming kernel, scan end}: elapsed

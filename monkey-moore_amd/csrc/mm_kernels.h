@@ -70,6 +70,9 @@ void launch_chain_seq(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, 
 // publishes the counters in host_result[0..8) and leaves ctrl zeroed; see mm_rank_scatter
 void launch_rank_sort(hipStream_t st, const uint64_t *in, unsigned long long *ctrl, int count_index, uint64_t cap,
                       uint32_t max_n, uint32_t *partials, uint64_t *host_result);
+// ascending order of n 64-bit keys (mm_sort.hip, rocPRIM radix sort); in and out must not overlap
+size_t sort_temp_bytes(uint64_t n);
+hipError_t sort_keys(hipStream_t st, const uint64_t *in, uint64_t *out, uint64_t n, void *temp, size_t temp_bytes);
 void launch_synth(hipStream_t st, uint8_t *rom, uint64_t nbytes, uint64_t seed, uint64_t base_offset);
 void launch_gather(hipStream_t st, const uint8_t *rom, uint64_t nbytes, const uint64_t *offsets, uint64_t n, uint32_t each,
                    uint8_t *out);

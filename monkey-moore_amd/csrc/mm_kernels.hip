@@ -875,11 +875,23 @@ bool choose_filter(const mmh_plan_desc &pl, FilterChoice *fc)
    return true;
 }
 
-// Enough SWAR conditions -> few enough false survivors (2^-24 / 2^-32 of the positions) that
-// mm_resolve, which stages the bytes anyway, verifies them; otherwise the compare loop runs in
-// the filter kernel (it stalls the stream, so only where survivors would swamp the resolver).
+// Who runs the reference's compare loop on the SWAR survivors.  mm_resolve does (it stages the
+// bytes anyway) when there are few false survivors -- 2^-24 / 2^-32 of the positions with 3 / 2
+// conditions -- or when the conditions already ARE the whole pattern (short keywords: every
+// survivor is a match up to the signed / modular distinction, and has to be resolved anyway).
+// Otherwise the loop runs in the filter kernel: that stalls the stream, but keeps millions of
+// false survivors away from the resolver.
 bool filter_verifies(const mmh_plan_desc &pl, const FilterChoice &fc)
 {
+   // independent comparisons of the pattern: the simple path also compares position 0 with the
+   // last one (bridge L-1), which the deltas in between already imply
+   uint32_t compared = 0;
+   for (uint32_t i = 0; i < pl.L; i++) {
+      compared += (pl.cmp_mask[i] != 0 && pl.bridge[i] < 0) ? 1u : 0u;
+   }
+   if (fc.ncond >= compared) {
+      return false;
+   }
    return !((pl.elem_bytes == 1 && fc.ncond >= 3) || (pl.elem_bytes == 2 && fc.ncond == 2));
 }
 

@@ -163,6 +163,23 @@ def test_dense_matches_constant_data(mm, gpu_engine, oracle):
     assert gpu_engine.scan(plan).tolist() == oracle.search(oplan, small).tolist()
 
 
+def test_many_matches_stay_on_the_resolver_path(mm, gpu_engine, oracle):
+    # tens of thousands of candidates: still filter + per-candidate resolvers (not the forward
+    # engine), ordered by the device radix sort instead of the rank kernels
+    rng = np.random.default_rng(5)
+    kw = "words"
+    rom = _random_rom_with_plants(rng, 32 << 20, 1, [ord(c) for c in kw], False, nplants=40000)
+    gpu_engine.upload(rom)
+    plan, oplan = mm.plan_relative(1, kw), oracle.plan(1, kw)
+    got = gpu_engine.scan(plan, block_bytes=524288, cap=1 << 17)
+    c = gpu_engine.counters()
+    assert c["path"] in (0, 2) and c["candidates"] > 30000
+    want = oracle.engine(oplan, rom, 524288)
+    assert got.tolist() == want.tolist() and len(want) > 16384
+    assert gpu_engine.scan(plan, cap=1 << 17).tolist() == oracle.search(oplan, rom).tolist()
+    assert gpu_engine.scan(plan, block_bytes=524288, cap=1000).tolist() == want.tolist()   # MMH_E_CAPACITY, retried bigger
+
+
 def test_low_entropy_alphabets(mm, gpu_engine, oracle):
     # small alphabets force unsafe skips, overlaps and long non-coalescing chains
     rng = np.random.default_rng(11)

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Collects the profiles/ evidence of a round on the GPU box (run through gpurun from the repo root):
+#   tools/collect_profiles.sh r01
+# kernel trace + stats of the default bench run, FETCH_SIZE and WRITE_SIZE in separate PMC passes
+# (never combined with tracing), and the un-profiled bench line.  Summaries land in gpurun_out/.
+set -u
+TAG=${1:-r01}
+REPO=$PWD
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd /tmp
+python3 "$REPO/bench.py" > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$REPO/bench.py" > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --prewarm-s 0.05 > /dev/null 2> "$OUT/pmc_fetch.err"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --prewarm-s 0.05 > /dev/null 2> "$OUT/pmc_write.err"
+cd "$REPO"
+python3 tools/summarize_profiles.py "$OUT" "$TAG"
