@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <utility>
 
 #include "mm_internal.h"
@@ -229,10 +230,11 @@ __device__ __forceinline__ uint4 mm_load_chunk(const uint8_t *rom, uint64_t nbyt
 #define MM_F8_MASK2(shape) (((shape) >> 4) & 15)
 #define MM_F8_RT(shape) (((shape) >> 8) & 1)
 
-// hit flags (bit 7 of a byte) of one dword; p1 / p2 = gap-1 / gap-2 byte deltas of the previous dword
+// One dword: a byte of the result is zero where all conditions of SHAPE hold for the match
+// anchored at that byte; p1 / p2 = gap-1 / gap-2 byte deltas of the previous dword
 template <int SHAPE>
-__device__ __forceinline__ uint32_t mm_f8_hits(uint32_t w, uint32_t wprev, uint32_t &p1, uint32_t &p2,
-                                               const uint32_t (&pat)[4], const uint32_t (&sh)[4])
+__device__ __forceinline__ uint32_t mm_f8_z(uint32_t w, uint32_t wprev, uint32_t &p1, uint32_t &p2,
+                                            const uint32_t (&pat)[4], const uint32_t (&sh)[4])
 {
    constexpr int NC = MM_F8_NC(SHAPE), M2 = MM_F8_MASK2(SHAPE);
    constexpr bool RT = MM_F8_RT(SHAPE) != 0;
@@ -247,7 +249,39 @@ __device__ __forceinline__ uint32_t mm_f8_hits(uint32_t w, uint32_t wprev, uint3
    }
    p1 = d1;
    p2 = d2;
-   return mm_haszero8(z);
+   return z;
+}
+
+// hit flags (bit 7 of a byte) of one dword
+template <int SHAPE>
+__device__ __forceinline__ uint32_t mm_f8_hits(uint32_t w, uint32_t wprev, uint32_t &p1, uint32_t &p2,
+                                               const uint32_t (&pat)[4], const uint32_t (&sh)[4])
+{
+   return mm_haszero8(mm_f8_z<SHAPE>(w, wprev, p1, p2, pat, sh));
+}
+
+// The first two conditions of a shape: what the streaming loop tests on every byte.  They let
+// 2^-16 of random positions through, i.e. some lane of a wave sees a hit in ~1.6 % of its
+// 1 KiB pieces; only then are all conditions evaluated (mm_f8_chunk) -- 14 instead of 21 VALU
+// operations per dword on the hot path, which is what separates the filter from the pure-read
+// bandwidth of the chip.
+#define MM_F8_STAGE1(shape) (((shape) & 0x130) | (MM_F8_NC(shape) < 2 ? MM_F8_NC(shape) : 2))
+
+// non-zero when some byte of the chunk passes the stage-1 conditions
+template <int SHAPE>
+__device__ __forceinline__ uint32_t mm_f8_chunk_any(const uint4 &w, uint32_t back, const uint32_t (&pat)[4],
+                                                    const uint32_t (&sh)[4])
+{
+   constexpr int S1 = MM_F8_STAGE1(SHAPE);
+   uint32_t p1 = mm_bytesub(back, back << 8);
+   uint32_t p2 = mm_bytesub(back, back << 16);
+   const uint32_t z0 = mm_f8_z<S1>(w.x, back, p1, p2, pat, sh);
+   const uint32_t z1 = mm_f8_z<S1>(w.y, w.x, p1, p2, pat, sh);
+   const uint32_t z2 = mm_f8_z<S1>(w.z, w.y, p1, p2, pat, sh);
+   const uint32_t z3 = mm_f8_z<S1>(w.w, w.z, p1, p2, pat, sh);
+   // mm_haszero8 on all four, with the final mask shared
+   return (((z0 - 0x01010101u) & ~z0) | ((z1 - 0x01010101u) & ~z1) | ((z2 - 0x01010101u) & ~z2) | ((z3 - 0x01010101u) & ~z3)) &
+          0x80808080u;
 }
 
 // hit flags of a 16-byte chunk; `back` = the dword in front of it
@@ -335,7 +369,16 @@ __global__ __launch_bounds__(256) void mm_filter_u8(MmFilterArgs a)
    const uint4 *rom4 = reinterpret_cast<const uint4 *>(a.g.rom);
    const uint32_t *rom1 = reinterpret_cast<const uint32_t *>(a.g.rom);
 
-   for (uint64_t g0 = wave * gps; g0 < a.ngroups; g0 += nwaves * gps) {
+   // Round i hands span i*nwaves + ((wave + 2731 i) mod nwaves) to this wave: neighbouring waves
+   // still stream neighbouring spans, but anything periodic in the ROM (candidates at every
+   // 32 MiB, say) lands on a different wave every round instead of piling up on a few.
+   const uint64_t nspans = (a.ngroups + gps - 1) / gps;
+   for (uint64_t round = 0; round * nwaves < nspans; round++) {
+      const uint64_t span = round * nwaves + (wave + round * 2731) % nwaves;
+      if (span >= nspans) {
+         continue;
+      }
+      const uint64_t g0 = span * gps;
       const uint64_t g1 = g0 + gps < a.ngroups ? g0 + gps : a.ngroups;
       uint32_t carry = g0 ? rom1[g0 * 1024 - 1] : 0u;          // dword in front of the span (wave uniform)
       uint4 w[DEPTH + 1][4];
@@ -346,6 +389,7 @@ __global__ __launch_bounds__(256) void mm_filter_u8(MmFilterArgs a)
          w[d][0] = p[0]; w[d][1] = p[64]; w[d][2] = p[128]; w[d][3] = p[192];
       }
       for (uint64_t g = g0; g < g1; g += DEPTH + 1) {
+         uint32_t pending = 0;                                  // bit 4*s + u: piece u of group g+s has stage-1 hits
 #pragma unroll
          for (int s = 0; s <= DEPTH; s++) {
             // ring slot s holds group g+s; refill the slot that is DEPTH groups ahead
@@ -355,24 +399,30 @@ __global__ __launch_bounds__(256) void mm_filter_u8(MmFilterArgs a)
             const uint4 *pn = rom4 + gn * 256 + lane;
             w[slot_new][0] = pn[0]; w[slot_new][1] = pn[64]; w[slot_new][2] = pn[128]; w[slot_new][3] = pn[192];
             if (g + s < g1) {
-               uint32_t h[4][4];
-               uint32_t any = 0;
 #pragma unroll
                for (int u = 0; u < 4; u++) {
                   // last dword of the previous 16 bytes: lane l-1's w.w; lane 0 keeps c
                   const uint32_t c = u == 0 ? carry : __builtin_amdgcn_readlane(w[s][u - 1].w, 63);
                   const uint32_t back = __builtin_amdgcn_update_dpp(c, w[s][u].w, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-                  any |= mm_f8_chunk<SHAPE>(w[s][u], back, a.pat, a.sh, h[u]);
+                  const uint32_t any = mm_f8_chunk_any<SHAPE>(w[s][u], back, a.pat, a.sh);
+                  pending |= __ballot(any != 0) != 0 ? 1u << (4 * s + u) : 0u;
                }
                carry = __builtin_amdgcn_readlane(w[s][3].w, 63);
-               if (__ballot(any != 0) != 0) {
-                  // rare: kept as one loop per piece so that the hot loop stays small
-#pragma unroll 1
-                  for (int u = 0; u < 4; u++) {
-                     const uint32_t bits = u == 0 ? mm_f8_pack(h[0]) : (u == 1 ? mm_f8_pack(h[1]) : (u == 2 ? mm_f8_pack(h[2]) : mm_f8_pack(h[3])));
-                     mm_f8_survivors(a, (g + s) * 4096 + (uint64_t)u * 1024 + lane * 16, bits);
-                  }
-               }
+            }
+         }
+         // Rare (~1.6 % of the pieces on random bytes): all conditions on the flagged pieces.  One
+         // rolled copy for the whole ring, working from a re-read of the piece (an L2 hit) rather
+         // than from the ring registers: indexing those with a run-time piece number would move the
+         // ring to scratch memory, and unrolling the survivor code 12 times costs 25 VGPRs.
+         while (pending) {
+            const uint32_t bit = (uint32_t)__builtin_ctz(pending);
+            pending &= pending - 1;
+            const uint64_t byte0 = (g + (bit >> 2)) * 4096 + (uint64_t)(bit & 3) * 1024 + lane * 16;
+            const uint4 wu = *reinterpret_cast<const uint4 *>(a.g.rom + byte0);
+            const uint32_t back = byte0 ? *reinterpret_cast<const uint32_t *>(a.g.rom + byte0 - 4) : 0u;
+            uint32_t h[4];
+            if (__ballot(mm_f8_chunk<SHAPE>(wu, back, a.pat, a.sh, h) != 0) != 0) {
+               mm_f8_survivors(a, byte0, mm_f8_pack(h));
             }
          }
       }
@@ -454,6 +504,33 @@ __device__ __forceinline__ uint32_t mm_f16_chunk(const uint32_t (&r)[7], bool be
    return any;
 }
 
+// Stage 1 of the 16-bit streaming loop: condition 0 only (2^-16 of random positions pass, so
+// some lane of a wave sees a hit in ~1.6 % of its 1 KiB pieces); mm_f16_chunk runs on those.
+#define MM_F16_STAGE1(shape) (((shape) & 0x10) | 1)
+
+// non-zero when some position of the chunk (either byte alignment) passes condition 0
+template <int SHAPE>
+__device__ __forceinline__ uint32_t mm_f16_chunk_any(const uint32_t (&r)[7], bool be, const uint32_t (&pat)[4])
+{
+   constexpr bool G0 = MM_F16_G0(SHAPE) != 0;
+   // gap 1 needs the element one place (2 bytes) back, gap 2 the one a whole dword back
+   uint32_t ev[7], od[7];
+#pragma unroll
+   for (int k = 2; k < 7; k++) {
+      ev[k] = be ? mm_bswap16x2(r[k]) : r[k];
+      const uint32_t o = mm_alignbit(r[k], r[k - 1], 24);
+      od[k] = be ? mm_bswap16x2(o) : o;
+   }
+   uint32_t acc = 0;
+#pragma unroll
+   for (int k = 3; k < 7; k++) {
+      const uint32_t ze = mm_sub16x2(ev[k], G0 ? ev[k - 1] : mm_alignbit(ev[k], ev[k - 1], 16)) ^ pat[0];
+      const uint32_t zo = mm_sub16x2(od[k], G0 ? od[k - 1] : mm_alignbit(od[k], od[k - 1], 16)) ^ pat[0];
+      acc |= ((ze - 0x00010001u) & ~ze) | ((zo - 0x00010001u) & ~zo);
+   }
+   return acc & 0x80008000u;
+}
+
 // 16 flags of a chunk: bit 4*j + 2*odd + half
 __device__ __forceinline__ uint32_t mm_f16_pack(const uint32_t (&he)[4], const uint32_t (&ho)[4])
 {
@@ -528,7 +605,16 @@ __global__ __launch_bounds__(256) void mm_filter_u16(MmFilterArgs a)
    const uint4 *rom4 = reinterpret_cast<const uint4 *>(a.g.rom);
    const uint32_t *rom1 = reinterpret_cast<const uint32_t *>(a.g.rom);
 
-   for (uint64_t g0 = wave * gps; g0 < a.ngroups; g0 += nwaves * gps) {
+   // Round i hands span i*nwaves + ((wave + 2731 i) mod nwaves) to this wave: neighbouring waves
+   // still stream neighbouring spans, but anything periodic in the ROM (candidates at every
+   // 32 MiB, say) lands on a different wave every round instead of piling up on a few.
+   const uint64_t nspans = (a.ngroups + gps - 1) / gps;
+   for (uint64_t round = 0; round * nwaves < nspans; round++) {
+      const uint64_t span = round * nwaves + (wave + round * 2731) % nwaves;
+      if (span >= nspans) {
+         continue;
+      }
+      const uint64_t g0 = span * gps;
       const uint64_t g1 = g0 + gps < a.ngroups ? g0 + gps : a.ngroups;
       // the three dwords in front of the span (wave uniform)
       uint32_t c1 = 0, c2 = 0, c3 = 0;
@@ -543,6 +629,7 @@ __global__ __launch_bounds__(256) void mm_filter_u16(MmFilterArgs a)
          w[d][0] = p[0]; w[d][1] = p[64]; w[d][2] = p[128]; w[d][3] = p[192];
       }
       for (uint64_t g = g0; g < g1; g += DEPTH + 1) {
+         uint32_t pending = 0;                                  // bit 4*s + u: piece u of group g+s has stage-1 hits
 #pragma unroll
          for (int s = 0; s <= DEPTH; s++) {
             constexpr int RING = DEPTH + 1;
@@ -551,8 +638,6 @@ __global__ __launch_bounds__(256) void mm_filter_u16(MmFilterArgs a)
             const uint4 *pn = rom4 + gn * 256 + lane;
             w[slot_new][0] = pn[0]; w[slot_new][1] = pn[64]; w[slot_new][2] = pn[128]; w[slot_new][3] = pn[192];
             if (g + s < g1) {
-               uint32_t he[4][4], ho[4][4];
-               uint32_t any = 0;
 #pragma unroll
                for (int u = 0; u < 4; u++) {
                   // dwords -3..-1 of this chunk: lane l-1's y, z, w; lane 0 keeps the carries
@@ -564,20 +649,27 @@ __global__ __launch_bounds__(256) void mm_filter_u16(MmFilterArgs a)
                   r[1] = __builtin_amdgcn_update_dpp(k2, w[s][u].z, 0x138, 0xf, 0xf, false);
                   r[2] = __builtin_amdgcn_update_dpp(k3, w[s][u].w, 0x138, 0xf, 0xf, false);
                   r[3] = w[s][u].x; r[4] = w[s][u].y; r[5] = w[s][u].z; r[6] = w[s][u].w;
-                  any |= mm_f16_chunk<SHAPE>(r, be, a.pat, he[u], ho[u]);
+                  const uint32_t any = mm_f16_chunk_any<SHAPE>(r, be, a.pat);
+                  pending |= __ballot(any != 0) != 0 ? 1u << (4 * s + u) : 0u;
                }
                c1 = __builtin_amdgcn_readlane(w[s][3].y, 63);
                c2 = __builtin_amdgcn_readlane(w[s][3].z, 63);
                c3 = __builtin_amdgcn_readlane(w[s][3].w, 63);
-               if (__ballot(any != 0) != 0) {
-#pragma unroll 1
-                  for (int u = 0; u < 4; u++) {
-                     const uint32_t bits = u == 0 ? mm_f16_pack(he[0], ho[0])
-                                                  : (u == 1 ? mm_f16_pack(he[1], ho[1])
-                                                            : (u == 2 ? mm_f16_pack(he[2], ho[2]) : mm_f16_pack(he[3], ho[3])));
-                     mm_f16_survivors(a, (g + s) * 4096 + (uint64_t)u * 1024 + lane * 16, bits);
-                  }
-               }
+            }
+         }
+         // rare: all conditions on the flagged pieces, from a re-read (see mm_filter_u8)
+         while (pending) {
+            const uint32_t bit = (uint32_t)__builtin_ctz(pending);
+            pending &= pending - 1;
+            const uint64_t c = (g + (bit >> 2)) * 256 + (uint64_t)(bit & 3) * 64 + lane;     // 16-byte chunk number
+            const uint4 wu = rom4[c];
+            uint32_t r[7] = {0, 0, 0, wu.x, wu.y, wu.z, wu.w};
+            if (c) {
+               r[0] = rom1[c * 4 - 3]; r[1] = rom1[c * 4 - 2]; r[2] = rom1[c * 4 - 1];
+            }
+            uint32_t he[4], ho[4];
+            if (__ballot(mm_f16_chunk<SHAPE>(r, be, a.pat, he, ho) != 0) != 0) {
+               mm_f16_survivors(a, c * 16, mm_f16_pack(he, ho));
             }
          }
       }
@@ -814,7 +906,10 @@ bool choose_filter(const mmh_plan_desc &pl, FilterChoice *fc)
       const int g = -(int)pl.bridge[i];
       return (g == 1 || g == 2) && i - g >= 0 ? g : 0;
    };
-   const int want = u8 ? 4 : 2;
+   int want = u8 ? 4 : 2;
+   if (const char *knob = getenv("MMOORE_FILTER_MAXCOND")) {      // tuning / experiments only
+      want = std::max(1, std::min(want, atoi(knob)));
+   }
    FilterChoice best;
    best.ncond = 0;
    bool best_contiguous = false;
@@ -895,14 +990,36 @@ bool filter_verifies(const mmh_plan_desc &pl, const FilterChoice &fc)
    return !((pl.elem_bytes == 1 && fc.ncond >= 3) || (pl.elem_bytes == 2 && fc.ncond == 2));
 }
 
+// Launch geometry of the span kernels: 8 workgroups (32 waves) per CU fill the chip with the
+// kernels' <= 64 VGPRs; a wave streams spans of 8 groups = 32 KiB.  Measured on 4 GiB (u8):
+// spans of 4 / 8 / 16 / 32 groups -> 0.732 / 0.695 / 0.711 / 0.712 ms; 1024 .. 4096 workgroups
+// are within 0.5 % of each other.  The environment knobs are for such experiments only.
+static uint64_t filter_max_blocks()
+{
+   static const uint64_t v = [] {
+      const char *knob = getenv("MMOORE_FILTER_BLOCKS");
+      return knob ? (uint64_t)std::max(1, atoi(knob)) : (uint64_t)256 * 8;
+   }();
+   return v;
+}
+
+static uint32_t filter_groups_per_span()
+{
+   static const uint32_t v = [] {
+      const char *knob = getenv("MMOORE_FILTER_GPS");
+      return knob ? (uint32_t)std::max(1, atoi(knob)) : 8u;
+   }();
+   return v;
+}
+
 template <int SHAPE>
 static void launch_filter_u8(hipStream_t st, const MmFilterArgs &a, const MmGeom &g)
 {
    if (a.ngroups) {
       uint64_t spans = (a.ngroups + a.groups_per_span - 1) / a.groups_per_span;
       uint64_t blocks = (spans + 3) / 4;
-      if (blocks > 256 * 8) {
-         blocks = 256 * 8;
+      if (blocks > filter_max_blocks()) {
+         blocks = filter_max_blocks();
       }
       hipLaunchKernelGGL(mm_filter_u8<SHAPE>, dim3((unsigned)blocks), dim3(256), 0, st, a);
    }
@@ -917,8 +1034,8 @@ static void launch_filter_u16(hipStream_t st, const MmFilterArgs &a, const MmGeo
    if (a.ngroups) {
       uint64_t spans = (a.ngroups + a.groups_per_span - 1) / a.groups_per_span;
       uint64_t blocks = (spans + 3) / 4;
-      if (blocks > 256 * 8) {
-         blocks = 256 * 8;
+      if (blocks > filter_max_blocks()) {
+         blocks = filter_max_blocks();
       }
       hipLaunchKernelGGL(mm_filter_u16<SHAPE>, dim3((unsigned)blocks), dim3(256), 0, st, a);
    }
@@ -948,7 +1065,7 @@ void launch_filter(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, con
    a.cand = cand; a.list_count = ctrl + MM_CTRL_LISTS; a.list_cap = cand_cap / MM_CAND_LISTS;
    // whole 4 KiB groups go to the span kernel, the ragged end to the bounds-checked one
    a.ngroups = g.nbytes / 4096;
-   a.groups_per_span = 16;
+   a.groups_per_span = filter_groups_per_span();
    a.edge_first = a.ngroups * 256;
    const uint32_t shape = fc.shape;
    if (pl.elem_bytes == 1) {
