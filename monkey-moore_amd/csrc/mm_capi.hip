@@ -66,6 +66,10 @@ int ensure_workspace(mmh_ctx *c, uint64_t out_cap)
       c->cand_cap = kInitialCap;
       HIP_TRY(hipMalloc(&c->d_cand, c->cand_cap * sizeof(uint64_t)));
       HIP_TRY(hipMalloc(&c->d_ctrl, mm::ctrl_bytes()));
+      HIP_TRY(hipMalloc(&c->d_mid_off, mm::mid_cap() * sizeof(uint64_t)));
+      HIP_TRY(hipMalloc(&c->d_mid_hi, mm::mid_cap() * sizeof(uint64_t)));
+      HIP_TRY(hipMalloc(&c->d_mid_set, mm::mid_cap() * sizeof(uint32_t)));
+      HIP_TRY(hipMalloc(&c->d_mid_slot, mm::mid_cap() * sizeof(uint32_t)));
       HIP_TRY(hipMalloc(&c->d_hard_off, mm::hard_cap() * sizeof(uint64_t)));
       HIP_TRY(hipMalloc(&c->d_hard_hi, mm::hard_cap() * sizeof(uint64_t)));
       HIP_TRY(hipMalloc(&c->d_hard_set, mm::hard_cap() * sizeof(uint32_t)));
@@ -176,6 +180,10 @@ extern "C" void mmh_destroy(mmh_ctx *c)
    if (c->d_cand) (void)hipFree(c->d_cand);
    if (c->d_out) (void)hipFree(c->d_out);
    if (c->d_ctrl) (void)hipFree(c->d_ctrl);
+   if (c->d_mid_off) (void)hipFree(c->d_mid_off);
+   if (c->d_mid_hi) (void)hipFree(c->d_mid_hi);
+   if (c->d_mid_set) (void)hipFree(c->d_mid_set);
+   if (c->d_mid_slot) (void)hipFree(c->d_mid_slot);
    if (c->d_hard_off) (void)hipFree(c->d_hard_off);
    if (c->d_hard_hi) (void)hipFree(c->d_hard_hi);
    if (c->d_hard_set) (void)hipFree(c->d_hard_set);
@@ -345,6 +353,7 @@ int run_pipeline(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, const mm:
    hipStream_t st = c->stream;
    mm::ResolveBuffers rb;
    rb.cand = c->d_cand; rb.cand_cap = c->cand_cap; rb.out = c->d_out; rb.out_cap = c->out_cap; rb.ctrl = c->d_ctrl;
+   rb.mid_off = c->d_mid_off; rb.mid_hi = c->d_mid_hi; rb.mid_set = c->d_mid_set; rb.mid_slot = c->d_mid_slot;
    rb.hard_off = c->d_hard_off; rb.hard_hi = c->d_hard_hi; rb.hard_set = c->d_hard_set; rb.hard_slot = c->d_hard_slot;
    rb.scratch = c->d_scratch;
    const int count_index = sequential ? 1 : 0;
@@ -378,7 +387,8 @@ int run_pipeline(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, const mm:
    oc->listed = c->h_result[count_index];
    oc->tiles = c->h_result[2];
    oc->hard = (uint32_t)(c->h_result[3] & 0xFFFFFFFFu);
-   oc->hard_overflow = (c->h_result[3] >> 32) != 0;
+   // left-overs beyond what mm_resolve2 / mm_hard_resolve take, or a prefix too long for the latter
+   oc->hard_overflow = (c->h_result[3] >> 32) != 0 || (c->h_result[5] & 0xFFFFFFFFu) > mm::mid_cap();
    oc->sorted_on_device = oc->listed <= kMaxRankSort && oc->listed <= c->out_cap;
    oc->matches = c->h_result[6] ? c->h_result[6] - 1 : oc->listed;
    c->ctrl_clean = true;                        // mm_rank_scatter's last block re-zeroed it

@@ -33,6 +33,10 @@ struct mmh_ctx {
    uint64_t *d_out = nullptr;       // unordered matches
    uint64_t out_cap = 0;
    unsigned long long *d_ctrl = nullptr;   // counters + arrival tickets, zeroed per scan (mm::ResolveBuffers)
+   uint64_t *d_mid_off = nullptr;   // hand-over list mm_resolve -> mm_resolve2
+   uint64_t *d_mid_hi = nullptr;
+   uint32_t *d_mid_set = nullptr;
+   uint32_t *d_mid_slot = nullptr;
    uint64_t *d_hard_off = nullptr;
    uint64_t *d_hard_hi = nullptr;
    uint32_t *d_hard_set = nullptr;

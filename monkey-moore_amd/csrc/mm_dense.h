@@ -13,11 +13,12 @@
 //                    of each super-tile
 //   mm_dense_tiles   per super-tile: walk its tile maps from that phase -> entry phase of
 //                    every tile
-//   mm_dense_emit    every tile again, now with its TRUE entry phase: the scalar unit
-//                    tracks the one live phase through the exceptional positions and hands
-//                    each group of 64 positions its phase; lane t then walks group t
-//                    (a handful of jumps) and collects the visited positions where the
-//                    compare loop matched.  One atomic per tile reserves the output range.
+//   mm_dense_emit    every tile again, now with its TRUE entry phase: jumps and match flags
+//                    of all positions in parallel (mm_tile_jumps), then one lane follows the
+//                    one real chain through them and notes the visited positions where the
+//                    compare loop matched (a tile is npos / mean-jump dependent LDS reads; the
+//                    other waves of the SIMD hide that latency).  One atomic per tile reserves
+//                    the output range, all lanes copy the finds out.
 #ifndef MM_DENSE_H
 #define MM_DENSE_H
 
@@ -46,10 +47,8 @@ __device__ __forceinline__ void mm_dense_domain(const MmDenseArgs &a, uint64_t d
    *nv = mm_domain_nv(a.t.g, b, p);
 }
 
-template <int BITS>
 __device__ __forceinline__ void mm_dense_maps_body(const MmDenseArgs &a, const MmPlanLds &P, MmWaveLds &W)
 {
-   const int D = (int)a.t.plan.L - 1;
    const int wave = (int)mm_uniform(threadIdx.x >> 6);
    const int lane = threadIdx.x & 63;
    const uint64_t ntiles = a.ndom * a.tpd;
@@ -59,14 +58,13 @@ __device__ __forceinline__ void mm_dense_maps_body(const MmDenseArgs &a, const M
       const int64_t lo = (int64_t)(item % a.tpd) * MM_TILE;
       uint64_t start; int64_t nv;
       mm_dense_domain(a, dom, &start, &nv);
-      MmPhaseMap<BITS> M;
-      M.identity();
+      uint32_t map = (uint32_t)lane;                      // tiles past the domain's end: identity
       if (lo < nv) {
          const int npos = (int)(nv - lo < MM_TILE ? nv - lo : MM_TILE);
-         mm_tile_map<BITS>(a.t, P, W, start, lo, npos, (uint32_t)(lo % D), lane, M);
+         map = mm_tile_map(a.t, P, W, start, lo, npos, mm_modd64(a.t, (uint64_t)lo), lane);
       }
       if (lane < MM_MAXD) {
-         a.maps[item * MM_MAXD + lane] = (uint8_t)M.get(lane);
+         a.maps[item * MM_MAXD + lane] = (uint8_t)map;
       }
    }
 }
@@ -76,12 +74,7 @@ __global__ __launch_bounds__(64 * MM_WAVES) void mm_dense_maps(MmDenseArgs a)
    __shared__ MmPlanLds P;
    __shared__ MmWaveLds Wv[MM_WAVES];
    mm_plan_to_lds(P, a.t.plan);
-   if (a.t.plan.L - 1 <= 16) {
-      mm_dense_maps_body<4>(a, P, Wv[threadIdx.x >> 6]);
-   }
-   else {
-      mm_dense_maps_body<8>(a, P, Wv[threadIdx.x >> 6]);
-   }
+   mm_dense_maps_body(a, P, Wv[threadIdx.x >> 6]);
 }
 
 // one workgroup (one wave) per super-tile.  MODE 0: compose the tile maps -> supmaps.
@@ -151,28 +144,20 @@ __global__ __launch_bounds__(64) void mm_dense_entries(MmDenseArgs a)
    }
 }
 
-struct MmEmitLds {
-   uint8_t jbuf[MM_TILE];                     // J of exceptional positions
-   uint16_t found[64][64];                    // per lane: tile positions of its group's matches
-};
-
 __global__ __launch_bounds__(64 * MM_WAVES) void mm_dense_emit(MmDenseArgs a)
 {
    __shared__ MmPlanLds P;
    __shared__ MmWaveLds Wv[MM_WAVES];
-   __shared__ MmEmitLds Ev[MM_WAVES];
    mm_plan_to_lds(P, a.t.plan);
 
-   const int L = (int)a.t.plan.L, S = (int)a.t.g.S;
-   const uint32_t D = (uint32_t)(L - 1);
-   const bool be = a.t.g.big_endian != 0;
+   const uint32_t D = a.t.plan.L - 1;
    const int wave = (int)mm_uniform(threadIdx.x >> 6);
    const int lane = threadIdx.x & 63;
    MmWaveLds &W = Wv[wave];
-   MmEmitLds &E = Ev[wave];
-   const int e1 = a.t.plan.expected[L - 1], b1 = a.t.plan.bridge[L - 1], w1 = a.t.plan.wst[L - 1];
-   const uint32_t m1 = a.t.plan.cmp_mask[L - 1];
-   const int match_jump = (int)a.t.plan.match_jump;
+   // tile positions of the matches on the chain, ascending: they overwrite the staged bytes,
+   // which nobody needs once the jumps are known
+   static_assert(sizeof(W.tile) >= MM_TILE * sizeof(uint16_t), "found[] must fit the tile buffer");
+   uint16_t *found = reinterpret_cast<uint16_t *>(W.tile);
    const uint64_t ntiles = a.ndom * a.tpd;
    const uint64_t nwaves = (uint64_t)gridDim.x * MM_WAVES;
    const uint32_t list = blockIdx.x & (MM_CAND_LISTS - 1);
@@ -186,108 +171,36 @@ __global__ __launch_bounds__(64 * MM_WAVES) void mm_dense_emit(MmDenseArgs a)
          continue;
       }
       const int npos = (int)(nv - lo < MM_TILE ? nv - lo : MM_TILE);
-      const int mis = mm_stage_tile(a.t, W, start, lo, npos, lane);
-      mm_wave_sync();
-      const uint8_t *tile = reinterpret_cast<const uint8_t *>(W.tile) + mis;
+      mm_tile_jumps(a.t, P, W, mm_uniform64(start), lo, npos, lane);
 
-      // jumps + match flags of every position; the live phase through the exceptions
-      uint32_t cur = a.entry[item];                       // phase of the next visited position
-      uint32_t ph0 = mm_modd(a.t, (uint32_t)(lo % D));    // phase of position 64t
-      uint32_t my_phase = 0;                              // lane t: live phase at the start of group t
-      unsigned long long my_exc = 0, my_match = 0;
-      const int nballots = (npos + 63) >> 6;
-      for (int t = 0; t < nballots; t++) {
-         const int q = 64 * t + lane;
-         int J = (int)D;
-         bool mt = false;
-         if (q < npos) {
-            const int c = mm_tile_elem(tile, q + L - 1, S, be);
-            const int pv = mm_tile_elem(tile, q + L - 1 + b1, S, be);
-            const int d = c - pv;
-            if (((uint32_t)(d ^ e1) & m1) != 0) {
-               const int s = mm_tile_skip(a.t, P, d);
-               J = s < w1 ? s : w1;
-            }
-            else {
-               J = match_jump;
-               mt = true;
-               for (int i = L - 2; i >= 0; --i) {
-                  const int ci = mm_tile_elem(tile, q + i, S, be);
-                  const int pi = mm_tile_elem(tile, q + i + P.bridge[i], S, be);
-                  const int di = ci - pi;
-                  if (((uint32_t)(di ^ P.expected[i]) & P.cmp_mask[i]) != 0) {
-                     const int s = mm_tile_skip(a.t, P, di);
-                     const int w = P.wst[i];
-                     J = s < w ? s : w;
-                     mt = false;
-                     break;
-                  }
-               }
-            }
-         }
-         const bool exc = J != (int)D;
-         if (exc) {
-            E.jbuf[q] = (uint8_t)J;
-         }
-         const unsigned long long em = __ballot(exc);
-         const unsigned long long mm = __ballot(mt);
-         if (lane == t) {
-            my_exc = em;
-            my_match = mm;
-            my_phase = cur;
-         }
-         // only the exceptions the live chain actually stands on move it
-         unsigned long long mask = em;
-         while (mask) {
-            const int bit = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            const uint32_t r = mm_modd(a.t, ph0 + (uint32_t)bit);
-            if (r == cur) {
-               const uint32_t Jb = (uint32_t)__builtin_amdgcn_readlane(J, bit);
-               uint32_t r2 = r + Jb;
-               cur = r2 >= D ? r2 - D : r2;
-            }
-         }
-         ph0 = mm_modd(a.t, ph0 + 64u);
-      }
-      mm_wave_sync();
-
-      // lane t walks group t from the first position in phase my_phase
+      // the one real chain: it enters the tile at the first position in phase entry[item]
       int nfound = 0;
-      if (lane < nballots) {
-         const uint32_t g_phase = mm_modd(a.t, mm_modd(a.t, (uint32_t)lane) * mm_modd(a.t, 64u) + (uint32_t)(lo % D));
-         uint32_t off = my_phase + D - g_phase;           // (my_phase - g_phase) mod D
-         off = off >= D ? off - D : off;
-         int pos = 64 * lane + (int)off;
-         const int end = 64 * lane + 64 < npos ? 64 * lane + 64 : npos;
-         while (pos < end) {
-            const int bit = pos & 63;
-            if ((my_match >> bit) & 1) {
-               E.found[lane][nfound++] = (uint16_t)pos;
+      if (lane == 0) {
+         const uint32_t lo_mod = mm_modd64(a.t, (uint64_t)lo);
+         uint32_t p = (uint32_t)a.entry[item] + D - lo_mod;
+         p = p >= D ? p - D : p;
+         while (p < (uint32_t)npos) {
+            const uint32_t j = W.jump[p];
+            if (j & MM_JUMP_MATCH) {
+               found[nfound++] = (uint16_t)p;
             }
-            pos += ((my_exc >> bit) & 1) ? E.jbuf[pos] : (int)D;
+            p += j & (MM_JUMP_MATCH - 1);
          }
       }
-      // one atomic per tile reserves the output range; lanes write their finds in order
-      int incl = nfound;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-         const int v = __shfl_up(incl, d);
-         incl += lane >= d ? v : 0;
-      }
-      const int total = __shfl(incl, 63);
-      if (total) {
+      nfound = (int)mm_uniform((uint32_t)nfound);
+      mm_wave_sync();
+      if (nfound) {
+         // one atomic per tile reserves the output range
          unsigned long long base = 0;
          if (lane == 0) {
-            base = atomicAdd(a.list_count + list * MM_LIST_STRIDE, (unsigned long long)total);
+            base = atomicAdd(a.list_count + list * MM_LIST_STRIDE, (unsigned long long)nfound);
          }
-         base = __shfl(base, 0) + (unsigned long long)(incl - nfound);
-         for (int k = 0; k < nfound; k++) {
-            const unsigned long long slot = base + k;
+         base = __shfl(base, 0);
+         for (int k = lane; k < nfound; k += 64) {
+            const unsigned long long slot = base + (unsigned long long)k;
             if (slot < a.list_cap) {
-               const uint64_t j = (uint64_t)lo + E.found[lane][k];
-               a.out[(uint64_t)list * a.list_cap + slot] =
-                  a.t.g.whole ? j : start + j * a.t.g.S + a.base_offset;
+               const uint64_t j = (uint64_t)lo + found[k];
+               a.out[(uint64_t)list * a.list_cap + slot] = a.t.g.whole ? j : start + j * a.t.g.S + a.base_offset;
             }
          }
       }

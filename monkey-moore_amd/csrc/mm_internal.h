@@ -44,6 +44,7 @@ struct MmGeom {
 enum {
    MM_CTRL_TOTAL = 0,        // candidates over all lists (written by mm_resolve; ~0 = a list overflowed)
    MM_CTRL_APPENDED = 1,     // matches appended by mm_chain_seq
+   MM_CTRL_MID = 2,          // lo 32: candidates handed from mm_resolve to mm_resolve2
    MM_CTRL_HARD = 3,         // lo 32: hard candidates, hi 32: "prefix too long" flag
    MM_CTRL_TICKET = 4,       // arrival ticket of mm_rank_scatter's blocks (the last one re-zeroes the block)
    MM_CTRL_TILES = 8,        // MM_STAT_STRIPES striped counters of tiles walked

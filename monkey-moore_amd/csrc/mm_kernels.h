@@ -35,7 +35,11 @@ struct ResolveBuffers {
    uint64_t *out;
    uint64_t out_cap;
    unsigned long long *ctrl;
-   uint64_t *hard_off;
+   uint64_t *mid_off;        // [mid_cap()] hand-over list mm_resolve -> mm_resolve2
+   uint64_t *mid_hi;
+   uint32_t *mid_set;
+   uint32_t *mid_slot;
+   uint64_t *hard_off;       // [hard_cap()] hand-over list mm_resolve2 -> mm_hard_resolve
    uint64_t *hard_hi;
    uint32_t *hard_set;
    uint32_t *hard_slot;
@@ -46,6 +50,7 @@ void launch_resolve(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, co
                     uint64_t base_offset, uint32_t max_candidates);
 size_t hard_scratch_bytes();
 size_t hard_cap();
+size_t mid_cap();
 size_t ctrl_bytes();
 size_t rank_partials_bytes(uint32_t max_n);
 // the candidate-free forward engine (mm_dense.h): sizes and buffers

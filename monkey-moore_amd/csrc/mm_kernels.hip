@@ -792,6 +792,9 @@ __global__ __launch_bounds__(256) void mm_rank_scatter(const uint64_t *in, unsig
             v += ctrl[MM_CTRL_TILES + k];
          }
       }
+      if (threadIdx.x == 5) {
+         v = ctrl[MM_CTRL_MID];                            // word 2 of the header carries the tile count
+      }
       host_result[threadIdx.x] = v;
    }
    if (n64 <= cap && n64 <= max_n) {
@@ -1108,6 +1111,11 @@ static MmTileArgs tile_args(const MmGeom &g, const mmh_plan_desc &pl)
    t.g = g; t.plan = pl;
    const uint32_t D = pl.L - 1;
    t.inv_d = (65536u + D - 1) / D;
+   t.inv_d32 = (uint32_t)((1ull << 32) / D) + 1u;
+   t.block_shift = ~0u;
+   if (g.block_bytes && (g.block_bytes & (g.block_bytes - 1)) == 0) {
+      t.block_shift = (uint32_t)__builtin_ctzll(g.block_bytes);
+   }
    t.skip_bloom = 0;
    for (uint32_t k = 0; k < pl.n_skip; k++) {
       t.skip_bloom |= 1ull << ((uint32_t)pl.skip_diff[k] & 63);
@@ -1124,9 +1132,22 @@ void launch_resolve(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, co
    a.total_out = rb.ctrl + MM_CTRL_TOTAL;
    a.out = rb.out; a.out_cap = rb.out_cap; a.tiles_walked = rb.ctrl + MM_CTRL_TILES;
    a.base_offset = base_offset; a.max_candidates = max_candidates;
-   a.hard_off = rb.hard_off; a.hard_hi = rb.hard_hi; a.hard_set = rb.hard_set; a.hard_slot = rb.hard_slot;
-   a.hard_count = reinterpret_cast<unsigned int *>(rb.ctrl + MM_CTRL_HARD);
-   hipLaunchKernelGGL(mm_resolve, dim3(4096), dim3(64 * MM_WAVES), 0, st, a);
+   a.mid_off = rb.mid_off; a.mid_hi = rb.mid_hi; a.mid_set = rb.mid_set; a.mid_slot = rb.mid_slot;
+   a.mid_count = reinterpret_cast<unsigned int *>(rb.ctrl + MM_CTRL_MID);
+   static const unsigned resolve_blocks = [] {
+      const char *knob = getenv("MMOORE_RESOLVE_BLOCKS");      // experiments only
+      return knob ? (unsigned)std::max(1, atoi(knob)) : 4096u;
+   }();
+   hipLaunchKernelGGL(mm_resolve, dim3(resolve_blocks), dim3(64 * MM_WAVES), 0, st, a);
+
+   MmResolve2Args m;
+   m.t = a.t;
+   m.mid_off = rb.mid_off; m.mid_hi = rb.mid_hi; m.mid_set = rb.mid_set; m.mid_slot = rb.mid_slot;
+   m.mid_count = a.mid_count;
+   m.out = rb.out; m.tiles_walked = rb.ctrl + MM_CTRL_TILES; m.base_offset = base_offset;
+   m.hard_off = rb.hard_off; m.hard_hi = rb.hard_hi; m.hard_set = rb.hard_set; m.hard_slot = rb.hard_slot;
+   m.hard_count = reinterpret_cast<unsigned int *>(rb.ctrl + MM_CTRL_HARD);
+   hipLaunchKernelGGL(mm_resolve2, dim3(256), dim3(64 * MM_WAVES), 0, st, m);
 
    MmHardArgs h;
    h.t = a.t;
@@ -1142,6 +1163,7 @@ void launch_resolve(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, co
 
 size_t hard_scratch_bytes() { return (size_t)MM_HARD_CAP * MM_HARD_MAX_TILES * MM_MAXD; }
 size_t hard_cap() { return MM_HARD_CAP; }
+size_t mid_cap() { return MM_MID_CAP; }
 size_t ctrl_bytes() { return MM_CTRL_DONE * sizeof(uint64_t) + MM_HARD_CAP * sizeof(unsigned int); }
 size_t rank_partials_bytes(uint32_t max_n) { return (size_t)MM_RANK_SLICES * max_n * sizeof(uint32_t); }
 

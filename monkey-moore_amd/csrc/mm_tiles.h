@@ -3,49 +3,61 @@
 //
 // Chain state = the next position the reference will visit.  Every jump is in
 // [1, D] with D = L-1, so at any boundary a the next visited position lies in
-// [a, a+D) and is identified by its PHASE (position mod D).  Processing position
-// j moves "phase j mod D" to "phase (j + J(j)) mod D" and leaves the others
-// alone; a jump of exactly D changes nothing ("exceptional" positions are the
-// ones with J != D: ~L/256 of them on random bytes).  The effect of a run of
-// positions is a map Z_D -> Z_D; maps of adjacent runs compose.
+// [a, a+D) and is identified by its PHASE (position mod D).  The effect of a run
+// of positions is a map Z_D -> Z_D (entry phase -> exit phase); maps of adjacent
+// runs compose.
 //
-// One wavefront turns a tile of MM_TILE positions into its map (mm_tile_map):
-//   1. coalesced copy of the tile's bytes into LDS, all loads in flight at once;
+// One wavefront turns a window of up to MM_TILE positions into its map (mm_tile_map):
+//   1. coalesced copy of the window's bytes into LDS, all loads in flight at once;
 //   2. position-parallel: iteration t, lane l runs the reference's compare loop
 //      at position 64t+l (consecutive lanes read consecutive LDS bytes:
-//      conflict-free).  The first compare, which settles all but ~1/256 of the
-//      positions, runs straight-line from wave-uniform registers;
-//   3. the ballot of the exceptional lanes is walked IN POSITION ORDER on the
-//      scalar unit: the map lives in SGPRs as packed 4-bit (D <= 16) or 8-bit
-//      phases and "every entry equal to r becomes r2" is a handful of SWAR
-//      scalar instructions.  No per-lane maps, no composition pass.
+//      conflict-free) and stores the jump J of its position in LDS.  The first
+//      compare, which settles all but ~1/256 of the positions, runs straight-line
+//      from wave-uniform registers;
+//   3. phase-parallel: lane e < D starts at the first position in phase e and
+//      follows the chain through the stored jumps, p += J[p], until it leaves the
+//      window; where it lands is the map's value for e.  npos / (mean jump) dependent
+//      LDS reads -- ~25 for a 256-position window of ordinary data -- whatever the
+//      pattern: walking the exceptional positions (J != D) one by one on the scalar
+//      unit instead costs ~40 scalar instructions each, which was fine for plain
+//      keywords (4 % exceptional) and 3-10x slower for wildcard patterns, whose
+//      capped skips make nearly every position exceptional.
+// The map lives in a VGPR (lane e holds map[e]); pulling a phase SET back through it
+// is one ballot:  A' = { e : map[e] in A } = ballot(lane < D && (A >> map) & 1).
 //
 // Users:
 //   mm_resolve        (one wave per filter candidate) keeps the set A of phases
-//                     that lead to visiting the candidate and pulls it back tile
-//                     by tile, A' = {e : map(e) in A}: empty -> not on the chain,
-//                     everything -> on the chain however the chain entered,
-//                     domain start -> the chain starts in phase 0
-//                     (monkey_moore.cpp:329).  Bounded look-back; candidates it
-//                     cannot settle go to
+//                     that lead to visiting the candidate and pulls it back window
+//                     by window: empty -> not on the chain, everything -> on the
+//                     chain however the chain entered, domain start -> the chain
+//                     starts in phase 0 (monkey_moore.cpp:329).  Two short windows
+//                     (<= 768 positions) settle a match in ordinary data; the rest go to
+//   mm_resolve2       (one workgroup per candidate) whose waves map the rest of the
+//                     candidate's 2048-position tile in parallel; what even that
+//                     cannot settle (constant / periodic data) goes to
 //   mm_hard_resolve   (several workgroups per candidate) which maps the whole
 //                     prefix of the domain in parallel and pulls A through it.
 #ifndef MM_TILES_H
 #define MM_TILES_H
 
-constexpr int MM_TILE = 2048;                 // positions per tile (32 ballots of 64)
+constexpr int MM_TILE = 2048;                 // positions per tile
 constexpr int MM_WAVES = 4;                   // waves per workgroup in the tile kernels
 constexpr int MM_MAXD = MMH_MAX_KEYWORD;      // bytes of a stored tile map
-constexpr int MM_FAST_STEPS = 4;              // look-back windows of mm_resolve: <= 256, 512, 1024, 2048 positions
+constexpr int MM_FAST_STEPS = 2;              // look-back windows of mm_resolve: <= 256, then <= 512 positions
+constexpr int MM_MID_CHUNK = 512;             // mm_resolve2: a workgroup's waves map chunks of this many positions in parallel
+constexpr int MM_MID_CAP = 2048;              // candidates mm_resolve hands to mm_resolve2 per scan
 constexpr int MM_HARD_PARTS = 64;             // workgroups per hard candidate
 constexpr int MM_HARD_CAP = 32;               // hard candidates handled per scan
 constexpr int MM_HARD_MAX_TILES = 8192;       // longest prefix (in tiles) mm_hard_resolve maps
+constexpr int MM_JUMP_MATCH = 0x80;           // flag in a stored jump: the compare loop reported a match here
 
 // wave-uniform constants shared by the tile kernels (kernel arguments -> SGPRs)
 struct MmTileArgs {
    MmGeom g;
    mmh_plan_desc plan;
-   uint32_t inv_d;          // ceil(65536 / D): x / D == (x * inv_d) >> 16 for x < 2048
+   uint32_t inv_d;          // ceil(65536 / D): x / D == (x * inv_d) >> 16 for x < 2100
+   uint32_t inv_d32;        // floor(2^32 / D) + 1: quotient estimate for 32-bit x, at most one too big
+   uint32_t block_shift;    // log2(block_bytes) when that is a power of two, else ~0
    uint64_t skip_bloom;     // bit (d & 63) set for every listed bad-character diff
 };
 
@@ -61,6 +73,7 @@ struct MmPlanLds {
 
 struct MmWaveLds {
    uint32_t tile[((MM_TILE + MMH_MAX_KEYWORD + 1) * 2 + 16) / 4];
+   uint8_t jump[MM_TILE];                    // J of every position of the window (| MM_JUMP_MATCH)
 };
 
 // tell the compiler a value is the same in every lane (keeps it in SGPRs / on the scalar unit)
@@ -102,61 +115,6 @@ __device__ __forceinline__ void mm_plan_to_lds(MmPlanLds &P, const mmh_plan_desc
    }
    __syncthreads();
 }
-
-// --------------------------------------------------------------------------
-// phase maps in scalar registers
-// --------------------------------------------------------------------------
-//
-// BITS = 4: 16 entries in one 64-bit word (D <= 16); BITS = 8: 32 entries in four.
-// update(r, r2): every entry that currently equals r becomes r2 -- exact per-field
-// zero detection (no borrow across fields), then a masked xor.
-
-template <int BITS>
-struct MmPhaseMap {
-   static constexpr int WORDS = BITS == 4 ? 1 : 4;
-   static constexpr int PER_WORD = 64 / BITS;
-   static constexpr uint64_t ONES = BITS == 4 ? 0x1111111111111111ull : 0x0101010101010101ull;
-   static constexpr uint64_t LOW = BITS == 4 ? 0x7777777777777777ull : 0x7F7F7F7F7F7F7F7Full;
-   static constexpr uint64_t HIGH = BITS == 4 ? 0x8888888888888888ull : 0x8080808080808080ull;
-   static constexpr uint64_t FIELD = (1ull << BITS) - 1;
-   uint64_t w[WORDS];
-
-   __device__ __forceinline__ void identity()
-   {
-#pragma unroll
-      for (int k = 0; k < WORDS; k++) {
-         uint64_t v = 0;
-#pragma unroll
-         for (int e = 0; e < PER_WORD; e++) {
-            v |= (uint64_t)((k * PER_WORD + e) & (int)FIELD) << (BITS * e);
-         }
-         w[k] = v;
-      }
-   }
-
-   __device__ __forceinline__ void update(uint32_t r, uint32_t r2)
-   {
-      const uint64_t rr = (uint64_t)r * ONES;
-      const uint64_t flip = (uint64_t)(r ^ r2) * ONES;
-#pragma unroll
-      for (int k = 0; k < WORDS; k++) {
-         const uint64_t x = w[k] ^ rr;
-         const uint64_t z = ~(((x & LOW) + LOW) | x) & HIGH;          // top bit of a field set iff field == r
-         const uint64_t m = (z >> (BITS - 1)) * FIELD;                 // whole-field mask
-         w[k] ^= m & flip;
-      }
-   }
-
-   __device__ __forceinline__ uint32_t get(int e) const
-   {
-      uint64_t word = w[0];
-      if (WORDS > 1) {
-         const int k = e / PER_WORD;
-         word = k == 0 ? w[0] : (k == 1 ? w[1 % WORDS] : (k == 2 ? w[2 % WORDS] : w[3 % WORDS]));
-      }
-      return (uint32_t)((word >> (BITS * (e % PER_WORD))) & FIELD);
-   }
-};
 
 // --------------------------------------------------------------------------
 // one tile -> its map
@@ -223,14 +181,54 @@ __device__ __forceinline__ int mm_tile_skip(const MmTileArgs &a, const MmPlanLds
    return s;
 }
 
-// x mod D for x < 2048 without a division
+// x mod D for x < 2100 without a division
 __device__ __forceinline__ uint32_t mm_modd(const MmTileArgs &a, uint32_t x)
 {
    return x - ((x * a.inv_d) >> 16) * (a.plan.L - 1);
 }
 
-// map of positions [lo, lo + npos) of the domain at byte `start`; lo_mod = lo mod D.
-// The result is wave uniform.
+// x mod D for any x (domain positions): a multiply for 32-bit values, the division only beyond
+__device__ __forceinline__ uint32_t mm_modd64(const MmTileArgs &a, uint64_t x)
+{
+   const uint32_t D = a.plan.L - 1;
+   if (D == 1) {
+      return 0;                                                    // (2^32 / 1 + 1 does not fit inv_d32)
+   }
+   if ((x >> 32) != 0) {
+      return (uint32_t)(x % D);
+   }
+   const uint32_t q = __umulhi((uint32_t)x, a.inv_d32);          // floor(x / D) or one more
+   const int32_t r = (int32_t)((uint32_t)x - q * D);
+   return (uint32_t)(r < 0 ? r + (int32_t)D : r);
+}
+
+// mm_locate with the divisions taken out: element sizes are 1 or 2, block sizes are powers of
+// two in practice (the general case keeps the division)
+__device__ __forceinline__ bool mm_locate_fast(const MmTileArgs &a, uint64_t o, uint64_t *b, uint32_t *p, int64_t *j)
+{
+   const uint32_t sshift = a.g.S - 1;                              // S = 1 or 2
+   if (a.g.whole) {
+      if (o & sshift) {
+         return false;
+      }
+      *b = 0; *p = 0; *j = (int64_t)(o >> sshift);
+      return *j < (int64_t)(a.g.nbytes >> sshift) - (int64_t)a.g.L + 1;
+   }
+   const uint64_t blk = a.block_shift < 64 ? o >> a.block_shift : o / a.g.block_bytes;
+   const uint64_t first = a.block_shift < 64 ? blk << a.block_shift : blk * a.g.block_bytes;
+   const uint64_t r = o - first;
+   *b = blk; *p = (uint32_t)(r & sshift); *j = (int64_t)(r >> sshift);
+   // mm_domain_nv (mm_internal.h) with shifts
+   const uint64_t full = a.g.block_bytes + ((uint64_t)(a.g.L - 1) << sshift);
+   const uint64_t remaining = a.g.nbytes - first;
+   const uint64_t size = remaining < full ? remaining : full;
+   uint64_t count = size >> sshift;
+   if ((uint64_t)*p + (count << sshift) > size) {
+      count -= 1;
+   }
+   return *j < (int64_t)count - (int64_t)a.g.L + 1;
+}
+
 // the reference's compare loop at position q of the staged tile: does it report a match?
 __device__ __forceinline__ bool mm_tile_matches(const MmTileArgs &a, const MmPlanLds &P, const uint8_t *tile, int q)
 {
@@ -246,20 +244,16 @@ __device__ __forceinline__ bool mm_tile_matches(const MmTileArgs &a, const MmPla
    return true;
 }
 
-template <int BITS>
-__device__ __forceinline__ void mm_tile_map(const MmTileArgs &a, const MmPlanLds &P, MmWaveLds &W, uint64_t start, int64_t lo,
-                                            int npos, uint32_t lo_mod, int lane, MmPhaseMap<BITS> &M,
-                                            bool *end_matches = nullptr)
+// Steps 1 and 2 of the header: stage positions [lo, lo + npos) of the domain at byte `start`
+// and leave the jump of every position (| MM_JUMP_MATCH where the compare loop matched) in
+// W.jump.  Returns the staged tile's first byte.
+__device__ __forceinline__ const uint8_t *mm_tile_jumps(const MmTileArgs &a, const MmPlanLds &P, MmWaveLds &W, uint64_t start,
+                                                        int64_t lo, int npos, int lane)
 {
-   start = mm_uniform64(start);
-   lo = (int64_t)mm_uniform64((uint64_t)lo);
-   npos = (int)mm_uniform((uint32_t)npos);
-   lo_mod = mm_uniform(lo_mod);
    const int mis = mm_stage_tile(a, W, start, lo, npos, lane);
    mm_wave_sync();
 
    const int L = (int)a.plan.L, S = (int)a.g.S;
-   const uint32_t D = (uint32_t)(L - 1);
    const bool be = a.g.big_endian != 0;
    const uint8_t *tile = reinterpret_cast<const uint8_t *>(W.tile) + mis;
    // the first compare (keyword position L-1) from wave-uniform registers
@@ -267,8 +261,6 @@ __device__ __forceinline__ void mm_tile_map(const MmTileArgs &a, const MmPlanLds
    const uint32_t m1 = a.plan.cmp_mask[L - 1];
    const int match_jump = (int)a.plan.match_jump;
 
-   M.identity();
-   uint32_t ph0 = lo_mod;                                 // phase of position 64t (scalar)
    const int nballots = (npos + 63) >> 6;
    // software pipeline: the element pair of iteration t+1 is read while t is finished
    int c = 0, pv = 0;
@@ -287,14 +279,14 @@ __device__ __forceinline__ void mm_tile_map(const MmTileArgs &a, const MmPlanLds
       const bool live = q < npos;
       const int d = c - pv;
       const bool deep = live && ((uint32_t)(d ^ e1) & m1) == 0;
-      int J = (int)D;                                     // lanes past the end: no-op
+      int J = 1;
       if (live) {
          const int s = mm_tile_skip(a, P, d);
          J = s < w1 ? s : w1;
       }
       if (__ballot(deep) != 0) {
          if (deep) {
-            J = match_jump;
+            J = match_jump | MM_JUMP_MATCH;
             for (int i = L - 2; i >= 0; --i) {
                const int ci = mm_tile_elem(tile, q + i, S, be);
                const int pi = mm_tile_elem(tile, q + i + P.bridge[i], S, be);
@@ -308,38 +300,54 @@ __device__ __forceinline__ void mm_tile_map(const MmTileArgs &a, const MmPlanLds
             }
          }
       }
-      // exceptional positions of this group, in position order, on the scalar unit
-      unsigned long long mask = __ballot(J != (int)D);
-      while (mask) {
-         const int bit = __builtin_ctzll(mask);
-         mask &= mask - 1;
-         const uint32_t Jb = (uint32_t)__builtin_amdgcn_readlane(J, bit);
-         const uint32_t r = mm_modd(a, ph0 + (uint32_t)bit);
-         uint32_t r2 = r + Jb;
-         r2 = r2 >= D ? r2 - D : r2;
-         M.update(r, r2);
+      if (live) {
+         // (a jump below 1 cannot come out of a plan of mm_plan.cpp; the walk below must never stall)
+         W.jump[q] = (uint8_t)((J & (MM_JUMP_MATCH - 1)) == 0 ? 1 : J);
       }
-      ph0 = mm_modd(a, ph0 + 64u);
       c = cn;
       pv = pn;
    }
-   if (end_matches) {
-      // position npos itself (the candidate in front of which this window ends); only
-      // meaningful when the domain holds L elements from there, which the caller checked
-      *end_matches = mm_tile_matches(a, P, tile, npos);
-   }
-   mm_wave_sync();                                        // the tile buffer may be restaged now
+   mm_wave_sync();
+   return tile;
 }
 
-// A' = { e < D : M[e] in A }
-template <int BITS>
-__device__ __forceinline__ uint32_t mm_pull_back(uint32_t A, int D, const MmPhaseMap<BITS> &M)
+// Map of positions [lo, lo + npos) of the domain at byte `start`; lo_mod = lo mod D.  Lane
+// e < D returns the exit phase of entry phase e (other lanes: their own number, i.e. the
+// identity).  *end_matches: does the compare loop match AT position npos (the candidate in
+// front of which the window ends)?  Only meaningful when the domain holds L elements from
+// there, which the caller checked.
+__device__ __forceinline__ uint32_t mm_tile_map(const MmTileArgs &a, const MmPlanLds &P, MmWaveLds &W, uint64_t start, int64_t lo,
+                                                int npos, uint32_t lo_mod, int lane, bool *end_matches = nullptr)
 {
-   uint32_t r = 0;
-   for (int e = 0; e < D; e++) {
-      r |= ((A >> M.get(e)) & 1u) << e;
+   start = mm_uniform64(start);
+   lo = (int64_t)mm_uniform64((uint64_t)lo);
+   npos = (int)mm_uniform((uint32_t)npos);
+   lo_mod = mm_uniform(lo_mod);
+   const uint8_t *tile = mm_tile_jumps(a, P, W, start, lo, npos, lane);
+   const uint32_t D = a.plan.L - 1;
+
+   uint32_t v = (uint32_t)lane;
+   if ((uint32_t)lane < D) {
+      uint32_t p = (uint32_t)lane + D - lo_mod;            // first position of the window in phase `lane`
+      p = p >= D ? p - D : p;
+      while (p < (uint32_t)npos) {
+         p += W.jump[p] & (MM_JUMP_MATCH - 1);
+      }
+      // the chain left the window at p in [npos, npos + D): its phase
+      v = mm_modd(a, lo_mod + (uint32_t)npos) + (p - (uint32_t)npos);
+      v = v >= D ? v - D : v;
    }
-   return r;
+   if (end_matches) {
+      *end_matches = mm_tile_matches(a, P, tile, npos);
+   }
+   mm_wave_sync();                                        // the wave's LDS may be restaged now
+   return v;
+}
+
+// A' = { e < D : map[e] in A }; `map` is the per-lane value mm_tile_map returned
+__device__ __forceinline__ uint32_t mm_pull_back(uint32_t A, uint32_t D, uint32_t map, int lane)
+{
+   return (uint32_t)__ballot((uint32_t)lane < D && ((A >> map) & 1u) != 0);
 }
 
 // --------------------------------------------------------------------------
@@ -360,12 +368,12 @@ struct MmResolveArgs {
    unsigned long long *tiles_walked;          // MM_STAT_STRIPES striped statistics counters
    uint64_t base_offset;                      // added to reported byte offsets
    uint32_t max_candidates;                   // above this the host switches engines
-   // candidates the bounded look-back could not settle
-   uint64_t *hard_off;                        // [MM_HARD_CAP] candidate byte offset
-   uint64_t *hard_hi;                         // [MM_HARD_CAP] frontier (domain position, multiple of MM_TILE)
-   uint32_t *hard_set;                        // [MM_HARD_CAP] acceptable phases at the frontier
-   uint32_t *hard_slot;                       // [MM_HARD_CAP] the candidate's result slot
-   unsigned int *hard_count;
+   // candidates the two short windows could not settle, for mm_resolve2
+   uint64_t *mid_off;                         // [MM_MID_CAP] candidate byte offset
+   uint64_t *mid_hi;                          // [MM_MID_CAP] frontier (domain position)
+   uint32_t *mid_set;                         // [MM_MID_CAP] acceptable phases at the frontier
+   uint32_t *mid_slot;                        // [MM_MID_CAP] the candidate's result slot
+   unsigned int *mid_count;
 };
 
 constexpr uint64_t MM_NO_MATCH = ~0ull;
@@ -375,10 +383,9 @@ __device__ __forceinline__ uint64_t mm_report_value(const MmGeom &g, uint64_t o,
    return g.whole ? o / g.S : o + base_offset;
 }
 
-template <int BITS>
 __device__ __forceinline__ void mm_resolve_body(const MmResolveArgs &a, const MmPlanLds &P, MmWaveLds &W)
 {
-   const int D = (int)a.t.plan.L - 1;
+   const uint32_t D = a.t.plan.L - 1;
    const int wave = (int)mm_uniform(threadIdx.x >> 6);
    const int lane = threadIdx.x & 63;
    // the filter's MM_CAND_LISTS (= 64 = one per lane) lists get one compact numbering:
@@ -407,9 +414,10 @@ __device__ __forceinline__ void mm_resolve_body(const MmResolveArgs &a, const Mm
 
    for (uint64_t ci = (uint64_t)blockIdx.x * MM_WAVES + wave; ci < ncand; ci += nwaves) {
       const int list = __popcll(__ballot(excl <= ci)) - 1;
-      const uint64_t o = a.cand[(uint64_t)list * a.list_cap + (ci - __shfl(excl, list))];
+      // wave uniform from here on: the index arithmetic below runs on the scalar unit
+      const uint64_t o = mm_uniform64(a.cand[(uint64_t)list * a.list_cap + (ci - __shfl(excl, list))]);
       uint64_t b; uint32_t p; int64_t jc;
-      if (!mm_locate(a.t.g, o, &b, &p, &jc)) {
+      if (!mm_locate_fast(a.t, o, &b, &p, &jc)) {
          // SWAR survivor that is not an alignment of any domain (file tail, 16-bit odd boundary)
          if (lane == 0) {
             a.out[ci] = MM_NO_MATCH;
@@ -418,7 +426,7 @@ __device__ __forceinline__ void mm_resolve_body(const MmResolveArgs &a, const Mm
       }
       const uint64_t start = mm_domain_start(a.t.g, b, p);
 
-      uint32_t A = 1u << (uint32_t)(jc % D);
+      uint32_t A = 1u << mm_modd64(a.t, (uint64_t)jc);
       int64_t hi = jc;
       int verdict = -1;                        // 1 visited, 0 not visited, -1 undecided
       if (jc == 0) {
@@ -428,22 +436,21 @@ __device__ __forceinline__ void mm_resolve_body(const MmResolveArgs &a, const Mm
          mm_step(a.t.plan, [&](int64_t k) { return mm_elem(a.t.g, start, k); }, 0, &matched);
          verdict = matched ? 1 : 0;
       }
-      // Look-back windows grow 256 -> 2048 positions and end on multiples of their size:
+      // Look-back windows of <= 256, then <= 512 positions, ending on multiples of their size:
       // a true match pulls every phase onto itself within a few keyword lengths (that is
-      // what the bad-character rule is for), so the first short window usually settles
-      // it; after the last step the frontier is tile aligned for mm_hard_resolve.
+      // what the bad-character rule is for), so the first window usually settles it.
       for (int step = 0; step < MM_FAST_STEPS && hi > 0 && verdict < 0; step++) {
-         const int64_t gran = (int64_t)(MM_TILE >> (MM_FAST_STEPS - 1 - step));
-         const int64_t lo = ((hi - 1) / gran) * gran;
-         MmPhaseMap<BITS> M;
+         const int64_t gran = (int64_t)256 << step;
+         const int64_t lo = (hi - 1) & ~(gran - 1);
          bool is_match = true;
-         mm_tile_map<BITS>(a.t, P, W, start, lo, (int)(hi - lo), (uint32_t)(lo % D), lane, M, step == 0 ? &is_match : nullptr);
+         const uint32_t map = mm_tile_map(a.t, P, W, start, lo, (int)(hi - lo), mm_modd64(a.t, (uint64_t)lo), lane,
+                                          step == 0 ? &is_match : nullptr);
          walked++;
          if (!is_match) {
             verdict = 0;                        // survived the SWAR conditions only
             break;
          }
-         A = mm_pull_back<BITS>(A, D, M);
+         A = mm_pull_back(A, D, map, lane);
          hi = lo;
          if (A == full || A == 0) {
             verdict = A ? 1 : 0;
@@ -456,12 +463,12 @@ __device__ __forceinline__ void mm_resolve_body(const MmResolveArgs &a, const Mm
       if (lane == 0) {
          a.out[ci] = verdict == 1 ? mm_report_value(a.t.g, o, a.base_offset) : MM_NO_MATCH;
          if (verdict < 0) {
-            unsigned int slot = atomicAdd(a.hard_count, 1u);
-            if (slot < MM_HARD_CAP) {
-               a.hard_off[slot] = o;
-               a.hard_hi[slot] = (uint64_t)hi;
-               a.hard_set[slot] = A;
-               a.hard_slot[slot] = (uint32_t)ci;
+            unsigned int slot = atomicAdd(a.mid_count, 1u);   // beyond MM_MID_CAP: the host sees the count and switches engines
+            if (slot < MM_MID_CAP) {
+               a.mid_off[slot] = o;
+               a.mid_hi[slot] = (uint64_t)hi;
+               a.mid_set[slot] = A;
+               a.mid_slot[slot] = (uint32_t)ci;
             }
          }
       }
@@ -476,12 +483,109 @@ __global__ __launch_bounds__(64 * MM_WAVES) void mm_resolve(MmResolveArgs a)
    __shared__ MmPlanLds P;
    __shared__ MmWaveLds Wv[MM_WAVES];
    mm_plan_to_lds(P, a.t.plan);
-   if (a.t.plan.L - 1 <= 16) {
-      mm_resolve_body<4>(a, P, Wv[threadIdx.x >> 6]);
+   mm_resolve_body(a, P, Wv[threadIdx.x >> 6]);
+}
+
+// --------------------------------------------------------------------------
+// second resolver: one workgroup per left-over candidate, waves in parallel
+// --------------------------------------------------------------------------
+//
+// A candidate mm_resolve could not settle has its frontier `hi` somewhere inside a tile of
+// MM_TILE positions.  The waves of a workgroup map the rest of that tile, [T, hi) with T the
+// tile's first position, in chunks of MM_MID_CHUNK positions AT THE SAME TIME (a chunk's map
+// does not depend on how the chain enters it); wave 0 then pulls the phase set back through
+// the chunk maps, top down.  Still undecided at T > 0 -> mm_hard_resolve.
+
+struct MmResolve2Args {
+   MmTileArgs t;
+   const uint64_t *mid_off;
+   const uint64_t *mid_hi;
+   const uint32_t *mid_set;
+   const uint32_t *mid_slot;
+   const unsigned int *mid_count;
+   uint64_t *out;                             // result slots (see MmResolveArgs)
+   unsigned long long *tiles_walked;
+   uint64_t base_offset;
+   uint64_t *hard_off;                        // [MM_HARD_CAP] candidate byte offset
+   uint64_t *hard_hi;                         // [MM_HARD_CAP] frontier (domain position, multiple of MM_TILE)
+   uint32_t *hard_set;                        // [MM_HARD_CAP] acceptable phases at the frontier
+   uint32_t *hard_slot;                       // [MM_HARD_CAP] the candidate's result slot
+   unsigned int *hard_count;
+};
+
+__device__ __forceinline__ void mm_resolve2_body(const MmResolve2Args &a, const MmPlanLds &P, MmWaveLds &W,
+                                                 uint8_t (&maps)[MM_TILE / MM_MID_CHUNK][MM_MAXD])
+{
+   const uint32_t D = a.t.plan.L - 1;
+   const int wave = (int)mm_uniform(threadIdx.x >> 6);
+   const int lane = threadIdx.x & 63;
+   const uint32_t full = D >= 32 ? 0xFFFFFFFFu : ((1u << D) - 1u);
+   unsigned int n = *a.mid_count;
+   n = n > MM_MID_CAP ? 0u : n;                // overflow: the host discards this scan and switches engines
+   unsigned long long walked = 0;
+   for (unsigned int e = blockIdx.x; e < n; e += gridDim.x) {
+      const uint64_t o = a.mid_off[e];
+      const int64_t hi = (int64_t)a.mid_hi[e];
+      uint64_t b; uint32_t p; int64_t jc;
+      mm_locate_fast(a.t, o, &b, &p, &jc);
+      const uint64_t start = mm_domain_start(a.t.g, b, p);
+      const int64_t T = (hi - 1) & ~(int64_t)(MM_TILE - 1);
+      const int nchunks = (int)((hi - T + MM_MID_CHUNK - 1) / MM_MID_CHUNK);
+      for (int k = wave; k < nchunks; k += MM_WAVES) {
+         const int64_t lo = T + (int64_t)k * MM_MID_CHUNK;
+         const int npos = (int)(hi - lo < MM_MID_CHUNK ? hi - lo : MM_MID_CHUNK);
+         const uint32_t map = mm_tile_map(a.t, P, W, start, lo, npos, mm_modd64(a.t, (uint64_t)lo), lane);
+         if (lane < MM_MAXD) {
+            maps[k][lane] = (uint8_t)map;
+         }
+         walked++;
+      }
+      __syncthreads();
+      if (wave == 0) {
+         uint32_t A = a.mid_set[e];
+         int verdict = -1;                       // 1 visited, 0 not visited, -1 undecided
+         for (int k = nchunks - 1; k >= 0; k--) {
+            A = mm_pull_back(A, D, maps[k][lane & (MM_MAXD - 1)], lane);
+            if (A == full || A == 0) {
+               verdict = A ? 1 : 0;
+               break;
+            }
+         }
+         if (verdict < 0 && T == 0) {
+            verdict = (A & 1u) ? 1 : 0;          // domain start: the chain is in phase 0
+         }
+         if (lane == 0) {
+            if (verdict == 1) {
+               a.out[a.mid_slot[e]] = mm_report_value(a.t.g, o, a.base_offset);   // the slot already says "no match"
+            }
+            else if (verdict < 0) {
+               unsigned int slot = atomicAdd(a.hard_count, 1u);
+               if (slot < MM_HARD_CAP) {
+                  a.hard_off[slot] = o;
+                  a.hard_hi[slot] = (uint64_t)T;
+                  a.hard_set[slot] = A;
+                  a.hard_slot[slot] = a.mid_slot[e];
+               }
+            }
+         }
+      }
+      __syncthreads();                           // maps[] is rewritten by the next candidate
    }
-   else {
-      mm_resolve_body<8>(a, P, Wv[threadIdx.x >> 6]);
+   if (lane == 0 && walked) {
+      atomicAdd(a.tiles_walked + (blockIdx.x % MM_STAT_STRIPES), walked);
    }
+}
+
+__global__ __launch_bounds__(64 * MM_WAVES) void mm_resolve2(MmResolve2Args a)
+{
+   __shared__ MmPlanLds P;
+   __shared__ MmWaveLds Wv[MM_WAVES];
+   __shared__ uint8_t maps[MM_TILE / MM_MID_CHUNK][MM_MAXD];
+   if (*a.mid_count == 0) {
+      return;
+   }
+   mm_plan_to_lds(P, a.t.plan);
+   mm_resolve2_body(a, P, Wv[threadIdx.x >> 6], maps);
 }
 
 // --------------------------------------------------------------------------
@@ -507,7 +611,6 @@ struct MmHardArgs {
    uint64_t base_offset;
 };
 
-template <int BITS>
 __device__ __forceinline__ void mm_hard_tiles(const MmHardArgs &a, const MmPlanLds &P, MmWaveLds &W, uint64_t start,
                                               uint64_t ntiles, uint8_t *maps)
 {
@@ -516,11 +619,10 @@ __device__ __forceinline__ void mm_hard_tiles(const MmHardArgs &a, const MmPlanL
    const int lane = threadIdx.x & 63;
    unsigned long long walked = 0;
    for (uint64_t t = (uint64_t)blockIdx.x * MM_WAVES + wave; t < ntiles; t += MM_HARD_PARTS * MM_WAVES) {
-      MmPhaseMap<BITS> M;
       const int64_t lo = (int64_t)(t * MM_TILE);
-      mm_tile_map<BITS>(a.t, P, W, start, lo, MM_TILE, (uint32_t)(lo % D), lane, M);
+      const uint32_t map = mm_tile_map(a.t, P, W, start, lo, MM_TILE, mm_modd64(a.t, (uint64_t)lo), lane);
       if (lane < MM_MAXD) {
-         maps[t * MM_MAXD + lane] = (uint8_t)M.get(lane);
+         maps[t * MM_MAXD + lane] = (uint8_t)map;
       }
       walked++;
    }
@@ -562,16 +664,11 @@ __global__ __launch_bounds__(64 * MM_WAVES) void mm_hard_resolve(MmHardArgs a)
    }
    mm_plan_to_lds(P, a.t.plan);
    uint64_t b; uint32_t p; int64_t jc;
-   mm_locate(a.t.g, o, &b, &p, &jc);
+   mm_locate_fast(a.t, o, &b, &p, &jc);
    const uint64_t start = mm_domain_start(a.t.g, b, p);
    uint8_t *maps = a.scratch + (uint64_t)i * MM_HARD_MAX_TILES * MM_MAXD;
 
-   if (D <= 16) {
-      mm_hard_tiles<4>(a, P, Wv[wave], start, ntiles, maps);
-   }
-   else {
-      mm_hard_tiles<8>(a, P, Wv[wave], start, ntiles, maps);
-   }
+   mm_hard_tiles(a, P, Wv[wave], start, ntiles, maps);
 
    // last-arriver pattern (agent-scope release / acquire around the ticket)
    __threadfence();
