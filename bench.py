@@ -70,8 +70,8 @@ def cpu_baseline(eng, spec_bytes, plan_kw, sample_bytes):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--gib-per-gpu", type=float, default=4.0)
     ap.add_argument("--cpu-sample-mib", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
