@@ -383,25 +383,43 @@ __device__ __forceinline__ uint64_t mm_report_value(const MmGeom &g, uint64_t o,
    return g.whole ? o / g.S : o + base_offset;
 }
 
-__device__ __forceinline__ void mm_resolve_body(const MmResolveArgs &a, const MmPlanLds &P, MmWaveLds &W)
+// shared by the waves of a resolver workgroup
+struct MmResolveLds {
+   unsigned long long excl[MM_CAND_LISTS];   // candidates in the lists before list c
+   unsigned long long ncand;                 // all of them (~0: a list overflowed)
+   unsigned int walked;                      // windows mapped by this workgroup
+};
+
+// The filter's MM_CAND_LISTS (= 64 = one per lane) lists get one compact numbering: candidate
+// ci is entry ci - excl[c] of the list c with excl[c] <= ci < excl[c+1].  Wave 0 reads the
+// counters (64 cache lines) once for the workgroup; call before a __syncthreads().
+__device__ __forceinline__ void mm_resolve_prefix(const MmResolveArgs &a, MmResolveLds &R)
+{
+   if (threadIdx.x < 64) {
+      const int lane = threadIdx.x;
+      const unsigned long long my_count = a.list_count[lane * MM_LIST_STRIDE];
+      unsigned long long incl = my_count;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+         const unsigned long long v = __shfl_up(incl, d);
+         incl += lane >= d ? v : 0ull;
+      }
+      R.excl[lane] = incl - my_count;
+      const bool overflow = __ballot(my_count > a.list_cap) != 0;
+      if (lane == 63) {
+         R.ncand = overflow ? ~0ull : incl;
+         R.walked = 0;
+      }
+   }
+}
+
+__device__ __forceinline__ void mm_resolve_body(const MmResolveArgs &a, const MmPlanLds &P, MmWaveLds &W, MmResolveLds &R)
 {
    const uint32_t D = a.t.plan.L - 1;
    const int wave = (int)mm_uniform(threadIdx.x >> 6);
    const int lane = threadIdx.x & 63;
-   // the filter's MM_CAND_LISTS (= 64 = one per lane) lists get one compact numbering:
-   // candidate ci is entry ci - excl[c] of the list c with excl[c] <= ci < excl[c+1]
-   const unsigned long long my_count = a.list_count[lane * MM_LIST_STRIDE];
-   unsigned long long incl = my_count;
-#pragma unroll
-   for (int d = 1; d < 64; d <<= 1) {
-      const unsigned long long v = __shfl_up(incl, d);
-      incl += lane >= d ? v : 0ull;
-   }
-   const unsigned long long excl = incl - my_count;
-   unsigned long long ncand = __shfl(incl, 63);
-   if (__ballot(my_count > a.list_cap) != 0) {
-      ncand = ~0ull;                           // a list overflowed
-   }
+   const unsigned long long excl = R.excl[lane];
+   const unsigned long long ncand = R.ncand;
    if (blockIdx.x == 0 && threadIdx.x == 0) {
       *a.total_out = ncand;
    }
@@ -473,8 +491,13 @@ __device__ __forceinline__ void mm_resolve_body(const MmResolveArgs &a, const Mm
          }
       }
    }
+   // statistics: one global atomic per workgroup (4 K of them on 16 addresses would sit on the kernel's tail)
    if (lane == 0 && walked) {
-      atomicAdd(a.tiles_walked + (blockIdx.x % MM_STAT_STRIPES), walked);
+      atomicAdd(&R.walked, (unsigned int)walked);
+   }
+   __syncthreads();
+   if (threadIdx.x == 0 && R.walked) {
+      atomicAdd(a.tiles_walked + (blockIdx.x % MM_STAT_STRIPES), (unsigned long long)R.walked);
    }
 }
 
@@ -482,8 +505,10 @@ __global__ __launch_bounds__(64 * MM_WAVES) void mm_resolve(MmResolveArgs a)
 {
    __shared__ MmPlanLds P;
    __shared__ MmWaveLds Wv[MM_WAVES];
-   mm_plan_to_lds(P, a.t.plan);
-   mm_resolve_body(a, P, Wv[threadIdx.x >> 6]);
+   __shared__ MmResolveLds R;
+   mm_resolve_prefix(a, R);
+   mm_plan_to_lds(P, a.t.plan);                 // ends with a __syncthreads()
+   mm_resolve_body(a, P, Wv[threadIdx.x >> 6], R);
 }
 
 // --------------------------------------------------------------------------
