@@ -27,6 +27,7 @@ EXPORTS = [
     "mmh_set_stream", "mmh_rom_upload", "mmh_rom_attach", "mmh_rom_download", "mmh_rom_alloc", "mmh_rom_synth",
     "mmh_rom_poke", "mmh_rom_fill", "mmh_scan", "mmh_set_engine", "mmh_last_timings", "mmh_last_counters",
     "mmh_timing_history", "mmh_filter_shape", "mmh_rom_load_file", "mmh_last_load_stats", "mmh_rom_gather",
+    "mmh_scan_submit", "mmh_scan_collect",
 ]
 
 
@@ -76,6 +77,8 @@ def lib():
         L.mmh_rom_poke.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
         L.mmh_rom_fill.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
         L.mmh_scan.argtypes = [C.c_void_p, C.POINTER(PlanDesc), C.c_uint64, C.c_int, C.c_uint64, u64p, C.c_uint64, u64p]
+        L.mmh_scan_submit.argtypes = [C.c_void_p, C.POINTER(PlanDesc), C.c_uint64, C.c_int, C.c_uint64, C.POINTER(C.c_int)]
+        L.mmh_scan_collect.argtypes = [C.c_void_p, C.c_int, u64p, C.c_uint64, u64p]
         L.mmh_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.mmh_last_counters.argtypes = [C.c_void_p, u64p]
         L.mmh_filter_shape.argtypes = [C.POINTER(PlanDesc), C.POINTER(C.c_uint32)]
@@ -217,6 +220,26 @@ class Engine:
             n = C.c_uint64(0)
             rc = lib().mmh_scan(self._h, C.byref(plan), block_bytes, int(big_endian), base_offset,
                                 out.ctypes.data_as(C.POINTER(C.c_uint64)), out.size, C.byref(n))
+            if rc == MMH_E_CAPACITY:
+                cap = int(n.value) + 16
+                continue
+            _check(rc)
+            return out[: n.value].copy()
+
+    def submit(self, plan, block_bytes=0, big_endian=False, base_offset=0):
+        """Enqueue a scan (at most two outstanding); returns the ticket for collect()."""
+        t = C.c_int(0)
+        _check(lib().mmh_scan_submit(self._h, C.byref(plan), block_bytes, int(big_endian), base_offset, C.byref(t)))
+        return t.value
+
+    def collect(self, ticket, cap=1 << 16):
+        """Wait for a submitted scan; returns what scan() would have returned."""
+        while True:
+            out = getattr(self, "_out", None)
+            if out is None or out.size < cap:
+                out = self._out = np.empty(cap, np.uint64)
+            n = C.c_uint64(0)
+            rc = lib().mmh_scan_collect(self._h, ticket, out.ctypes.data_as(C.POINTER(C.c_uint64)), out.size, C.byref(n))
             if rc == MMH_E_CAPACITY:
                 cap = int(n.value) + 16
                 continue

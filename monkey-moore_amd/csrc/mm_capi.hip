@@ -59,32 +59,33 @@ extern "C" const char *mmh_last_error(void) { return g_error.c_str(); }
 
 namespace {
 
-int ensure_workspace(mmh_ctx *c, uint64_t out_cap)
+int ensure_workspace(mmh_ctx *c, MmWorkspace &w, uint64_t out_cap)
 {
    HIP_TRY(hipSetDevice(c->device));
-   if (!c->d_cand) {
-      c->cand_cap = kInitialCap;
-      HIP_TRY(hipMalloc(&c->d_cand, c->cand_cap * sizeof(uint64_t)));
-      HIP_TRY(hipMalloc(&c->d_ctrl, mm::ctrl_bytes()));
-      HIP_TRY(hipMalloc(&c->d_mid_off, mm::mid_cap() * sizeof(uint64_t)));
-      HIP_TRY(hipMalloc(&c->d_mid_hi, mm::mid_cap() * sizeof(uint64_t)));
-      HIP_TRY(hipMalloc(&c->d_mid_set, mm::mid_cap() * sizeof(uint32_t)));
-      HIP_TRY(hipMalloc(&c->d_mid_slot, mm::mid_cap() * sizeof(uint32_t)));
-      HIP_TRY(hipMalloc(&c->d_hard_off, mm::hard_cap() * sizeof(uint64_t)));
-      HIP_TRY(hipMalloc(&c->d_hard_hi, mm::hard_cap() * sizeof(uint64_t)));
-      HIP_TRY(hipMalloc(&c->d_hard_set, mm::hard_cap() * sizeof(uint32_t)));
-      HIP_TRY(hipMalloc(&c->d_hard_slot, mm::hard_cap() * sizeof(uint32_t)));
-      HIP_TRY(hipMalloc(&c->d_scratch, mm::hard_scratch_bytes()));
-      HIP_TRY(hipMalloc(&c->d_partials, mm::rank_partials_bytes(kMaxRankSort)));
-      HIP_TRY(hipHostMalloc(&c->h_result, (kHeaderWords + kMaxRankSort) * sizeof(uint64_t), hipHostMallocDefault));
+   if (!w.d_cand) {
+      w.cand_cap = kInitialCap;
+      HIP_TRY(hipMalloc(&w.d_cand, w.cand_cap * sizeof(uint64_t)));
+      HIP_TRY(hipMalloc(&w.d_ctrl, mm::ctrl_bytes()));
+      HIP_TRY(hipMalloc(&w.d_mid_off, mm::mid_cap() * sizeof(uint64_t)));
+      HIP_TRY(hipMalloc(&w.d_mid_hi, mm::mid_cap() * sizeof(uint64_t)));
+      HIP_TRY(hipMalloc(&w.d_mid_set, mm::mid_cap() * sizeof(uint32_t)));
+      HIP_TRY(hipMalloc(&w.d_mid_slot, mm::mid_cap() * sizeof(uint32_t)));
+      HIP_TRY(hipMalloc(&w.d_hard_off, mm::hard_cap() * sizeof(uint64_t)));
+      HIP_TRY(hipMalloc(&w.d_hard_hi, mm::hard_cap() * sizeof(uint64_t)));
+      HIP_TRY(hipMalloc(&w.d_hard_set, mm::hard_cap() * sizeof(uint32_t)));
+      HIP_TRY(hipMalloc(&w.d_hard_slot, mm::hard_cap() * sizeof(uint32_t)));
+      HIP_TRY(hipMalloc(&w.d_scratch, mm::hard_scratch_bytes()));
+      HIP_TRY(hipMalloc(&w.d_partials, mm::rank_partials_bytes(kMaxRankSort)));
+      HIP_TRY(hipHostMalloc(&w.h_result, (kHeaderWords + kMaxRankSort) * sizeof(uint64_t), hipHostMallocDefault));
+      w.ctrl_clean = false;
    }
-   if (out_cap > c->out_cap) {
-      if (c->d_out) {
-         HIP_TRY(hipFree(c->d_out));
-         c->d_out = nullptr;
+   if (out_cap > w.out_cap) {
+      if (w.d_out) {
+         HIP_TRY(hipFree(w.d_out));
+         w.d_out = nullptr;
       }
-      HIP_TRY(hipMalloc(&c->d_out, out_cap * sizeof(uint64_t)));
-      c->out_cap = out_cap;
+      HIP_TRY(hipMalloc(&w.d_out, out_cap * sizeof(uint64_t)));
+      w.out_cap = out_cap;
    }
    for (auto &triple : c->ring) {
       for (auto &e : triple) {
@@ -96,9 +97,28 @@ int ensure_workspace(mmh_ctx *c, uint64_t out_cap)
    return MMH_OK;
 }
 
+void free_workspace(MmWorkspace &w)
+{
+   if (w.d_cand) (void)hipFree(w.d_cand);
+   if (w.d_out) (void)hipFree(w.d_out);
+   if (w.d_ctrl) (void)hipFree(w.d_ctrl);
+   if (w.d_mid_off) (void)hipFree(w.d_mid_off);
+   if (w.d_mid_hi) (void)hipFree(w.d_mid_hi);
+   if (w.d_mid_set) (void)hipFree(w.d_mid_set);
+   if (w.d_mid_slot) (void)hipFree(w.d_mid_slot);
+   if (w.d_hard_off) (void)hipFree(w.d_hard_off);
+   if (w.d_hard_hi) (void)hipFree(w.d_hard_hi);
+   if (w.d_hard_set) (void)hipFree(w.d_hard_set);
+   if (w.d_hard_slot) (void)hipFree(w.d_hard_slot);
+   if (w.d_scratch) (void)hipFree(w.d_scratch);
+   if (w.d_partials) (void)hipFree(w.d_partials);
+   if (w.h_result) (void)hipHostFree(w.h_result);
+   w = MmWorkspace();
+}
+
 } // namespace
 
-int mmh_workspace(mmh_ctx *c) { return ensure_workspace(c, std::max<uint64_t>(c->out_cap, kInitialCap)); }
+int mmh_workspace(mmh_ctx *c) { return ensure_workspace(c, c->ws[0], std::max<uint64_t>(c->ws[0].out_cap, kInitialCap)); }
 
 namespace {
 
@@ -177,24 +197,23 @@ extern "C" void mmh_destroy(mmh_ctx *c)
    (void)hipSetDevice(c->device);
    (void)hipStreamSynchronize(c->stream);
    release_rom(c);
-   if (c->d_cand) (void)hipFree(c->d_cand);
-   if (c->d_out) (void)hipFree(c->d_out);
-   if (c->d_ctrl) (void)hipFree(c->d_ctrl);
-   if (c->d_mid_off) (void)hipFree(c->d_mid_off);
-   if (c->d_mid_hi) (void)hipFree(c->d_mid_hi);
-   if (c->d_mid_set) (void)hipFree(c->d_mid_set);
-   if (c->d_mid_slot) (void)hipFree(c->d_mid_slot);
-   if (c->d_hard_off) (void)hipFree(c->d_hard_off);
-   if (c->d_hard_hi) (void)hipFree(c->d_hard_hi);
-   if (c->d_hard_set) (void)hipFree(c->d_hard_set);
-   if (c->d_hard_slot) (void)hipFree(c->d_hard_slot);
-   if (c->d_scratch) (void)hipFree(c->d_scratch);
-   if (c->d_partials) (void)hipFree(c->d_partials);
+   for (auto &p : c->pending) {
+      p.active = false;
+   }
+   for (hipStream_t t : c->lane_stream) {
+      if (t) {
+         (void)hipStreamSynchronize(t);
+         (void)hipStreamDestroy(t);
+      }
+   }
+   if (c->lane_fence) (void)hipEventDestroy(c->lane_fence);
+   for (auto &w : c->ws) {
+      free_workspace(w);
+   }
    if (c->d_dense) (void)hipFree(c->d_dense);
    if (c->d_sort_in) (void)hipFree(c->d_sort_in);
    if (c->d_sort_out) (void)hipFree(c->d_sort_out);
    if (c->d_sort_tmp) (void)hipFree(c->d_sort_tmp);
-   if (c->h_result) (void)hipHostFree(c->h_result);
    for (auto &triple : c->ring) {
       for (auto &e : triple) {
          if (e) (void)hipEventDestroy(e);
@@ -346,55 +365,72 @@ struct Outcome {
    bool sorted_on_device = false;
 };
 
-// enqueue [zero counters] -> engine kernels -> ordering into pinned host memory, then wait
-int run_pipeline(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, const mm::FilterChoice &fc, bool sequential,
-                 uint64_t base_offset, uint32_t max_candidates, Outcome *oc)
+// enqueue [zero counters] -> engine kernels -> ordering into pinned host memory; `ev` = the
+// scan's event triple {start, behind the streaming kernel, end}
+int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev, const MmGeom &g, const mmh_plan_desc &pl,
+                     const mm::FilterChoice &fc, bool sequential, uint64_t base_offset, uint32_t max_candidates)
 {
-   hipStream_t st = c->stream;
    mm::ResolveBuffers rb;
-   rb.cand = c->d_cand; rb.cand_cap = c->cand_cap; rb.out = c->d_out; rb.out_cap = c->out_cap; rb.ctrl = c->d_ctrl;
-   rb.mid_off = c->d_mid_off; rb.mid_hi = c->d_mid_hi; rb.mid_set = c->d_mid_set; rb.mid_slot = c->d_mid_slot;
-   rb.hard_off = c->d_hard_off; rb.hard_hi = c->d_hard_hi; rb.hard_set = c->d_hard_set; rb.hard_slot = c->d_hard_slot;
-   rb.scratch = c->d_scratch;
+   rb.cand = w.d_cand; rb.cand_cap = w.cand_cap; rb.out = w.d_out; rb.out_cap = w.out_cap; rb.ctrl = w.d_ctrl;
+   rb.mid_off = w.d_mid_off; rb.mid_hi = w.d_mid_hi; rb.mid_set = w.d_mid_set; rb.mid_slot = w.d_mid_slot;
+   rb.hard_off = w.d_hard_off; rb.hard_hi = w.d_hard_hi; rb.hard_set = w.d_hard_set; rb.hard_slot = w.d_hard_slot;
+   rb.scratch = w.d_scratch;
    const int count_index = sequential ? 1 : 0;
 
-   c->h_result[6] = 0;                         // mm_rank_scatter publishes "matches + 1" here
-   if (!c->ctrl_clean) {
-      HIP_TRY(hipMemsetAsync(c->d_ctrl, 0, mm::ctrl_bytes(), st));
+   w.h_result[6] = 0;                          // mm_rank_scatter publishes "matches + 1" here
+   if (!w.ctrl_clean) {
+      HIP_TRY(hipMemsetAsync(w.d_ctrl, 0, mm::ctrl_bytes(), st));
    }
-   c->ctrl_clean = false;
+   w.ctrl_clean = false;
    // Only two events inside a scan (around the streaming kernel): every hipEventRecord
    // between dependent kernels costs ~6 us of stream time on this stack.
-   begin_scan_events(c, !sequential);
-   HIP_TRY(hipEventRecord(c->ev[0], st));
+   HIP_TRY(hipEventRecord(ev[0], st));
    if (!sequential) {
-      mm::launch_filter(st, g, pl, fc, c->d_cand, c->d_ctrl, c->cand_cap);
+      mm::launch_filter(st, g, pl, fc, w.d_cand, w.d_ctrl, w.cand_cap);
    }
-   HIP_TRY(hipEventRecord(c->ev[1], st));
+   HIP_TRY(hipEventRecord(ev[1], st));
    if (!sequential) {
       mm::launch_resolve(st, g, pl, rb, base_offset, max_candidates);
    }
    else {
-      mm::launch_chain_seq(st, g, pl, c->d_out, c->d_ctrl + 1, c->out_cap, base_offset);
+      mm::launch_chain_seq(st, g, pl, w.d_out, w.d_ctrl + 1, w.out_cap, base_offset);
    }
-   mm::launch_rank_sort(st, c->d_out, c->d_ctrl, count_index, c->out_cap, kMaxRankSort, c->d_partials, c->h_result);
+   mm::launch_rank_sort(st, w.d_out, w.d_ctrl, count_index, w.out_cap, kMaxRankSort, w.d_partials, w.h_result);
    HIP_TRY(hipGetLastError());
-   HIP_TRY(hipEventRecord(c->ev[2], st));
+   HIP_TRY(hipEventRecord(ev[2], st));
+   (void)c;
+   return MMH_OK;
+}
+
+// wait for an enqueued scan and read what it published
+int finish_pipeline(MmWorkspace &w, hipEvent_t *ev, bool sequential, Outcome *oc)
+{
    // waiting on the scan's last event returns ~6 us sooner than hipStreamSynchronize on this
    // stack (measured: 12 vs 18-20 us between the end of the device work and the caller)
-   HIP_TRY(hipEventSynchronize(c->ev[2]));
-   c->scans_recorded++;
-
-   oc->candidates = c->h_result[0];
-   oc->listed = c->h_result[count_index];
-   oc->tiles = c->h_result[2];
-   oc->hard = (uint32_t)(c->h_result[3] & 0xFFFFFFFFu);
+   HIP_TRY(hipEventSynchronize(ev[2]));
+   const int count_index = sequential ? 1 : 0;
+   oc->candidates = w.h_result[0];
+   oc->listed = w.h_result[count_index];
+   oc->tiles = w.h_result[2];
+   oc->hard = (uint32_t)(w.h_result[3] & 0xFFFFFFFFu);
    // left-overs beyond what mm_resolve2 / mm_hard_resolve take, or a prefix too long for the latter
-   oc->hard_overflow = (c->h_result[3] >> 32) != 0 || (c->h_result[5] & 0xFFFFFFFFu) > mm::mid_cap();
-   oc->sorted_on_device = oc->listed <= kMaxRankSort && oc->listed <= c->out_cap;
-   oc->matches = c->h_result[6] ? c->h_result[6] - 1 : oc->listed;
-   c->ctrl_clean = true;                        // mm_rank_scatter's last block re-zeroed it
+   oc->hard_overflow = (w.h_result[3] >> 32) != 0 || (w.h_result[5] & 0xFFFFFFFFu) > mm::mid_cap();
+   oc->sorted_on_device = oc->listed <= kMaxRankSort && oc->listed <= w.out_cap;
+   oc->matches = w.h_result[6] ? w.h_result[6] - 1 : oc->listed;
+   w.ctrl_clean = true;                         // mm_rank_scatter's last block re-zeroed it
    return MMH_OK;
+}
+
+int run_pipeline(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, const mm::FilterChoice &fc, bool sequential,
+                 uint64_t base_offset, uint32_t max_candidates, Outcome *oc)
+{
+   begin_scan_events(c, !sequential);
+   c->scans_recorded++;
+   int rc = enqueue_pipeline(c, c->ws[0], c->stream, c->ev, g, pl, fc, sequential, base_offset, max_candidates);
+   if (rc != MMH_OK) {
+      return rc;
+   }
+   return finish_pipeline(c->ws[0], c->ev, sequential, oc);
 }
 
 int grow(uint64_t **buf, uint64_t *cap, uint64_t need)
@@ -469,10 +505,10 @@ int run_dense(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, uint64_t bas
    db.supmaps = db.maps + round(dg.maps_bytes);
    db.supentry = db.supmaps + round(dg.supmaps_bytes);
    db.entry = db.supentry + round(dg.supentry_bytes);
-   db.out = c->d_out; db.out_cap = c->out_cap; db.ctrl = c->d_ctrl;
+   db.out = c->ws[0].d_out; db.out_cap = c->ws[0].out_cap; db.ctrl = c->ws[0].d_ctrl;
 
-   HIP_TRY(hipMemsetAsync(c->d_ctrl, 0, mm::ctrl_bytes(), st));
-   c->ctrl_clean = false;
+   HIP_TRY(hipMemsetAsync(c->ws[0].d_ctrl, 0, mm::ctrl_bytes(), st));
+   c->ws[0].ctrl_clean = false;
    begin_scan_events(c, false);
    HIP_TRY(hipEventRecord(c->ev[0], st));
    HIP_TRY(hipEventRecord(c->ev[1], st));
@@ -480,11 +516,11 @@ int run_dense(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, uint64_t bas
    HIP_TRY(hipGetLastError());
    HIP_TRY(hipEventRecord(c->ev[2], st));
    std::vector<unsigned long long> ctrl(mm::ctrl_bytes() / sizeof(unsigned long long));
-   HIP_TRY(hipMemcpyAsync(ctrl.data(), c->d_ctrl, mm::ctrl_bytes(), hipMemcpyDeviceToHost, st));
+   HIP_TRY(hipMemcpyAsync(ctrl.data(), c->ws[0].d_ctrl, mm::ctrl_bytes(), hipMemcpyDeviceToHost, st));
    HIP_TRY(hipStreamSynchronize(st));
    c->scans_recorded++;
 
-   const uint64_t list_cap = c->out_cap / MM_CAND_LISTS;
+   const uint64_t list_cap = c->ws[0].out_cap / MM_CAND_LISTS;
    uint64_t most = 0, total = 0;
    for (int l = 0; l < MM_CAND_LISTS; l++) {
       const uint64_t n = ctrl[MM_CTRL_LISTS + l * MM_LIST_STRIDE];
@@ -493,7 +529,7 @@ int run_dense(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, uint64_t bas
    }
    if (most > list_cap) {
       // some list overflowed: size every list for the fullest one and run again
-      int rc = ensure_workspace(c, (most + most / 8 + 1024) * MM_CAND_LISTS);
+      int rc = ensure_workspace(c, c->ws[0], (most + most / 8 + 1024) * MM_CAND_LISTS);
       if (rc != MMH_OK) {
          return rc;
       }
@@ -509,7 +545,7 @@ int run_dense(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, uint64_t bas
    for (int l = 0; l < MM_CAND_LISTS; l++) {
       const uint64_t n = ctrl[MM_CTRL_LISTS + l * MM_LIST_STRIDE];
       if (n) {
-         HIP_TRY(hipMemcpyAsync(c->d_sort_in + at, c->d_out + (uint64_t)l * list_cap, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+         HIP_TRY(hipMemcpyAsync(c->d_sort_in + at, c->ws[0].d_out + (uint64_t)l * list_cap, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
          at += n;
       }
    }
@@ -518,25 +554,24 @@ int run_dense(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, uint64_t bas
 
 } // namespace
 
-extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian,
-                        uint64_t base_offset, uint64_t *out, uint64_t cap, uint64_t *out_count)
+namespace {
+
+int check_scan_args(const mmh_ctx *c, const mmh_plan_desc *plan, const char *who)
 {
-   if (!c || !plan || !out_count || (!out && cap)) {
-      mmh_set_error("mmh_scan: bad argument");
-      return MMH_E_ARG;
-   }
-   *out_count = 0;
    if (!c->rom) {
-      mmh_set_error("mmh_scan: no ROM attached");
+      mmh_set_error("%s: no ROM attached", who);
       return MMH_E_STATE;
    }
    if (plan->L < 2 || plan->L > MMH_MAX_KEYWORD || (plan->elem_bytes != 1 && plan->elem_bytes != 2) ||
        plan->match_jump < 1 || plan->n_skip > MMH_MAX_KEYWORD) {
-      mmh_set_error("mmh_scan: malformed plan");
+      mmh_set_error("%s: malformed plan", who);
       return MMH_E_PLAN;
    }
-   HIP_TRY(hipSetDevice(c->device));
+   return MMH_OK;
+}
 
+MmGeom scan_geometry(const mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian)
+{
    MmGeom g;
    g.rom = c->rom;
    g.nbytes = c->rom_bytes;
@@ -549,8 +584,40 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
    if (g.whole) {
       g.nbytes = (g.nbytes / g.S) * g.S;        // whole elements only, like search(const Ty*, len)
    }
+   return g;
+}
 
-   int rc = ensure_workspace(c, std::max<uint64_t>(c->out_cap, kInitialCap));
+// More candidates than this and the forward engine (cost linear in the ROM: ~5 ms per GiB)
+// is the better deal: the resolvers take ~2-10 ns per candidate (measured: 65 K candidates
+// of a 3-symbol keyword on 4 GiB add 0.12 ms, against 21 ms for the forward engine).
+// Lists beyond kMaxRankSort entries are ordered by the radix sort of mm_sort.hip.
+uint32_t candidate_limit(const MmWorkspace &w)
+{
+   uint32_t limit = 262144u;
+   if (const char *knob = getenv("MMOORE_MAX_CANDIDATES")) {
+      limit = (uint32_t)std::min<unsigned long long>(strtoull(knob, nullptr, 10), w.cand_cap / 2);
+   }
+   return limit;
+}
+
+} // namespace
+
+extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian,
+                        uint64_t base_offset, uint64_t *out, uint64_t cap, uint64_t *out_count)
+{
+   if (!c || !plan || !out_count || (!out && cap)) {
+      mmh_set_error("mmh_scan: bad argument");
+      return MMH_E_ARG;
+   }
+   *out_count = 0;
+   int rc = check_scan_args(c, plan, "mmh_scan");
+   if (rc != MMH_OK) {
+      return rc;
+   }
+   HIP_TRY(hipSetDevice(c->device));
+   const MmGeom g = scan_geometry(c, plan, block_bytes, big_endian);
+
+   rc = ensure_workspace(c, c->ws[0], std::max<uint64_t>(c->ws[0].out_cap, kInitialCap));
    if (rc != MMH_OK) {
       return rc;
    }
@@ -565,14 +632,7 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
    // pattern, candidate sets too dense, prefixes too long) go to the forward "dense" engine,
    // whose cost is linear in the ROM.  1 / 2 force the sequential / dense engine (tests).
    enum { FAST, SEQUENTIAL, DENSE } mode = c->engine == 1 ? SEQUENTIAL : (c->engine == 2 || !have_filter) ? DENSE : FAST;
-   // More candidates than this and the forward engine (cost linear in the ROM: ~6 ms per GiB)
-   // is the better deal: the resolvers take ~2-10 ns per candidate (measured: 65 K candidates
-   // of a 3-symbol keyword on 4 GiB add 0.14 ms, against 23 ms for the forward engine).
-   // Lists beyond kMaxRankSort entries are ordered by the radix sort of mm_sort.hip.
-   uint32_t max_candidates = 262144u;
-   if (const char *knob = getenv("MMOORE_MAX_CANDIDATES")) {
-      max_candidates = (uint32_t)std::min<unsigned long long>(strtoull(knob, nullptr, 10), c->cand_cap / 2);
-   }
+   const uint32_t max_candidates = candidate_limit(c->ws[0]);
 
    Outcome oc;
    std::vector<uint64_t> long_list;
@@ -596,12 +656,12 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
       if (rc != MMH_OK) {
          return rc;
       }
-      if (mode == FAST && (oc.candidates > c->out_cap || oc.candidates > max_candidates || oc.hard_overflow)) {
+      if (mode == FAST && (oc.candidates > c->ws[0].out_cap || oc.candidates > max_candidates || oc.hard_overflow)) {
          mode = DENSE;                            // too dense / too long for the per-candidate resolvers
          continue;
       }
-      if (oc.listed > c->out_cap) {
-         rc = ensure_workspace(c, oc.listed + oc.listed / 8 + 1024);
+      if (oc.listed > c->ws[0].out_cap) {
+         rc = ensure_workspace(c, c->ws[0], oc.listed + oc.listed / 8 + 1024);
          if (rc != MMH_OK) {
             return rc;
          }
@@ -613,7 +673,7 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
    // lists too long for the rank kernels: radix sort on the device, "not a match" slots dropped
    // (search_engine.cpp:193-197 does a std::sort)
    if (!host_list && !oc.sorted_on_device) {
-      rc = sort_to_host(c, c->d_out, oc.listed, &long_list);
+      rc = sort_to_host(c, c->ws[0].d_out, oc.listed, &long_list);
       if (rc != MMH_OK) {
          return rc;
       }
@@ -638,8 +698,126 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
       std::memcpy(out, long_list.data(), oc.matches * sizeof(uint64_t));
    }
    else {
-      std::memcpy(out, c->h_result + kHeaderWords, oc.matches * sizeof(uint64_t));
+      std::memcpy(out, c->ws[0].h_result + kHeaderWords, oc.matches * sizeof(uint64_t));
    }
+   return MMH_OK;
+}
+
+// ---- two scans in flight ------------------------------------------------------------------
+//
+// mmh_scan_submit enqueues the filter + resolver pipeline of a scan on one of two lanes (own
+// stream, own workspace, own pinned result block) and returns; mmh_scan_collect waits for it.
+// With two lanes the host's share of a scan (launches, the wait, copying the offsets out) and
+// the small kernels behind the streaming filter overlap the NEXT scan's streaming kernel.
+// Anything the lanes do not run themselves -- forced engines, patterns without a SWAR key,
+// candidate floods, lists beyond the rank kernels -- is rescanned synchronously by collect.
+
+extern "C" int mmh_scan_submit(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian,
+                               uint64_t base_offset, int *ticket)
+{
+   if (!c || !plan || !ticket) {
+      mmh_set_error("mmh_scan_submit: bad argument");
+      return MMH_E_ARG;
+   }
+   int rc = check_scan_args(c, plan, "mmh_scan_submit");
+   if (rc != MMH_OK) {
+      return rc;
+   }
+   const int lane = c->next_ticket & 1;
+   MmPending &p = c->pending[lane];
+   if (p.active) {
+      mmh_set_error("mmh_scan_submit: two scans are already outstanding, collect ticket %d first", p.ticket);
+      return MMH_E_STATE;
+   }
+   HIP_TRY(hipSetDevice(c->device));
+   MmWorkspace &w = c->ws[1 + lane];
+   rc = ensure_workspace(c, w, std::max<uint64_t>(w.out_cap, kInitialCap));
+   if (rc != MMH_OK) {
+      return rc;
+   }
+   if (!c->lane_stream[lane]) {
+      HIP_TRY(hipStreamCreateWithFlags(&c->lane_stream[lane], hipStreamNonBlocking));
+   }
+   if (!c->lane_fence) {
+      HIP_TRY(hipEventCreateWithFlags(&c->lane_fence, hipEventDisableTiming));
+   }
+   p = MmPending();
+   p.ticket = c->next_ticket;
+   p.plan = *plan;
+   p.block_bytes = block_bytes;
+   p.big_endian = big_endian;
+   p.base_offset = base_offset;
+   p.max_candidates = candidate_limit(w);
+
+   const MmGeom g = scan_geometry(c, plan, block_bytes, big_endian);
+   mm::FilterChoice fc;
+   const bool have_filter = mm::choose_filter(*plan, &fc);
+   if (c->engine != 0 || !have_filter || g.nbytes == 0) {
+      p.needs_rescan = true;                    // collect runs mmh_scan
+   }
+   else {
+      // the ROM may still be in the making on the context's stream (upload, synth, poke)
+      HIP_TRY(hipEventRecord(c->lane_fence, c->stream));
+      HIP_TRY(hipStreamWaitEvent(c->lane_stream[lane], c->lane_fence, 0));
+      // (Making this lane's filter wait for the other lane's filter event was tried: 766 us per
+      // scan instead of 721 -- the hardware interleaves the two queues better on its own.)
+      begin_scan_events(c, true);
+      c->scans_recorded++;
+      p.ev = c->ev;
+      rc = enqueue_pipeline(c, w, c->lane_stream[lane], p.ev, g, *plan, fc, false, base_offset, p.max_candidates);
+      if (rc != MMH_OK) {
+         return rc;
+      }
+   }
+   p.active = true;
+   *ticket = c->next_ticket++;
+   return MMH_OK;
+}
+
+extern "C" int mmh_scan_collect(mmh_ctx *c, int ticket, uint64_t *out, uint64_t cap, uint64_t *out_count)
+{
+   if (!c || !out_count || (!out && cap)) {
+      mmh_set_error("mmh_scan_collect: bad argument");
+      return MMH_E_ARG;
+   }
+   *out_count = 0;
+   MmPending &p = c->pending[ticket & 1];
+   if (!p.active || p.ticket != ticket) {
+      mmh_set_error("mmh_scan_collect: ticket %d is not outstanding", ticket);
+      return MMH_E_STATE;
+   }
+   HIP_TRY(hipSetDevice(c->device));
+   bool rescan = p.needs_rescan;
+   Outcome oc;
+   MmWorkspace &w = c->ws[1 + (ticket & 1)];
+   if (!rescan) {
+      int rc = finish_pipeline(w, p.ev, false, &oc);
+      if (rc != MMH_OK) {
+         p.active = false;
+         return rc;
+      }
+      rescan = oc.candidates > w.out_cap || oc.candidates > p.max_candidates || oc.hard_overflow || !oc.sorted_on_device;
+   }
+   if (rescan) {
+      // (the ticket stays outstanding when the caller's buffer turns out too small: collect again)
+      int rc = mmh_scan(c, &p.plan, p.block_bytes, p.big_endian, p.base_offset, out, cap, out_count);
+      if (rc != MMH_E_CAPACITY) {
+         p.active = false;
+      }
+      return rc;
+   }
+   c->counters[0] = oc.candidates;
+   c->counters[1] = oc.matches;
+   c->counters[2] = oc.tiles;
+   c->counters[3] = oc.hard ? 2 : 0;
+   *out_count = oc.matches;
+   if (oc.matches > cap) {
+      mmh_set_error("mmh_scan_collect: %llu matches do not fit the caller's buffer of %llu (collect again)",
+                    (unsigned long long)oc.matches, (unsigned long long)cap);
+      return MMH_E_CAPACITY;                    // results stay in the lane's pinned block
+   }
+   std::memcpy(out, w.h_result + kHeaderWords, oc.matches * sizeof(uint64_t));
+   p.active = false;
    return MMH_OK;
 }
 

@@ -8,6 +8,8 @@
 
 #include <vector>
 
+#include "mmoore_hip.h"
+
 // pinned staging of mmh_rom_load_file (mm_ingest.hip): two pieces per reader thread
 struct MmIngest {
    static constexpr size_t kPiece = 4u << 20;
@@ -19,15 +21,9 @@ struct MmIngest {
    int last_threads = 0;
 };
 
-struct mmh_ctx {
-   int device = 0;
-   hipStream_t own_stream = nullptr;
-   hipStream_t stream = nullptr;
-
-   uint8_t *rom = nullptr;
-   uint64_t rom_bytes = 0;
-   uint64_t rom_alloc = 0;          // > 0 when the library owns the buffer
-
+// Device buffers of ONE scan in flight (see mm::ResolveBuffers) plus the pinned host block its
+// results are published in.
+struct MmWorkspace {
    uint64_t *d_cand = nullptr;      // candidate byte offsets
    uint64_t cand_cap = 0;
    uint64_t *d_out = nullptr;       // unordered matches
@@ -43,6 +39,33 @@ struct mmh_ctx {
    uint32_t *d_hard_slot = nullptr;
    uint8_t *d_scratch = nullptr;    // tile maps of hard candidates
    uint32_t *d_partials = nullptr;  // rank sort partial counts
+   uint64_t *h_result = nullptr;    // pinned: [kHeaderWords counters][kMaxRankSort ordered matches], written by the device
+   bool ctrl_clean = false;         // the previous scan's last kernel left d_ctrl zeroed
+};
+
+// a scan submitted with mmh_scan_submit and not collected yet
+struct MmPending {
+   bool active = false;
+   bool needs_rescan = false;       // plan / engine choice the lanes do not run: collect scans synchronously
+   int ticket = 0;
+   mmh_plan_desc plan{};
+   uint64_t block_bytes = 0;
+   int big_endian = 0;
+   uint64_t base_offset = 0;
+   uint32_t max_candidates = 0;
+   hipEvent_t *ev = nullptr;        // its event triple in the ring
+};
+
+struct mmh_ctx {
+   int device = 0;
+   hipStream_t own_stream = nullptr;
+   hipStream_t stream = nullptr;
+
+   uint8_t *rom = nullptr;
+   uint64_t rom_bytes = 0;
+   uint64_t rom_alloc = 0;          // > 0 when the library owns the buffer
+
+   MmWorkspace ws[3];               // [0] mmh_scan; [1], [2] the two lanes of mmh_scan_submit / _collect
    uint8_t *d_dense = nullptr;      // dense engine: tile maps, super-tile maps, entry phases (one allocation)
    size_t dense_bytes = 0;
    uint64_t *d_sort_in = nullptr;   // long lists: contiguous keys (dense engine), ordered keys, rocPRIM scratch
@@ -51,7 +74,6 @@ struct mmh_ctx {
    uint64_t sort_out_cap = 0;
    void *d_sort_tmp = nullptr;
    size_t sort_tmp_bytes = 0;
-   uint64_t *h_result = nullptr;    // pinned: [kHeaderWords counters][kMaxRankSort ordered matches], written by the device
 
    // Ring of event triples {scan start, behind the streaming kernel, scan end}: elapsed
    // times are only computed when somebody asks (mmh_last_timings / mmh_timing_history),
@@ -61,7 +83,10 @@ struct mmh_ctx {
    bool ring_has_filter[kRing] = {};
    uint64_t scans_recorded = 0;     // slot of scan k is k % kRing
    hipEvent_t *ev = nullptr;        // the current scan's triple
-   bool ctrl_clean = false;         // the previous scan's last kernel left d_ctrl zeroed
+   hipStream_t lane_stream[2] = {nullptr, nullptr};   // streams of the submit lanes
+   hipEvent_t lane_fence = nullptr;                     // orders a lane behind earlier work on `stream`
+   MmPending pending[2];
+   int next_ticket = 0;
    int engine = 0;
    uint64_t counters[4] = {0, 0, 0, 0};
    MmIngest ingest;

@@ -207,7 +207,7 @@ extern "C" int mmh_rom_gather(mmh_ctx *c, const uint64_t *offsets, uint64_t n, u
       return rc;
    }
    // scan workspace doubles as staging: d_out takes the offsets, d_cand the packed bytes
-   const uint64_t batch = std::min<uint64_t>(c->out_cap, c->cand_cap * sizeof(uint64_t) / bytes_each);
+   const uint64_t batch = std::min<uint64_t>(c->ws[0].out_cap, c->ws[0].cand_cap * sizeof(uint64_t) / bytes_each);
    if (batch == 0) {
       mmh_set_error("mmh_rom_gather: %u bytes per offset is too much", bytes_each);
       return MMH_E_ARG;
@@ -215,13 +215,13 @@ extern "C" int mmh_rom_gather(mmh_ctx *c, const uint64_t *offsets, uint64_t n, u
    uint8_t *out = static_cast<uint8_t *>(host_out);
    for (uint64_t first = 0; first < n; first += batch) {
       const uint64_t m = std::min(batch, n - first);
-      if (hipMemcpyAsync(c->d_out, offsets + first, m * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+      if (hipMemcpyAsync(c->ws[0].d_out, offsets + first, m * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream) != hipSuccess) {
          mmh_set_error("mmh_rom_gather: offset upload failed");
          return MMH_E_DEVICE;
       }
-      mm::launch_gather(c->stream, c->rom, c->rom_bytes, c->d_out, m, bytes_each, reinterpret_cast<uint8_t *>(c->d_cand));
+      mm::launch_gather(c->stream, c->rom, c->rom_bytes, c->ws[0].d_out, m, bytes_each, reinterpret_cast<uint8_t *>(c->ws[0].d_cand));
       if (hipGetLastError() != hipSuccess ||
-          hipMemcpyAsync(out + first * bytes_each, c->d_cand, m * bytes_each, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+          hipMemcpyAsync(out + first * bytes_each, c->ws[0].d_cand, m * bytes_each, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
           hipStreamSynchronize(c->stream) != hipSuccess) {
          mmh_set_error("mmh_rom_gather: device gather failed");
          return MMH_E_DEVICE;

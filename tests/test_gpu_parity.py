@@ -364,3 +364,42 @@ def test_rom_from_file_and_gather(mm, gpu_engine, oracle, tmp_path):
         gpu_engine.load_file(str(tmp_path / "missing.bin"), 0, 16)
     with pytest.raises(mm.MMError):
         gpu_engine.load_file(str(path), data.size - 10, 100)  # runs off the end of the file: short read
+
+
+def test_two_scans_in_flight(mm, gpu_engine, oracle):
+    # mmh_scan_submit / mmh_scan_collect: same offsets as mmh_scan, two tickets outstanding at a
+    # time, different plans interleaved on the same ROM; the paths the lanes do not run themselves
+    # (no SWAR key -> dense engine, long match lists) come back through the synchronous rescan
+    rng = np.random.default_rng(31)
+    kws = [("relativesrch", 0), ("re*at*vesrch", ord("*")), ("a**d**g", ord("*")), ("words", 0)]
+    rom = rng.integers(0, 256, 24 << 20).astype(np.uint8)
+    for n, (kw, wc) in enumerate(kws):
+        vals = [None if ch == "*" else ord(ch) for ch in kw]
+        planted = _random_rom_with_plants(rng, 1 << 20, 1, vals, False, nplants=300 if kw != "words" else 20000)
+        at = (5 * n + 2) << 20
+        rom[at:at + planted.size] = planted
+    gpu_engine.upload(rom)
+    plans = [mm.plan_relative(1, kw, wc) for kw, wc in kws]
+    want = [gpu_engine.scan(p, block_bytes=524288, cap=1 << 16).tolist() for p in plans]
+    assert want[0] == oracle.engine(oracle.plan(1, kws[0][0]), rom, 524288).tolist()
+    assert len(want[3]) > 16384 and all(len(w) > 20 for w in want), [len(w) for w in want]
+    order = [0, 1, 2, 3, 3, 0, 2, 1, 0, 0, 1]
+    tickets, got = [], []
+    for k in order:
+        tickets.append((k, gpu_engine.submit(plans[k], block_bytes=524288)))
+        if len(tickets) == 2:
+            i, t = tickets.pop(0)
+            got.append((i, gpu_engine.collect(t, cap=1000).tolist()))      # cap too small now and then: retried
+    extra = gpu_engine.submit(plans[0], block_bytes=524288)
+    with pytest.raises(mm.MMError):
+        gpu_engine.submit(plans[0], block_bytes=524288)                    # a third outstanding scan is refused
+    tickets.append((0, extra))
+    order = order + [0]
+    while tickets:
+        i, t = tickets.pop(0)
+        got.append((i, gpu_engine.collect(t).tolist()))
+    with pytest.raises(mm.MMError):
+        gpu_engine.collect(12345)
+    assert [i for i, _ in got] == order
+    for i, offs in got:
+        assert offs == want[i], kws[i]
