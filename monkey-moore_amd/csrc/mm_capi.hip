@@ -593,11 +593,7 @@ MmGeom scan_geometry(const mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block
 // Lists beyond kMaxRankSort entries are ordered by the radix sort of mm_sort.hip.
 uint32_t candidate_limit(const MmWorkspace &w)
 {
-   uint32_t limit = 262144u;
-   if (const char *knob = getenv("MMOORE_MAX_CANDIDATES")) {
-      limit = (uint32_t)std::min<unsigned long long>(strtoull(knob, nullptr, 10), w.cand_cap / 2);
-   }
-   return limit;
+   return (uint32_t)std::min<uint64_t>(mm::tuning().max_candidates, w.cand_cap / 2);
 }
 
 } // namespace

@@ -8,6 +8,15 @@
 
 namespace mm {
 
+struct Tuning {
+   int filter_max_conditions;        // MMOORE_FILTER_MAXCOND   (4)
+   uint64_t filter_blocks;           // MMOORE_FILTER_BLOCKS    (2048 workgroups)
+   uint32_t filter_groups_per_span;  // MMOORE_FILTER_GPS       (8 groups of 4 KiB)
+   unsigned resolve_blocks;          // MMOORE_RESOLVE_BLOCKS   (4096 workgroups)
+   uint32_t max_candidates;          // MMOORE_MAX_CANDIDATES   (262144 per scan)
+};
+const Tuning &tuning();
+
 struct FilterChoice {
    uint32_t ncond;     // 0 = no usable SWAR condition (no literal with a literal one or two to its left)
    uint32_t iA;        // keyword position whose delta is condition 0 (the anchor)

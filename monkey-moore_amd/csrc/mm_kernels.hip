@@ -888,6 +888,26 @@ __global__ __launch_bounds__(256) void mm_gather(const uint8_t *rom, uint64_t nb
 
 namespace mm {
 
+// Experiment knobs, read once per process.  They exist for the tuning probes under tools/
+// (launch geometry sweeps, condition-count sweeps); production runs leave them unset.
+const Tuning &tuning()
+{
+   static const Tuning t = [] {
+      auto number = [](const char *name, long fallback) {
+         const char *v = getenv(name);
+         return v && *v ? std::max(1L, atol(v)) : fallback;
+      };
+      Tuning k;
+      k.filter_max_conditions = (int)number("MMOORE_FILTER_MAXCOND", 4);
+      k.filter_blocks = (uint64_t)number("MMOORE_FILTER_BLOCKS", 256 * 8);
+      k.filter_groups_per_span = (uint32_t)number("MMOORE_FILTER_GPS", 8);
+      k.resolve_blocks = (unsigned)number("MMOORE_RESOLVE_BLOCKS", 4096);
+      k.max_candidates = (uint32_t)number("MMOORE_MAX_CANDIDATES", 262144);
+      return k;
+   }();
+   return t;
+}
+
 // Picks the SWAR conditions of a plan: an anchor position iA (condition 0) and up to three
 // more literal positions to its left, each compared with its left neighbour (gap 1) or, over
 // one wildcard, with the literal two to the left (gap 2 = bridge -2 of the plan).  Condition k
@@ -909,10 +929,7 @@ bool choose_filter(const mmh_plan_desc &pl, FilterChoice *fc)
       const int g = -(int)pl.bridge[i];
       return (g == 1 || g == 2) && i - g >= 0 ? g : 0;
    };
-   int want = u8 ? 4 : 2;
-   if (const char *knob = getenv("MMOORE_FILTER_MAXCOND")) {      // tuning / experiments only
-      want = std::max(1, std::min(want, atoi(knob)));
-   }
+   const int want = std::min(u8 ? 4 : 2, tuning().filter_max_conditions);
    FilterChoice best;
    best.ncond = 0;
    bool best_contiguous = false;
@@ -997,23 +1014,8 @@ bool filter_verifies(const mmh_plan_desc &pl, const FilterChoice &fc)
 // kernels' <= 64 VGPRs; a wave streams spans of 8 groups = 32 KiB.  Measured on 4 GiB (u8):
 // spans of 4 / 8 / 16 / 32 groups -> 0.732 / 0.695 / 0.711 / 0.712 ms; 1024 .. 4096 workgroups
 // are within 0.5 % of each other.  The environment knobs are for such experiments only.
-static uint64_t filter_max_blocks()
-{
-   static const uint64_t v = [] {
-      const char *knob = getenv("MMOORE_FILTER_BLOCKS");
-      return knob ? (uint64_t)std::max(1, atoi(knob)) : (uint64_t)256 * 8;
-   }();
-   return v;
-}
-
-static uint32_t filter_groups_per_span()
-{
-   static const uint32_t v = [] {
-      const char *knob = getenv("MMOORE_FILTER_GPS");
-      return knob ? (uint32_t)std::max(1, atoi(knob)) : 8u;
-   }();
-   return v;
-}
+static uint64_t filter_max_blocks() { return tuning().filter_blocks; }
+static uint32_t filter_groups_per_span() { return tuning().filter_groups_per_span; }
 
 template <int SHAPE>
 static void launch_filter_u8(hipStream_t st, const MmFilterArgs &a, const MmGeom &g)
@@ -1134,11 +1136,7 @@ void launch_resolve(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, co
    a.base_offset = base_offset; a.max_candidates = max_candidates;
    a.mid_off = rb.mid_off; a.mid_hi = rb.mid_hi; a.mid_set = rb.mid_set; a.mid_slot = rb.mid_slot;
    a.mid_count = reinterpret_cast<unsigned int *>(rb.ctrl + MM_CTRL_MID);
-   static const unsigned resolve_blocks = [] {
-      const char *knob = getenv("MMOORE_RESOLVE_BLOCKS");      // experiments only
-      return knob ? (unsigned)std::max(1, atoi(knob)) : 4096u;
-   }();
-   hipLaunchKernelGGL(mm_resolve, dim3(resolve_blocks), dim3(64 * MM_WAVES), 0, st, a);
+   hipLaunchKernelGGL(mm_resolve, dim3(tuning().resolve_blocks), dim3(64 * MM_WAVES), 0, st, a);
 
    MmResolve2Args m;
    m.t = a.t;
