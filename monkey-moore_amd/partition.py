@@ -18,34 +18,71 @@ def shard_range(total_bytes, block_bytes, keyword_len, elem_bytes, rank, world):
     return first, max(end - first, 0)
 
 
+_buffers = {}
+
+
+def _gather_buffers(world, device, width):
+    """Staging reused from step to step: a (pinned, on GPUs) host record, its device copy and
+    the world x width table the collective fills."""
+    import torch
+    key = (world, str(device), width)
+    b = _buffers.get(key)
+    if b is None:
+        host = torch.zeros(width, dtype=torch.int64)
+        if device.type == "cuda":
+            host = host.pin_memory()
+        b = _buffers[key] = dict(host=host, view=host.numpy(),
+                                 rec=torch.zeros(width, dtype=torch.int64, device=device),
+                                 table=torch.zeros(world * width, dtype=torch.int64, device=device), flat_ok=True)
+    return b
+
+
+def _all_gather(dist, b, world, width):
+    """One collective into the contiguous table (falls back to the list form where the
+    backend has no all_gather_into_tensor)."""
+    if b["flat_ok"]:
+        try:
+            dist.all_gather_into_tensor(b["table"], b["rec"])
+            return
+        except (RuntimeError, NotImplementedError, AttributeError):
+            b["flat_ok"] = False
+    dist.all_gather(list(b["table"].view(world, width).unbind(0)), b["rec"])
+
+
 def gather_offsets(offsets, rank, world, device, dist):
     """All ranks call this with their ascending uint64 offsets (already global).  Rank 0
     gets the concatenation in rank order (= globally ascending), the others get None.
 
     The payload is tiny and latency-bound (8 B per match), so the common case is ONE
     collective: an all_gather of fixed-width records [count, offsets...] (64 KiB per rank;
-    on the 8-GPU xGMI mesh every peer is one hop away).  Every rank sees every count, so
-    all ranks agree without further traffic on whether some list did not fit; only then a
-    second, padded all_gather of the full lists follows."""
+    on the 8-GPU xGMI mesh every peer is one hop away) into one contiguous table, followed by
+    ONE device-to-host copy per rank (the counts column; on rank 0 the whole table).  Every
+    rank sees every count, so all ranks agree without further traffic on whether some list did
+    not fit; only then a second, padded all_gather of the full lists follows."""
     import torch
+    width = GATHER_WIDTH
     mine = np.ascontiguousarray(offsets).astype(np.int64)
-    record = np.zeros(GATHER_WIDTH, np.int64)
-    record[0] = mine.size
-    k = min(mine.size, GATHER_WIDTH - 1)
-    record[1:1 + k] = mine[:k]
-    rec = torch.from_numpy(record).to(device)
-    records = [torch.empty(GATHER_WIDTH, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(records, rec)
-    counts = torch.stack([r[0] for r in records]).cpu().numpy()      # every rank: 8 B per peer
-    if int(counts.max()) <= GATHER_WIDTH - 1:
+    b = _gather_buffers(world, device, width)
+    k = min(mine.size, width - 1)
+    b["view"][0] = mine.size
+    b["view"][1:1 + k] = mine[:k]
+    b["rec"].copy_(b["host"], non_blocking=True)          # stream ordered before the collective
+    _all_gather(dist, b, world, width)
+    table = b["table"].view(world, width)
+    if rank == 0:
+        host_table = table.cpu().numpy()
+        counts = host_table[:, 0].copy()
+    else:
+        host_table = None
+        counts = table[:, 0].cpu().numpy()                # every rank: 8 B per peer
+    if int(counts.max()) <= width - 1:
         if rank != 0:
             return None
-        table = torch.stack(records).cpu().numpy()
-        return np.concatenate([table[r, 1:1 + counts[r]] for r in range(world)]).astype(np.uint64)
-    width = int(counts.max())
-    padded = torch.zeros(width, dtype=torch.int64, device=device)
+        return np.concatenate([host_table[r, 1:1 + counts[r]] for r in range(world)]).astype(np.uint64)
+    longest = int(counts.max())
+    padded = torch.zeros(longest, dtype=torch.int64, device=device)
     padded[: mine.size] = torch.from_numpy(mine).to(device)
-    full = [torch.empty(width, dtype=torch.int64, device=device) for _ in range(world)]
+    full = [torch.empty(longest, dtype=torch.int64, device=device) for _ in range(world)]
     dist.all_gather(full, padded)
     if rank != 0:
         return None

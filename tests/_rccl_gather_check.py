@@ -1,0 +1,34 @@
+"""Run by test_gpu_parity.py::test_offset_gather_on_rccl_world_of_one in a fresh process."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29571")
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+from conftest import load_package  # noqa: E402
+
+mm = load_package()
+try:
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 4223, mm.partition.GATHER_WIDTH - 1, mm.partition.GATHER_WIDTH + 5000):
+        offs = np.sort(rng.choice(1 << 40, size=n, replace=False)).astype(np.uint64)
+        got = mm.partition.gather_offsets(offs, 0, 1, dev, dist)
+        assert got.dtype == np.uint64 and got.tolist() == offs.tolist(), n
+    # and the engine next to torch, the way bench.py sets it up
+    eng = mm.Engine(0)
+    buf = torch.zeros((1 << 20) + 32, dtype=torch.uint8, device=dev)
+    eng.attach(buf.data_ptr(), 1 << 20)
+    eng.synth(7)
+    assert len(eng.scan(mm.plan_relative(1, "ab"), block_bytes=65536)) > 0
+    print("gather ok")
+finally:
+    dist.destroy_process_group()

@@ -1,6 +1,8 @@
 """Parity of the HIP path (through the C ABI) with the oracle and the golden
 vectors.  Needs a real MI355X: run with `pytest -m gpu`.  Offsets are compared
 bit-exactly (integer work: no tolerance)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -403,3 +405,17 @@ def test_two_scans_in_flight(mm, gpu_engine, oracle):
     assert [i for i, _ in got] == order
     for i, offs in got:
         assert offs == want[i], kws[i]
+
+
+def test_offset_gather_on_rccl_world_of_one():
+    # The collective plumbing bench.py uses at N > 1 (pinned staging, all_gather_into_tensor on
+    # RCCL, one device-to-host copy), exercised on the one GPU this suite has.  In its own
+    # process, torch first -- as in bench.py: torch brings its own HIP runtime, which finds no
+    # device once the system runtime behind libmmoore_hip.so has initialised the GPU.
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_gather_check.py")], capture_output=True, text=True,
+                       timeout=240)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "gather ok" in r.stdout
