@@ -56,9 +56,18 @@ def cpu_baseline(eng, spec_bytes, plan_kw, sample_bytes):
         finally:
             if os.path.exists(path):
                 os.unlink(path)
+        # per-core figure in the shape of the reference's own benchmark (SURVEY 8d ii):
+        # MonkeyMoore<uint8_t>::search, one thread, 16 MiB of its mt19937(42) buffer, keyword "abcde"
+        c1 = ref.bench_data(1, 16 << 20)
+        t0 = time.perf_counter()
+        ref.search(1, "abcde", c1)
+        single = (16 << 20) / (time.perf_counter() - t0) / 1e9
         return dict(value=sample_bytes / best / 1e9, unit="GB/s", cores=cores, kind="reference",
                     sample="first %d MiB of the bench ROM in a tmpfs file, SearchEngine<uint8_t>::run, %d threads, "
-                           "512 KiB blocks, best of 2" % (sample_bytes >> 20, cores)), offs, sample_bytes
+                           "512 KiB blocks, best of 2" % (sample_bytes >> 20, cores),
+                    single_thread_GBps=single,
+                    single_thread_sample="MonkeyMoore<uint8_t>::search, 1 thread, 16 MiB mt19937(42) buffer, keyword 'abcde' "
+                                         "(benchmarks/bench_search.cpp shape)"), offs, sample_bytes
     orc = Oracle()
     t0 = time.perf_counter()
     offs = orc.engine(orc.plan(1, plan_kw), rom, BLOCK)
@@ -224,6 +233,10 @@ def main():
                 "algorithmic_bytes": shard,
                 "kernel_ms": filt,
                 "scan_device_ms": float(np.mean(tot_ms)),
+                "scan_device_ms_median": float(np.median(tot_ms)),
+                "scan_device_ms_min": float(np.min(tot_ms)),
+                "kernel_ms_median": float(np.median(filt_ms)),
+                "kernel_ms_min": float(np.min(filt_ms)),
             },
             "stages_ms": {"filter": filt, "resolve_order_publish": float(np.mean(post_ms)),
                           "device_total": float(np.mean(tot_ms)), "host_wall_per_step": elapsed / args.steps * 1e3},

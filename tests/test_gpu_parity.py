@@ -419,3 +419,31 @@ def test_offset_gather_on_rccl_world_of_one():
                        timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "gather ok" in r.stdout
+
+
+def test_synthetic_rom_goldens_on_device(mm, gpu_engine):
+    # ROMs generated ON THE DEVICE (mm_synth_fill + pokes) hash to the golden file's
+    # SHA-256 and scan to the offsets the compiled reference reported for them
+    import hashlib
+    from _oracle import Ref
+    for c in load_golden("synth_roms.json"):
+        if c.get("bench_data"):
+            # C1: the reference benchmark's own buffer (its generator lives in the compiled reference shim)
+            if not Ref.available():
+                continue
+            data = Ref().bench_data(c["elem_bytes"], c["nbytes"])
+            assert hashlib.sha256(data.tobytes()).hexdigest() == c["sha256"], c["name"]
+            gpu_engine.upload(data)
+            for kw, want in c["search"].items():
+                assert gpu_engine.scan(mm.plan_relative(c["elem_bytes"], kw)).tolist() == want, (c["name"], kw)
+            continue
+        spec = mm.synth.RomSpec(c["seed"], c["nbytes"], c["keyword"], c["elem_bytes"], c["wildcard"], c["big_endian"], 524288)
+        gpu_engine.alloc(c["nbytes"])
+        spec.apply_device(gpu_engine)
+        assert hashlib.sha256(gpu_engine.download(0, c["nbytes"]).tobytes()).hexdigest() == c["sha256"], c["name"]
+        plan = mm.plan_relative(c["elem_bytes"], c["keyword"], c["wildcard"] or 0)
+        for block, want in c["engine"].items():
+            got = _scan_both(gpu_engine, plan, block_bytes=int(block), big_endian=c["big_endian"])
+            assert got.tolist() == want, (c["name"], block)
+        if "whole_buffer" in c:
+            assert gpu_engine.scan(plan).tolist() == c["whole_buffer"], c["name"]
