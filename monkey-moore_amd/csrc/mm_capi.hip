@@ -382,22 +382,19 @@ int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev,
       HIP_TRY(hipMemsetAsync(w.d_ctrl, 0, mm::ctrl_bytes(), st));
    }
    w.ctrl_clean = false;
-   // Only two events inside a scan (around the streaming kernel): every hipEventRecord
-   // between dependent kernels costs ~6 us of stream time on this stack.
-   HIP_TRY(hipEventRecord(ev[0], st));
+   // The scan's three events ride on kernel dispatches (hipExtLaunchKernelGGL) where they can:
+   // a hipEventRecord between dependent kernels costs ~6 us of stream time on this stack.
    if (!sequential) {
-      mm::launch_filter(st, g, pl, fc, w.d_cand, w.d_ctrl, w.cand_cap);
-   }
-   HIP_TRY(hipEventRecord(ev[1], st));
-   if (!sequential) {
+      mm::launch_filter(st, g, pl, fc, w.d_cand, w.d_ctrl, w.cand_cap, ev[0], ev[1]);
       mm::launch_resolve(st, g, pl, rb, base_offset, max_candidates);
    }
    else {
+      HIP_TRY(hipEventRecord(ev[0], st));
+      HIP_TRY(hipEventRecord(ev[1], st));
       mm::launch_chain_seq(st, g, pl, w.d_out, w.d_ctrl + 1, w.out_cap, base_offset);
    }
-   mm::launch_rank_sort(st, w.d_out, w.d_ctrl, count_index, w.out_cap, kMaxRankSort, w.d_partials, w.h_result);
+   mm::launch_rank_sort(st, w.d_out, w.d_ctrl, count_index, w.out_cap, kMaxRankSort, w.d_partials, w.h_result, ev[2]);
    HIP_TRY(hipGetLastError());
-   HIP_TRY(hipEventRecord(ev[2], st));
    (void)c;
    return MMH_OK;
 }

@@ -31,8 +31,10 @@ bool choose_filter(const mmh_plan_desc &pl, FilterChoice *fc);
 // true: the filter kernel runs the full compare loop on its survivors; false: mm_resolve does
 bool filter_verifies(const mmh_plan_desc &pl, const FilterChoice &fc);
 
+// start / stop (optional): HIP events carried by the first / last filter kernel's own dispatch
 void launch_filter(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc,
-                   uint64_t *cand, unsigned long long *ctrl, uint64_t cand_cap);
+                   uint64_t *cand, unsigned long long *ctrl, uint64_t cand_cap, hipEvent_t start = nullptr,
+                   hipEvent_t stop = nullptr);
 
 // Device buffers of one scan.  ctrl is zeroed before every scan; layout: MM_CTRL_* in
 // mm_internal.h.  cand holds MM_CAND_LISTS candidate lists of cand_cap / MM_CAND_LISTS entries.
@@ -83,7 +85,7 @@ void launch_chain_seq(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, 
 // orders the ctrl[count_index] keys of `in` into host_result[8..] (pinned host memory),
 // publishes the counters in host_result[0..8) and leaves ctrl zeroed; see mm_rank_scatter
 void launch_rank_sort(hipStream_t st, const uint64_t *in, unsigned long long *ctrl, int count_index, uint64_t cap,
-                      uint32_t max_n, uint32_t *partials, uint64_t *host_result);
+                      uint32_t max_n, uint32_t *partials, uint64_t *host_result, hipEvent_t stop = nullptr);
 // ascending order of n 64-bit keys (mm_sort.hip, rocPRIM radix sort); in and out must not overlap
 size_t sort_temp_bytes(uint64_t n);
 hipError_t sort_keys(hipStream_t st, const uint64_t *in, uint64_t *out, uint64_t n, void *temp, size_t temp_bytes);

@@ -22,6 +22,7 @@
 //
 // No MFMA anywhere: the path is integer byte comparison (BASELINE.json).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cstdlib>
@@ -1017,48 +1018,63 @@ bool filter_verifies(const mmh_plan_desc &pl, const FilterChoice &fc)
 static uint64_t filter_max_blocks() { return tuning().filter_blocks; }
 static uint32_t filter_groups_per_span() { return tuning().filter_groups_per_span; }
 
-template <int SHAPE>
-static void launch_filter_u8(hipStream_t st, const MmFilterArgs &a, const MmGeom &g)
+// Kernel launch with optional HIP events riding on the dispatch itself (hipExtLaunchKernelGGL):
+// `start` / `stop` take the kernel's begin / end time stamps without the separate marker
+// packets of hipEventRecord, which cost ~6 us of stream time each between dependent kernels.
+template <class Kernel, class Args>
+static void launch_timed(Kernel kernel, dim3 grid, dim3 block, hipStream_t st, hipEvent_t start, hipEvent_t stop, const Args &a)
 {
-   if (a.ngroups) {
+   if (start || stop) {
+      hipExtLaunchKernelGGL(kernel, grid, block, 0, st, start, stop, 0, a);
+   }
+   else {
+      hipLaunchKernelGGL(kernel, grid, block, 0, st, a);
+   }
+}
+
+// span kernel over the whole 4 KiB groups + bounds-checked edge kernel over the ragged end:
+// `start` goes to whichever runs first, `stop` to whichever runs last
+template <class Span, class Edge>
+static void launch_filter_pair(Span span, Edge edge, hipStream_t st, const MmFilterArgs &a, const MmGeom &g, hipEvent_t start,
+                               hipEvent_t stop)
+{
+   const bool have_span = a.ngroups != 0;
+   const bool have_edge = a.edge_first * 16 < g.nbytes;
+   if (have_span) {
       uint64_t spans = (a.ngroups + a.groups_per_span - 1) / a.groups_per_span;
       uint64_t blocks = (spans + 3) / 4;
       if (blocks > filter_max_blocks()) {
          blocks = filter_max_blocks();
       }
-      hipLaunchKernelGGL(mm_filter_u8<SHAPE>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+      launch_timed(span, dim3((unsigned)blocks), dim3(256), st, start, have_edge ? nullptr : stop, a);
    }
-   if (a.edge_first * 16 < g.nbytes) {
-      hipLaunchKernelGGL(mm_filter_u8_edge<SHAPE>, dim3(1), dim3(256), 0, st, a);
+   if (have_edge) {
+      launch_timed(edge, dim3(1), dim3(256), st, have_span ? nullptr : start, stop, a);
    }
 }
 
 template <int SHAPE>
-static void launch_filter_u16(hipStream_t st, const MmFilterArgs &a, const MmGeom &g)
+static void launch_filter_u8(hipStream_t st, const MmFilterArgs &a, const MmGeom &g, hipEvent_t start, hipEvent_t stop)
 {
-   if (a.ngroups) {
-      uint64_t spans = (a.ngroups + a.groups_per_span - 1) / a.groups_per_span;
-      uint64_t blocks = (spans + 3) / 4;
-      if (blocks > filter_max_blocks()) {
-         blocks = filter_max_blocks();
-      }
-      hipLaunchKernelGGL(mm_filter_u16<SHAPE>, dim3((unsigned)blocks), dim3(256), 0, st, a);
-   }
-   if (a.edge_first * 16 < g.nbytes) {
-      hipLaunchKernelGGL(mm_filter_u16_edge<SHAPE>, dim3(1), dim3(256), 0, st, a);
-   }
+   launch_filter_pair(mm_filter_u8<SHAPE>, mm_filter_u8_edge<SHAPE>, st, a, g, start, stop);
+}
+
+template <int SHAPE>
+static void launch_filter_u16(hipStream_t st, const MmFilterArgs &a, const MmGeom &g, hipEvent_t start, hipEvent_t stop)
+{
+   launch_filter_pair(mm_filter_u16<SHAPE>, mm_filter_u16_edge<SHAPE>, st, a, g, start, stop);
 }
 
 // run-time-shift shapes of NC conditions: one instantiation per gap mask
 template <int NC, int... M2>
 static bool launch_filter_u8_masks(uint32_t mask2, std::integer_sequence<int, M2...>, hipStream_t st, const MmFilterArgs &a,
-                                   const MmGeom &g)
+                                   const MmGeom &g, hipEvent_t start, hipEvent_t stop)
 {
-   return ((mask2 == (uint32_t)M2 ? (launch_filter_u8<NC | (M2 << 4) | 0x100>(st, a, g), true) : false) || ...);
+   return ((mask2 == (uint32_t)M2 ? (launch_filter_u8<NC | (M2 << 4) | 0x100>(st, a, g, start, stop), true) : false) || ...);
 }
 
 void launch_filter(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc,
-                   uint64_t *cand, unsigned long long *ctrl, uint64_t cand_cap)
+                   uint64_t *cand, unsigned long long *ctrl, uint64_t cand_cap, hipEvent_t start, hipEvent_t stop)
 {
    MmFilterArgs a;
    a.g = g; a.plan = pl; a.iA = fc.iA; a.ncond = fc.ncond;
@@ -1077,31 +1093,31 @@ void launch_filter(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, con
       const uint32_t mask2 = MM_F8_MASK2(shape);
       if (!MM_F8_RT(shape)) {
          switch (fc.ncond) {
-         case 4: launch_filter_u8<4>(st, a, g); break;
-         case 3: launch_filter_u8<3>(st, a, g); break;
-         case 2: launch_filter_u8<2>(st, a, g); break;
-         default: launch_filter_u8<1>(st, a, g); break;
+         case 4: launch_filter_u8<4>(st, a, g, start, stop); break;
+         case 3: launch_filter_u8<3>(st, a, g, start, stop); break;
+         case 2: launch_filter_u8<2>(st, a, g, start, stop); break;
+         default: launch_filter_u8<1>(st, a, g, start, stop); break;
          }
       }
       else {
          switch (fc.ncond) {
-         case 4: launch_filter_u8_masks<4>(mask2, std::make_integer_sequence<int, 16>(), st, a, g); break;
-         case 3: launch_filter_u8_masks<3>(mask2, std::make_integer_sequence<int, 8>(), st, a, g); break;
-         case 2: launch_filter_u8_masks<2>(mask2, std::make_integer_sequence<int, 4>(), st, a, g); break;
-         default: launch_filter_u8_masks<1>(mask2, std::make_integer_sequence<int, 2>(), st, a, g); break;
+         case 4: launch_filter_u8_masks<4>(mask2, std::make_integer_sequence<int, 16>(), st, a, g, start, stop); break;
+         case 3: launch_filter_u8_masks<3>(mask2, std::make_integer_sequence<int, 8>(), st, a, g, start, stop); break;
+         case 2: launch_filter_u8_masks<2>(mask2, std::make_integer_sequence<int, 4>(), st, a, g, start, stop); break;
+         default: launch_filter_u8_masks<1>(mask2, std::make_integer_sequence<int, 2>(), st, a, g, start, stop); break;
          }
       }
    }
    else {
       switch (shape) {
-      case 1: launch_filter_u16<1>(st, a, g); break;
-      case 1 | 16: launch_filter_u16<1 | 16>(st, a, g); break;
-      case 2: launch_filter_u16<2>(st, a, g); break;
-      case 2 | 32: launch_filter_u16<2 | 32>(st, a, g); break;
-      case 2 | 16 | 64: launch_filter_u16<2 | 16 | 64>(st, a, g); break;
+      case 1: launch_filter_u16<1>(st, a, g, start, stop); break;
+      case 1 | 16: launch_filter_u16<1 | 16>(st, a, g, start, stop); break;
+      case 2: launch_filter_u16<2>(st, a, g, start, stop); break;
+      case 2 | 32: launch_filter_u16<2 | 32>(st, a, g, start, stop); break;
+      case 2 | 16 | 64: launch_filter_u16<2 | 16 | 64>(st, a, g, start, stop); break;
       default:
          // (gap-2 anchor with an adjacent second condition cannot occur: position iA-1 would be a wildcard)
-         launch_filter_u16<1>(st, a, g);
+         launch_filter_u16<1>(st, a, g, start, stop);
          break;
       }
    }
@@ -1216,12 +1232,19 @@ void launch_chain_seq(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, 
 }
 
 void launch_rank_sort(hipStream_t st, const uint64_t *in, unsigned long long *ctrl, int count_index, uint64_t cap,
-                      uint32_t max_n, uint32_t *partials, uint64_t *host_result)
+                      uint32_t max_n, uint32_t *partials, uint64_t *host_result, hipEvent_t stop)
 {
    hipLaunchKernelGGL(mm_rank_count, dim3(16, MM_RANK_SLICES), dim3(256), 0, st, in, ctrl + count_index, cap, max_n,
                       partials);
-   hipLaunchKernelGGL(mm_rank_scatter, dim3(64), dim3(256), 0, st, in, ctrl, count_index, cap, max_n, partials,
-                      host_result, (uint32_t)(ctrl_bytes() / sizeof(unsigned long long)));
+   const uint32_t ctrl_words = (uint32_t)(ctrl_bytes() / sizeof(unsigned long long));
+   if (stop) {
+      hipExtLaunchKernelGGL(mm_rank_scatter, dim3(64), dim3(256), 0, st, nullptr, stop, 0, in, ctrl, count_index, cap, max_n,
+                            partials, host_result, ctrl_words);
+   }
+   else {
+      hipLaunchKernelGGL(mm_rank_scatter, dim3(64), dim3(256), 0, st, in, ctrl, count_index, cap, max_n, partials,
+                         host_result, ctrl_words);
+   }
 }
 
 void launch_synth(hipStream_t st, uint8_t *rom, uint64_t nbytes, uint64_t seed, uint64_t base_offset)
