@@ -14,11 +14,11 @@
 //   mm_dense_tiles   per super-tile: walk its tile maps from that phase -> entry phase of
 //                    every tile
 //   mm_dense_emit    every tile again, now with its TRUE entry phase: jumps and match flags
-//                    of all positions in parallel (mm_tile_jumps), then one lane follows the
-//                    one real chain through them and notes the visited positions where the
-//                    compare loop matched (a tile is npos / mean-jump dependent LDS reads; the
-//                    other waves of the SIMD hide that latency).  One atomic per tile reserves
-//                    the output range, all lanes copy the finds out.
+//                    of all positions in parallel (mm_tile_jumps), the phase maps of the
+//                    tile's 32 groups of 64 positions in parallel (mm_group_maps), one lane
+//                    threads the entry phase through them, then lane g walks group g (a
+//                    handful of jumps) and notes the visited positions where the compare loop
+//                    matched.  One atomic per tile reserves the output range.
 #ifndef MM_DENSE_H
 #define MM_DENSE_H
 
@@ -173,33 +173,53 @@ __global__ __launch_bounds__(64 * MM_WAVES) void mm_dense_emit(MmDenseArgs a)
       const int npos = (int)(nv - lo < MM_TILE ? nv - lo : MM_TILE);
       mm_tile_jumps(a.t, P, W, mm_uniform64(start), lo, npos, lane);
 
-      // the one real chain: it enters the tile at the first position in phase entry[item]
-      int nfound = 0;
+      // The one real chain enters the tile in phase entry[item].  Its phase on entering every
+      // group of 64 positions comes from the group maps; then lane g walks group g and notes
+      // the visited positions where the compare loop matched.
+      const uint32_t lo_mod = mm_modd64(a.t, (uint64_t)lo);
+      const int ngroups = (npos + 63) >> 6;
+      mm_group_maps(a.t, W, npos, lo_mod, lane);
       if (lane == 0) {
-         const uint32_t lo_mod = mm_modd64(a.t, (uint64_t)lo);
-         uint32_t p = (uint32_t)a.entry[item] + D - lo_mod;
-         p = p >= D ? p - D : p;
-         while (p < (uint32_t)npos) {
+         uint32_t ph = a.entry[item];
+         for (int g = 0; g < ngroups; g++) {
+            W.gentry[g] = (uint8_t)ph;
+            ph = W.gmap[g][ph];
+         }
+      }
+      mm_wave_sync();
+      int nfound = 0;
+      if (lane < ngroups) {
+         const uint32_t first = 64u * (uint32_t)lane;
+         const uint32_t end = first + 64 < (uint32_t)npos ? first + 64 : (uint32_t)npos;
+         uint32_t off = (uint32_t)W.gentry[lane] + D - mm_modd(a.t, lo_mod + first);
+         off = off >= D ? off - D : off;
+         uint32_t p = first + off;
+         while (p < end) {
             const uint32_t j = W.jump[p];
             if (j & MM_JUMP_MATCH) {
-               found[nfound++] = (uint16_t)p;
+               found[first + nfound++] = (uint16_t)p;      // group g's finds live in found[64 g ...]
             }
             p += j & (MM_JUMP_MATCH - 1);
          }
       }
-      nfound = (int)mm_uniform((uint32_t)nfound);
-      mm_wave_sync();
-      if (nfound) {
-         // one atomic per tile reserves the output range
+      // one atomic per tile reserves the output range; lanes copy their finds in group order
+      int incl = nfound;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+         const int v = __shfl_up(incl, d);
+         incl += lane >= d ? v : 0;
+      }
+      const int total = __shfl(incl, 63);
+      if (total) {
          unsigned long long base = 0;
          if (lane == 0) {
-            base = atomicAdd(a.list_count + list * MM_LIST_STRIDE, (unsigned long long)nfound);
+            base = atomicAdd(a.list_count + list * MM_LIST_STRIDE, (unsigned long long)total);
          }
-         base = __shfl(base, 0);
-         for (int k = lane; k < nfound; k += 64) {
+         base = __shfl(base, 0) + (unsigned long long)(incl - nfound);
+         for (int k = 0; k < nfound; k++) {
             const unsigned long long slot = base + (unsigned long long)k;
             if (slot < a.list_cap) {
-               const uint64_t j = (uint64_t)lo + found[k];
+               const uint64_t j = (uint64_t)lo + found[64 * lane + k];
                a.out[(uint64_t)list * a.list_cap + slot] = a.t.g.whole ? j : start + j * a.t.g.S + a.base_offset;
             }
          }

@@ -74,6 +74,8 @@ struct MmPlanLds {
 struct MmWaveLds {
    uint32_t tile[((MM_TILE + MMH_MAX_KEYWORD + 1) * 2 + 16) / 4];
    uint8_t jump[MM_TILE];                    // J of every position of the window (| MM_JUMP_MATCH)
+   uint8_t gmap[MM_TILE / 64][MM_MAXD];      // phase map of every group of 64 positions (long windows)
+   uint8_t gentry[MM_TILE / 64];             // mm_dense_emit: the chain's phase on entering each group
 };
 
 // tell the compiler a value is the same in every lane (keeps it in SGPRs / on the scalar unit)
@@ -311,6 +313,33 @@ __device__ __forceinline__ const uint8_t *mm_tile_jumps(const MmTileArgs &a, con
    return tile;
 }
 
+// Long windows: the phase map of every group of 64 positions, W.gmap[g][e] = phase in which
+// the chain that enters group g in phase e leaves it.  ngroups * D independent little walks
+// (<= 64 / mean-jump steps each) spread over the lanes; composing the group maps afterwards
+// costs one LDS lookup per group.  Needs W.jump (mm_tile_jumps).
+__device__ __forceinline__ void mm_group_maps(const MmTileArgs &a, MmWaveLds &W, int npos, uint32_t lo_mod, int lane)
+{
+   const uint32_t D = a.plan.L - 1;
+   const uint32_t ngroups = (uint32_t)(npos + 63) >> 6;
+   const uint32_t ntasks = ngroups * D;                        // <= 32 * 31
+   for (uint32_t task = (uint32_t)lane; task < ntasks; task += 64) {
+      const uint32_t g = (task * a.inv_d) >> 16;                // task / D
+      const uint32_t e = task - g * D;
+      const uint32_t first = 64 * g;
+      const uint32_t end = first + 64 < (uint32_t)npos ? first + 64 : (uint32_t)npos;
+      uint32_t off = e + D - mm_modd(a, lo_mod + first);        // first position of the group in phase e
+      off = off >= D ? off - D : off;
+      uint32_t p = first + off;
+      while (p < end) {
+         p += W.jump[p] & (MM_JUMP_MATCH - 1);
+      }
+      uint32_t v = mm_modd(a, lo_mod + end) + (p - end);        // it left the group at p in [end, end + D)
+      v = v >= D ? v - D : v;
+      W.gmap[g][e] = (uint8_t)v;
+   }
+   mm_wave_sync();
+}
+
 // Map of positions [lo, lo + npos) of the domain at byte `start`; lo_mod = lo mod D.  Lane
 // e < D returns the exit phase of entry phase e (other lanes: their own number, i.e. the
 // identity).  *end_matches: does the compare loop match AT position npos (the candidate in
@@ -327,7 +356,17 @@ __device__ __forceinline__ uint32_t mm_tile_map(const MmTileArgs &a, const MmPla
    const uint32_t D = a.plan.L - 1;
 
    uint32_t v = (uint32_t)lane;
-   if ((uint32_t)lane < D) {
+   if (npos > 512) {
+      // long window: group maps in parallel, then lane e follows phase e through them
+      mm_group_maps(a, W, npos, lo_mod, lane);
+      if ((uint32_t)lane < D) {
+         const int ngroups = (npos + 63) >> 6;
+         for (int g = 0; g < ngroups; g++) {
+            v = W.gmap[g][v];
+         }
+      }
+   }
+   else if ((uint32_t)lane < D) {
       uint32_t p = (uint32_t)lane + D - lo_mod;            // first position of the window in phase `lane`
       p = p >= D ? p - D : p;
       while (p < (uint32_t)npos) {
