@@ -9,6 +9,7 @@
 #include <fstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "mmoore/monkey_moore.hpp"
@@ -182,6 +183,55 @@ int main()
       CHECK(is_ascii_upper(U'Q') && !is_ascii_upper(U'q') && !is_ascii_upper(0x3042), "is_ascii_upper");
       CHECK(is_ascii_lower(U'q') && is_ascii_digit(U'7') && !is_ascii_digit(U'x'), "is_ascii_lower/digit");
       CHECK(mmoore::swap_always<uint16_t>(0x1234) == 0x3412 && mmoore::swap_always<uint32_t>(0x11223344u) == 0x44332211u, "swap_always");
+   }
+   // one MonkeyMoore instance searched from several threads at once, as the reference's workers
+   // do (search_engine.cpp:114,147): every thread gets its own device context
+   {
+      MonkeyMoore<uint8_t> shared(std::vector<CharType>{'m', 'o', 'n', 'k', 'e', 'y'}, 0, {});
+      constexpr int kThreads = 4;
+      std::vector<std::vector<uint8_t>> roms(kThreads);
+      std::vector<std::vector<uint64_t>> expect(kThreads), got(kThreads);
+      for (int t = 0; t < kThreads; t++) {
+         roms[t].resize((1u << 20) + 977 * t);
+         uint32_t x = 12345u + t;
+         for (auto &b : roms[t]) {
+            x = x * 1664525u + 1013904223u;
+            b = static_cast<uint8_t>(x >> 24);
+         }
+         for (size_t at = 5000 + 31 * t; at + 6 < roms[t].size(); at += 40000 + 1000 * t) {
+            const char *kw = "monkey";
+            for (int k = 0; k < 6; k++) {
+               roms[t][at + k] = static_cast<uint8_t>(kw[k] - 60 + t);
+            }
+         }
+         for (auto &r : shared.search(roms[t].data(), roms[t].size())) {
+            expect[t].push_back(r.first);
+         }
+      }
+      std::vector<std::thread> pool;
+      std::atomic<int> errors{0};
+      for (int t = 0; t < kThreads; t++) {
+         pool.emplace_back([&, t] {
+            try {
+               for (int rep = 0; rep < 5; rep++) {
+                  got[t].clear();
+                  for (auto &r : shared.search(roms[t].data(), roms[t].size())) {
+                     got[t].push_back(r.first);
+                  }
+               }
+            }
+            catch (const std::exception &) {
+               errors++;
+            }
+         });
+      }
+      for (auto &th : pool) {
+         th.join();
+      }
+      CHECK(errors == 0, "concurrent search threw");
+      for (int t = 0; t < kThreads; t++) {
+         CHECK(got[t] == expect[t] && expect[t].size() >= 20, "thread %d: %zu results, expected %zu", t, got[t].size(), expect[t].size());
+      }
    }
    std::printf("%d checks, %d failures\n", checks, failures);
    return failures ? 1 : 0;

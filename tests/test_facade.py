@@ -21,7 +21,7 @@ def _build_tests(mm):
     exe = os.path.join(BUILD, "facade_tests")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), "-I" + BUILD,
                            os.path.join(CPP, "facade_tests.cpp"), "-L" + mm.build.LIB_DIR, "-lmonkey-core", "-lmmoore_hip",
-                           "-Wl,-rpath," + mm.build.LIB_DIR, "-o", exe])
+                           "-Wl,-rpath," + mm.build.LIB_DIR, "-pthread", "-o", exe])
     return exe
 
 
