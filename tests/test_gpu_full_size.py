@@ -59,3 +59,28 @@ def test_c4_8gib_16bit_le(mm, gpu_engine, oracle):
     # the 16-bit odd-boundary rule: no reported offset is k*B - 1
     assert not np.any((got % np.uint64(BLOCK)) == np.uint64(BLOCK - 1))
     assert np.any(got % np.uint64(2) == 1)               # odd alignments are found
+
+
+def test_c5_shard_8gib_8bit_ragged(mm, gpu_engine, oracle):
+    # one GPU's share of BASELINE C5 (64 GiB over 8 GPUs = 8 GiB per GPU, 8-bit, 12 symbols), with
+    # a ragged tail and a non-zero partition base: offsets beyond 2^32, the edge kernel behind the
+    # last whole 4 KiB group, a last block shorter than the others
+    nbytes = (8 << 30) + 12345
+    base = 3 * (8 << 30)
+    spec = mm.synth.RomSpec(42, base + nbytes, "relativesrch", 1, None, False, BLOCK, base=base, nbytes=nbytes)
+    gpu_engine.alloc(nbytes)
+    spec.apply_device(gpu_engine)
+    tail = np.frombuffer(b"relativesrch", np.uint8) - 30
+    gpu_engine.poke(nbytes - 12, tail)                    # a match ending on the ROM's last byte
+    gpu_engine.poke(nbytes - 5000, tail)
+    plan = mm.plan_relative(1, "relativesrch")
+    got = gpu_engine.scan(plan, block_bytes=BLOCK, base_offset=base)
+    rom = _download(gpu_engine, nbytes)
+    want = oracle_engine_parallel(oracle, oracle.plan(1, "relativesrch"), rom, BLOCK) + np.uint64(base)
+    assert got.tolist() == want.tolist()
+    assert len(got) >= 8192 and int(got[-1]) == base + nbytes - 12
+    # two scans in flight deliver the same
+    t1 = gpu_engine.submit(plan, block_bytes=BLOCK, base_offset=base)
+    t2 = gpu_engine.submit(plan, block_bytes=BLOCK, base_offset=0)
+    assert gpu_engine.collect(t1).tolist() == want.tolist()
+    assert (gpu_engine.collect(t2) + np.uint64(base)).tolist() == want.tolist()
