@@ -56,7 +56,7 @@ def gather_offsets(offsets, rank, world, device, dist):
     The payload is tiny and latency-bound (8 B per match), so the common case is ONE
     collective: an all_gather of fixed-width records [count, offsets...] (64 KiB per rank;
     on the 8-GPU xGMI mesh every peer is one hop away) into one contiguous table, followed by
-    ONE device-to-host copy per rank (the counts column; on rank 0 the whole table).  Every
+    ONE device-to-host copy per rank.  Every
     rank sees every count, so all ranks agree without further traffic on whether some list did
     not fit; only then a second, padded all_gather of the full lists follows."""
     import torch
@@ -68,13 +68,10 @@ def gather_offsets(offsets, rank, world, device, dist):
     b["view"][1:1 + k] = mine[:k]
     b["rec"].copy_(b["host"], non_blocking=True)          # stream ordered before the collective
     _all_gather(dist, b, world, width)
-    table = b["table"].view(world, width)
-    if rank == 0:
-        host_table = table.cpu().numpy()
-        counts = host_table[:, 0].copy()
-    else:
-        host_table = None
-        counts = table[:, 0].cpu().numpy()                # every rank: 8 B per peer
+    # one contiguous device-to-host copy on every rank (a strided read of the counts column
+    # alone would cost a gather kernel plus the copy)
+    host_table = b["table"].view(world, width).cpu().numpy()
+    counts = host_table[:, 0].copy()
     if int(counts.max()) <= width - 1:
         if rank != 0:
             return None
