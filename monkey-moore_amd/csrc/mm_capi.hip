@@ -477,12 +477,12 @@ int sort_to_host(mmh_ctx *c, const uint64_t *keys, uint64_t n, std::vector<uint6
 // The candidate-free forward engine (mm_dense.h).  Matches land in MM_CAND_LISTS device
 // lists; they are fetched and ordered on the host (dense results are long lists anyway).
 int run_dense(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, uint64_t base_offset, std::vector<uint64_t> *found,
-              bool *grew)
+              bool *grew, const uint32_t *dom_list = nullptr, uint64_t listed_domains = 0)
 {
    hipStream_t st = c->stream;
    *grew = false;
    found->clear();
-   const mm::DenseGeom dg = mm::dense_geom(g);
+   const mm::DenseGeom dg = mm::dense_geom(g, listed_domains);
    if (dg.tpd == 0) {
       return MMH_OK;                              // no alignment fits anywhere
    }
@@ -509,7 +509,7 @@ int run_dense(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, uint64_t bas
    begin_scan_events(c, false);
    HIP_TRY(hipEventRecord(c->ev[0], st));
    HIP_TRY(hipEventRecord(c->ev[1], st));
-   mm::launch_dense(st, g, pl, dg, db, base_offset);
+   mm::launch_dense(st, g, pl, dg, db, base_offset, dom_list);
    HIP_TRY(hipGetLastError());
    HIP_TRY(hipEventRecord(c->ev[2], st));
    std::vector<unsigned long long> ctrl(mm::ctrl_bytes() / sizeof(unsigned long long));
@@ -552,6 +552,84 @@ int run_dense(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, uint64_t bas
 } // namespace
 
 namespace {
+
+// A scan whose left-over lists overflowed (floods of candidates only the domain prefix can
+// settle: matches right behind long constant runs, say).  Instead of sending the whole ROM to
+// the forward engine: (1) flag pass -- mm_resolve again, setting the bit of every domain that
+// holds an unsettled candidate; (2) forward engine over the flagged domains only; (3) the first
+// pass's verdicts stand everywhere else.  Engine mode only (a whole-buffer scan is one domain).
+int run_flagged_domains(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, uint64_t base_offset, uint32_t max_candidates,
+                        uint64_t first_pass_slots, std::vector<uint64_t> *merged, uint64_t *domains_flagged)
+{
+   hipStream_t st = c->stream;
+   MmWorkspace &w = c->ws[0];
+   const uint64_t ndom = g.nblocks * g.S;
+   const uint64_t words = (ndom + 31) / 32;
+   int rc = grow(&c->d_sort_in, &c->sort_in_cap, (words + 1) / 2 + ndom / 2 + 2);   // bitmap, then the domain list, as u32
+   if (rc != MMH_OK) {
+      return rc;
+   }
+   uint32_t *d_bits = reinterpret_cast<uint32_t *>(c->d_sort_in);
+   HIP_TRY(hipMemsetAsync(d_bits, 0, words * sizeof(uint32_t), st));
+   HIP_TRY(hipMemsetAsync(w.d_ctrl, 0, mm::ctrl_bytes(), st));
+   w.ctrl_clean = false;
+   // the candidate lists of the first pass are gone with the control block: run the filter again
+   mm::FilterChoice fc;
+   mm::choose_filter(pl, &fc);
+   mm::ResolveBuffers rb;
+   rb.cand = w.d_cand; rb.cand_cap = w.cand_cap; rb.out = w.d_out; rb.out_cap = w.out_cap; rb.ctrl = w.d_ctrl;
+   rb.mid_off = w.d_mid_off; rb.mid_hi = w.d_mid_hi; rb.mid_set = w.d_mid_set; rb.mid_slot = w.d_mid_slot;
+   rb.hard_off = w.d_hard_off; rb.hard_hi = w.d_hard_hi; rb.hard_set = w.d_hard_set; rb.hard_slot = w.d_hard_slot;
+   rb.scratch = w.d_scratch;
+   mm::launch_filter(st, g, pl, fc, w.d_cand, w.d_ctrl, w.cand_cap);
+   mm::launch_resolve(st, g, pl, rb, base_offset, max_candidates, d_bits);
+   HIP_TRY(hipGetLastError());
+   std::vector<uint32_t> bits(words);
+   std::vector<uint64_t> slots(first_pass_slots);
+   HIP_TRY(hipMemcpyAsync(bits.data(), d_bits, words * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+   // every candidate got its slot again (same candidates; their order may differ from the first pass)
+   HIP_TRY(hipMemcpyAsync(slots.data(), w.d_out, first_pass_slots * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+   HIP_TRY(hipStreamSynchronize(st));
+
+   std::vector<uint32_t> doms;
+   for (uint64_t d = 0; d < ndom; d++) {
+      if ((bits[d >> 5] >> (d & 31)) & 1u) {
+         doms.push_back((uint32_t)d);
+      }
+   }
+   *domains_flagged = doms.size();
+   auto flagged = [&](uint64_t reported) {
+      const uint64_t o = reported - base_offset;
+      const uint64_t blk = o / g.block_bytes;
+      const uint64_t d = blk * g.S + (o - blk * g.block_bytes) % g.S;
+      return ((bits[d >> 5] >> (d & 31)) & 1u) != 0;
+   };
+   merged->clear();
+   for (uint64_t v : slots) {
+      if (v != ~0ull && !flagged(v)) {
+         merged->push_back(v);
+      }
+   }
+   if (!doms.empty()) {
+      uint32_t *d_list = d_bits + words + (words & 1);
+      HIP_TRY(hipMemcpyAsync(d_list, doms.data(), doms.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+      std::vector<uint64_t> dense;
+      for (int attempt = 0; attempt < 4; attempt++) {
+         bool grew = false;
+         rc = run_dense(c, g, pl, base_offset, &dense, &grew, d_list, doms.size());
+         if (rc != MMH_OK) {
+            return rc;
+         }
+         if (!grew) {
+            break;
+         }
+      }
+      merged->insert(merged->end(), dense.begin(), dense.end());
+   }
+   std::sort(merged->begin(), merged->end());       // search_engine.cpp:193-197
+   w.ctrl_clean = false;
+   return MMH_OK;
+}
 
 int check_scan_args(const mmh_ctx *c, const mmh_plan_desc *plan, const char *who)
 {
@@ -629,7 +707,7 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
 
    Outcome oc;
    std::vector<uint64_t> long_list;
-   bool host_list = false;
+   bool host_list = false, flagged_domains = false;
    for (int attempt = 0; attempt < 6; attempt++) {
       if (mode == DENSE) {
          bool grew = false;
@@ -648,6 +726,17 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
       rc = run_pipeline(c, g, *plan, fc, mode == SEQUENTIAL, base_offset, max_candidates, &oc);
       if (rc != MMH_OK) {
          return rc;
+      }
+      if (mode == FAST && oc.hard_overflow && !g.whole && oc.candidates <= c->ws[0].out_cap && oc.candidates <= max_candidates) {
+         // more left-overs than mm_resolve2 / mm_hard_resolve take: forward engine on their domains only
+         rc = run_flagged_domains(c, g, *plan, base_offset, max_candidates, oc.candidates, &long_list, &oc.tiles);
+         if (rc != MMH_OK) {
+            return rc;
+         }
+         oc.matches = long_list.size();
+         host_list = true;
+         flagged_domains = true;
+         break;
       }
       if (mode == FAST && (oc.candidates > c->ws[0].out_cap || oc.candidates > max_candidates || oc.hard_overflow)) {
          mode = DENSE;                            // too dense / too long for the per-candidate resolvers
@@ -676,7 +765,7 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
    c->counters[0] = oc.candidates;
    c->counters[1] = oc.matches;
    c->counters[2] = oc.tiles;
-   c->counters[3] = mode == SEQUENTIAL ? 1 : (mode == DENSE ? 3 : (oc.hard ? 2 : 0));
+   c->counters[3] = mode == SEQUENTIAL ? 1 : (mode == DENSE ? 3 : (flagged_domains ? 4 : (oc.hard ? 2 : 0)));
 
    *out_count = oc.matches;
    if (oc.matches > cap) {

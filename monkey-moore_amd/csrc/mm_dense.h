@@ -26,7 +26,8 @@ constexpr int MM_SUPER = 256;                 // tiles per super-tile
 
 struct MmDenseArgs {
    MmTileArgs t;
-   uint64_t ndom;           // domains: nblocks * S in engine mode, 1 in whole-buffer mode
+   uint64_t ndom;           // domains worked on: nblocks * S in engine mode, 1 in whole-buffer mode, or the length of dom_list
+   const uint32_t *dom_list;   // nullptr: every domain; else the domains to work on (buffers are indexed by list position)
    uint32_t tpd;            // tiles per domain (ceil(max positions / MM_TILE))
    uint32_t nsup;           // super-tiles per domain
    uint8_t *maps;           // [ndom * tpd][MM_MAXD]
@@ -41,6 +42,9 @@ struct MmDenseArgs {
 
 __device__ __forceinline__ void mm_dense_domain(const MmDenseArgs &a, uint64_t dom, uint64_t *start, int64_t *nv)
 {
+   if (a.dom_list) {
+      dom = a.dom_list[dom];
+   }
    const uint64_t b = a.t.g.whole ? 0 : dom / a.t.g.S;
    const uint32_t p = a.t.g.whole ? 0 : (uint32_t)(dom % a.t.g.S);
    *start = mm_domain_start(a.t.g, b, p);

@@ -57,8 +57,10 @@ struct ResolveBuffers {
    uint8_t *scratch;
 };
 
+// flag_bits != nullptr: the flag pass -- mm_resolve alone, setting the bit of every domain that
+// holds a candidate its two windows cannot settle (one bit per domain, zeroed by the caller)
 void launch_resolve(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const ResolveBuffers &rb,
-                    uint64_t base_offset, uint32_t max_candidates);
+                    uint64_t base_offset, uint32_t max_candidates, uint32_t *flag_bits = nullptr);
 size_t hard_scratch_bytes();
 size_t hard_cap();
 size_t mid_cap();
@@ -77,9 +79,10 @@ struct DenseBuffers {
    uint64_t out_cap;
    unsigned long long *ctrl; // list counters at MM_CTRL_LISTS
 };
-DenseGeom dense_geom(const MmGeom &g);
+// listed_domains > 0: geometry for a forward pass over that many listed domains only
+DenseGeom dense_geom(const MmGeom &g, uint64_t listed_domains = 0);
 void launch_dense(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const DenseGeom &dg, const DenseBuffers &db,
-                  uint64_t base_offset);
+                  uint64_t base_offset, const uint32_t *dom_list = nullptr);
 void launch_chain_seq(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, uint64_t *out,
                       unsigned long long *out_count, uint64_t out_cap, uint64_t base_offset);
 // orders the ctrl[count_index] keys of `in` into host_result[8..] (pinned host memory),

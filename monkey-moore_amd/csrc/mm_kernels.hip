@@ -1142,7 +1142,7 @@ static MmTileArgs tile_args(const MmGeom &g, const mmh_plan_desc &pl)
 }
 
 void launch_resolve(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const ResolveBuffers &rb,
-                    uint64_t base_offset, uint32_t max_candidates)
+                    uint64_t base_offset, uint32_t max_candidates, uint32_t *flag_bits)
 {
    MmResolveArgs a;
    a.t = tile_args(g, pl);
@@ -1152,7 +1152,11 @@ void launch_resolve(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, co
    a.base_offset = base_offset; a.max_candidates = max_candidates;
    a.mid_off = rb.mid_off; a.mid_hi = rb.mid_hi; a.mid_set = rb.mid_set; a.mid_slot = rb.mid_slot;
    a.mid_count = reinterpret_cast<unsigned int *>(rb.ctrl + MM_CTRL_MID);
+   a.flag_bits = flag_bits;
    hipLaunchKernelGGL(mm_resolve, dim3(tuning().resolve_blocks), dim3(64 * MM_WAVES), 0, st, a);
+   if (flag_bits) {
+      return;                                  // flag pass: the left-overs are not handed on
+   }
 
    MmResolve2Args m;
    m.t = a.t;
@@ -1181,10 +1185,10 @@ size_t mid_cap() { return MM_MID_CAP; }
 size_t ctrl_bytes() { return MM_CTRL_DONE * sizeof(uint64_t) + MM_HARD_CAP * sizeof(unsigned int); }
 size_t rank_partials_bytes(uint32_t max_n) { return (size_t)MM_RANK_SLICES * max_n * sizeof(uint32_t); }
 
-DenseGeom dense_geom(const MmGeom &g)
+DenseGeom dense_geom(const MmGeom &g, uint64_t listed_domains)
 {
    DenseGeom d;
-   d.ndom = g.whole ? 1 : g.nblocks * g.S;
+   d.ndom = listed_domains ? listed_domains : (g.whole ? 1 : g.nblocks * g.S);
    int64_t most = 0;
    for (uint32_t p = 0; p < (g.whole ? 1u : g.S); p++) {
       int64_t nv = mm_domain_nv(g, 0, p);                 // block 0 is the largest kind of block
@@ -1200,11 +1204,11 @@ DenseGeom dense_geom(const MmGeom &g)
 }
 
 void launch_dense(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const DenseGeom &dg, const DenseBuffers &db,
-                  uint64_t base_offset)
+                  uint64_t base_offset, const uint32_t *dom_list)
 {
    MmDenseArgs a;
    a.t = tile_args(g, pl);
-   a.ndom = dg.ndom; a.tpd = dg.tpd; a.nsup = dg.nsup;
+   a.ndom = dg.ndom; a.tpd = dg.tpd; a.nsup = dg.nsup; a.dom_list = dom_list;
    a.maps = db.maps; a.supmaps = db.supmaps; a.supentry = db.supentry; a.entry = db.entry;
    a.out = db.out; a.list_count = db.ctrl + MM_CTRL_LISTS; a.list_cap = db.out_cap / MM_CAND_LISTS;
    a.base_offset = base_offset;

@@ -413,6 +413,10 @@ struct MmResolveArgs {
    uint32_t *mid_set;                         // [MM_MID_CAP] acceptable phases at the frontier
    uint32_t *mid_slot;                        // [MM_MID_CAP] the candidate's result slot
    unsigned int *mid_count;
+   // Flag pass (after a scan whose left-over lists overflowed): instead of handing undecided
+   // candidates on, set the bit of their domain -- the host then runs the forward engine on
+   // exactly those domains.  nullptr in a normal scan.
+   uint32_t *flag_bits;
 };
 
 constexpr uint64_t MM_NO_MATCH = ~0ull;
@@ -519,7 +523,11 @@ __device__ __forceinline__ void mm_resolve_body(const MmResolveArgs &a, const Mm
       }
       if (lane == 0) {
          a.out[ci] = verdict == 1 ? mm_report_value(a.t.g, o, a.base_offset) : MM_NO_MATCH;
-         if (verdict < 0) {
+         if (verdict < 0 && a.flag_bits) {
+            const uint64_t dom = a.t.g.whole ? 0 : b * a.t.g.S + p;
+            atomicOr(&a.flag_bits[dom >> 5], 1u << (dom & 31));
+         }
+         else if (verdict < 0) {
             unsigned int slot = atomicAdd(a.mid_count, 1u);   // beyond MM_MID_CAP: the host sees the count and switches engines
             if (slot < MM_MID_CAP) {
                a.mid_off[slot] = o;

@@ -447,3 +447,26 @@ def test_synthetic_rom_goldens_on_device(mm, gpu_engine):
             assert got.tolist() == want, (c["name"], block)
         if "whole_buffer" in c:
             assert gpu_engine.scan(plan).tolist() == c["whole_buffer"], c["name"]
+
+
+@pytest.mark.parametrize("elem", [1, 2])
+def test_flood_of_undecidable_candidates_uses_flagged_domains(mm, gpu_engine, oracle, elem):
+    # 'abcde' candidates can only be settled from the start of their domain (test_hard_candidates).
+    # More of them than the hard list takes: the forward engine then runs on the flagged domains
+    # only (path 4), everything else keeps the resolvers' verdicts.
+    rng = np.random.default_rng(17 + elem)
+    block, nblocks = 65536, 512
+    vals = [ord(c) for c in "abcde"]
+    rom = _random_rom_with_plants(rng, block * nblocks, elem, vals, False, nplants=150)
+    gpu_engine.upload(rom)
+    plan, oplan = mm.plan_relative(elem, "abcde"), oracle.plan(elem, "abcde")
+    got = gpu_engine.scan(plan, block_bytes=block)
+    ctr = gpu_engine.counters()
+    want = oracle.engine(oplan, rom, block)
+    assert got.tolist() == want.tolist()
+    assert len(want) >= 20
+    assert ctr["path"] == 4 and 100 <= ctr["tiles_walked"] <= 160, ctr      # [2] = flagged domains on this path
+    # the forced engines agree, and so do two scans in flight (collect falls back to the same path)
+    assert _scan_both(gpu_engine, plan, block_bytes=block).tolist() == want.tolist()
+    t = gpu_engine.submit(plan, block_bytes=block)
+    assert gpu_engine.collect(t).tolist() == want.tolist()
