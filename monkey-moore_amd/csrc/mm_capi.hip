@@ -841,8 +841,9 @@ extern "C" int mmh_scan_submit(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t b
       // the ROM may still be in the making on the context's stream (upload, synth, poke)
       HIP_TRY(hipEventRecord(c->lane_fence, c->stream));
       HIP_TRY(hipStreamWaitEvent(c->lane_stream[lane], c->lane_fence, 0));
-      // (Making this lane's filter wait for the other lane's filter event was tried: 766 us per
-      // scan instead of 721 -- the hardware interleaves the two queues better on its own.)
+      // (Making this lane's filter wait for the other lane's "filter done" event was tried, with
+      // filter grids of 1024 .. 2048 workgroups: 766-913 us per scan instead of 697 -- the
+      // hardware interleaves the two queues better on its own.)
       begin_scan_events(c, true);
       c->scans_recorded++;
       p.ev = c->ev;
