@@ -393,18 +393,17 @@ int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev,
       HIP_TRY(hipEventRecord(ev[1], st));
       mm::launch_chain_seq(st, g, pl, w.d_out, w.d_ctrl + 1, w.out_cap, base_offset);
    }
-   mm::launch_rank_sort(st, w.d_out, w.d_ctrl, count_index, w.out_cap, kMaxRankSort, w.d_partials, w.h_result, ev[2]);
+   // (first phase: when mm_resolve leaves candidates over, the ordering kernel keeps the control
+   // block for the second phase, see finish_pipeline)
+   mm::launch_rank_sort(st, w.d_out, w.d_ctrl, count_index, w.out_cap, kMaxRankSort, w.d_partials, w.h_result, ev[2],
+                        !sequential);
    HIP_TRY(hipGetLastError());
    (void)c;
    return MMH_OK;
 }
 
-// wait for an enqueued scan and read what it published
-int finish_pipeline(MmWorkspace &w, hipEvent_t *ev, bool sequential, Outcome *oc)
+void read_outcome(const MmWorkspace &w, bool sequential, Outcome *oc)
 {
-   // waiting on the scan's last event returns ~6 us sooner than hipStreamSynchronize on this
-   // stack (measured: 12 vs 18-20 us between the end of the device work and the caller)
-   HIP_TRY(hipEventSynchronize(ev[2]));
    const int count_index = sequential ? 1 : 0;
    oc->candidates = w.h_result[0];
    oc->listed = w.h_result[count_index];
@@ -414,7 +413,41 @@ int finish_pipeline(MmWorkspace &w, hipEvent_t *ev, bool sequential, Outcome *oc
    oc->hard_overflow = (w.h_result[3] >> 32) != 0 || (w.h_result[5] & 0xFFFFFFFFu) > mm::mid_cap();
    oc->sorted_on_device = oc->listed <= kMaxRankSort && oc->listed <= w.out_cap;
    oc->matches = w.h_result[6] ? w.h_result[6] - 1 : oc->listed;
-   w.ctrl_clean = true;                         // mm_rank_scatter's last block re-zeroed it
+}
+
+// Wait for an enqueued scan and read what it published.  When mm_resolve left candidates over
+// (rare: low-entropy neighbourhoods, degenerate keywords) the second phase runs here:
+// mm_resolve2 -> mm_hard_resolve -> the ordering again.  Launching those two kernels with every
+// scan cost ~10 us of launch latency for nothing in the usual case.
+int finish_pipeline(MmWorkspace &w, hipStream_t st, hipEvent_t *ev, const MmGeom &g, const mmh_plan_desc &pl,
+                    uint64_t base_offset, uint32_t max_candidates, bool sequential, Outcome *oc)
+{
+   // waiting on the scan's last event returns ~6 us sooner than hipStreamSynchronize on this
+   // stack (measured: 12 vs 18-20 us between the end of the device work and the caller)
+   HIP_TRY(hipEventSynchronize(ev[2]));
+   read_outcome(w, sequential, oc);
+   const uint64_t leftovers = sequential ? 0 : (w.h_result[5] & 0xFFFFFFFFu);
+   if (leftovers == 0) {
+      w.ctrl_clean = true;                      // mm_rank_scatter's last block re-zeroed the control block
+      return MMH_OK;
+   }
+   w.ctrl_clean = false;                        // kept for the second phase
+   if (leftovers > mm::mid_cap() || oc->candidates > w.out_cap || oc->candidates > max_candidates) {
+      return MMH_OK;                            // the caller switches engines (hard_overflow / too many candidates)
+   }
+   mm::ResolveBuffers rb;
+   rb.cand = w.d_cand; rb.cand_cap = w.cand_cap; rb.out = w.d_out; rb.out_cap = w.out_cap; rb.ctrl = w.d_ctrl;
+   rb.mid_off = w.d_mid_off; rb.mid_hi = w.d_mid_hi; rb.mid_set = w.d_mid_set; rb.mid_slot = w.d_mid_slot;
+   rb.hard_off = w.d_hard_off; rb.hard_hi = w.d_hard_hi; rb.hard_set = w.d_hard_set; rb.hard_slot = w.d_hard_slot;
+   rb.scratch = w.d_scratch;
+   w.h_result[6] = 0;
+   mm::launch_leftovers(st, g, pl, rb, base_offset);
+   mm::launch_rank_sort(st, w.d_out, w.d_ctrl, 0, w.out_cap, kMaxRankSort, w.d_partials, w.h_result);
+   HIP_TRY(hipGetLastError());
+   HIP_TRY(hipEventRecord(ev[2], st));
+   HIP_TRY(hipEventSynchronize(ev[2]));
+   read_outcome(w, sequential, oc);
+   w.ctrl_clean = true;
    return MMH_OK;
 }
 
@@ -427,7 +460,7 @@ int run_pipeline(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, const mm:
    if (rc != MMH_OK) {
       return rc;
    }
-   return finish_pipeline(c->ws[0], c->ev, sequential, oc);
+   return finish_pipeline(c->ws[0], c->stream, c->ev, g, pl, base_offset, max_candidates, sequential, oc);
 }
 
 int grow(uint64_t **buf, uint64_t *cap, uint64_t need)
@@ -874,7 +907,8 @@ extern "C" int mmh_scan_collect(mmh_ctx *c, int ticket, uint64_t *out, uint64_t 
    Outcome oc;
    MmWorkspace &w = c->ws[1 + (ticket & 1)];
    if (!rescan) {
-      int rc = finish_pipeline(w, p.ev, false, &oc);
+      const MmGeom g = scan_geometry(c, &p.plan, p.block_bytes, p.big_endian);
+      int rc = finish_pipeline(w, c->lane_stream[ticket & 1], p.ev, g, p.plan, p.base_offset, p.max_candidates, false, &oc);
       if (rc != MMH_OK) {
          p.active = false;
          return rc;

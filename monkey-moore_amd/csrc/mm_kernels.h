@@ -61,6 +61,8 @@ struct ResolveBuffers {
 // holds a candidate its two windows cannot settle (one bit per domain, zeroed by the caller)
 void launch_resolve(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const ResolveBuffers &rb,
                     uint64_t base_offset, uint32_t max_candidates, uint32_t *flag_bits = nullptr);
+// the scan's second phase (only when mm_resolve left candidates over): mm_resolve2 + mm_hard_resolve
+void launch_leftovers(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const ResolveBuffers &rb, uint64_t base_offset);
 size_t hard_scratch_bytes();
 size_t hard_cap();
 size_t mid_cap();
@@ -86,9 +88,11 @@ void launch_dense(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, cons
 void launch_chain_seq(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, uint64_t *out,
                       unsigned long long *out_count, uint64_t out_cap, uint64_t base_offset);
 // orders the ctrl[count_index] keys of `in` into host_result[8..] (pinned host memory),
-// publishes the counters in host_result[0..8) and leaves ctrl zeroed; see mm_rank_scatter
+// publishes the counters in host_result[0..8) and leaves ctrl zeroed -- unless keep_leftovers
+// is set and mm_resolve left candidates over (the second phase follows); see mm_rank_scatter
 void launch_rank_sort(hipStream_t st, const uint64_t *in, unsigned long long *ctrl, int count_index, uint64_t cap,
-                      uint32_t max_n, uint32_t *partials, uint64_t *host_result, hipEvent_t stop = nullptr);
+                      uint32_t max_n, uint32_t *partials, uint64_t *host_result, hipEvent_t stop = nullptr,
+                      bool keep_leftovers = false);
 // ascending order of n 64-bit keys (mm_sort.hip, rocPRIM radix sort); in and out must not overlap
 size_t sort_temp_bytes(uint64_t n);
 hipError_t sort_keys(hipStream_t st, const uint64_t *in, uint64_t *out, uint64_t n, void *temp, size_t temp_bytes);

@@ -781,10 +781,14 @@ __global__ __launch_bounds__(256) void mm_rank_count(const uint64_t *in, const u
 // scan; 0 afterwards means "every key is a match").
 __global__ __launch_bounds__(256) void mm_rank_scatter(const uint64_t *in, unsigned long long *ctrl, int count_index,
                                                        uint64_t cap, uint32_t max_n, const uint32_t *partials,
-                                                       uint64_t *host_result, uint32_t ctrl_words)
+                                                       uint64_t *host_result, uint32_t ctrl_words, uint32_t keep_leftovers)
 {
    __shared__ int last_block;
    const unsigned long long n64 = ctrl[count_index];
+   // keep_leftovers: the scan's first phase -- when mm_resolve left candidates over, the host
+   // launches the second phase (mm_resolve2, mm_hard_resolve, this ordering again), which needs
+   // the control block as it is
+   const bool leftovers = keep_leftovers && (ctrl[MM_CTRL_MID] & 0xFFFFFFFFull) != 0;
    if (blockIdx.x == 0 && threadIdx.x < 8 && threadIdx.x != 6) {
       unsigned long long v = ctrl[threadIdx.x];            // counters travel with the results
       if (threadIdx.x == 2) {
@@ -825,8 +829,15 @@ __global__ __launch_bounds__(256) void mm_rank_scatter(const uint64_t *in, unsig
    }
    __syncthreads();
    if (last_block) {
-      for (uint32_t k = threadIdx.x; k < ctrl_words; k += blockDim.x) {
-         ctrl[k] = 0;
+      if (leftovers) {
+         if (threadIdx.x == 0) {
+            ctrl[MM_CTRL_TICKET] = 0;                        // the second phase's ordering counts arrivals again
+         }
+      }
+      else {
+         for (uint32_t k = threadIdx.x; k < ctrl_words; k += blockDim.x) {
+            ctrl[k] = 0;
+         }
       }
    }
 }
@@ -1154,21 +1165,24 @@ void launch_resolve(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, co
    a.mid_count = reinterpret_cast<unsigned int *>(rb.ctrl + MM_CTRL_MID);
    a.flag_bits = flag_bits;
    hipLaunchKernelGGL(mm_resolve, dim3(tuning().resolve_blocks), dim3(64 * MM_WAVES), 0, st, a);
-   if (flag_bits) {
-      return;                                  // flag pass: the left-overs are not handed on
-   }
+}
 
+// Second phase of a scan, launched only when mm_resolve left candidates over (the host sees
+// the count in the published header): mm_resolve2, then mm_hard_resolve for what even that
+// could not settle.  Two always-launched no-op kernels cost ~5 us each per scan.
+void launch_leftovers(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const ResolveBuffers &rb, uint64_t base_offset)
+{
    MmResolve2Args m;
-   m.t = a.t;
+   m.t = tile_args(g, pl);
    m.mid_off = rb.mid_off; m.mid_hi = rb.mid_hi; m.mid_set = rb.mid_set; m.mid_slot = rb.mid_slot;
-   m.mid_count = a.mid_count;
+   m.mid_count = reinterpret_cast<unsigned int *>(rb.ctrl + MM_CTRL_MID);
    m.out = rb.out; m.tiles_walked = rb.ctrl + MM_CTRL_TILES; m.base_offset = base_offset;
    m.hard_off = rb.hard_off; m.hard_hi = rb.hard_hi; m.hard_set = rb.hard_set; m.hard_slot = rb.hard_slot;
    m.hard_count = reinterpret_cast<unsigned int *>(rb.ctrl + MM_CTRL_HARD);
    hipLaunchKernelGGL(mm_resolve2, dim3(256), dim3(64 * MM_WAVES), 0, st, m);
 
    MmHardArgs h;
-   h.t = a.t;
+   h.t = m.t;
    h.hard_off = rb.hard_off; h.hard_hi = rb.hard_hi; h.hard_set = rb.hard_set; h.hard_slot = rb.hard_slot;
    h.hard_count = reinterpret_cast<unsigned int *>(rb.ctrl + MM_CTRL_HARD);
    h.overflow = reinterpret_cast<unsigned int *>(rb.ctrl + MM_CTRL_HARD) + 1;
@@ -1236,18 +1250,19 @@ void launch_chain_seq(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, 
 }
 
 void launch_rank_sort(hipStream_t st, const uint64_t *in, unsigned long long *ctrl, int count_index, uint64_t cap,
-                      uint32_t max_n, uint32_t *partials, uint64_t *host_result, hipEvent_t stop)
+                      uint32_t max_n, uint32_t *partials, uint64_t *host_result, hipEvent_t stop, bool keep_leftovers)
 {
+   const uint32_t keep = keep_leftovers ? 1u : 0u;
    hipLaunchKernelGGL(mm_rank_count, dim3(16, MM_RANK_SLICES), dim3(256), 0, st, in, ctrl + count_index, cap, max_n,
                       partials);
    const uint32_t ctrl_words = (uint32_t)(ctrl_bytes() / sizeof(unsigned long long));
    if (stop) {
       hipExtLaunchKernelGGL(mm_rank_scatter, dim3(64), dim3(256), 0, st, nullptr, stop, 0, in, ctrl, count_index, cap, max_n,
-                            partials, host_result, ctrl_words);
+                            partials, host_result, ctrl_words, keep);
    }
    else {
       hipLaunchKernelGGL(mm_rank_scatter, dim3(64), dim3(256), 0, st, in, ctrl, count_index, cap, max_n, partials,
-                         host_result, ctrl_words);
+                         host_result, ctrl_words, keep);
    }
 }
 
