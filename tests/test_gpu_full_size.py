@@ -84,3 +84,31 @@ def test_c5_shard_8gib_8bit_ragged(mm, gpu_engine, oracle):
     t2 = gpu_engine.submit(plan, block_bytes=BLOCK, base_offset=0)
     assert gpu_engine.collect(t1).tolist() == want.tolist()
     assert (gpu_engine.collect(t2) + np.uint64(base)).tolist() == want.tolist()
+
+
+def test_c5_64gib_on_one_gpu(mm, gpu_engine, oracle):
+    # BASELINE C5's whole 64 GiB ROM resident in ONE MI355X's 288 GB of HBM: 131072 blocks, offsets
+    # up to 2^36, one scan, compared in full with the oracle run over the host cores.  (The bench
+    # shards C5 over 8 GPUs; the engine itself does not need to.)
+    import psutil
+    nbytes = 64 << 30
+    if psutil.virtual_memory().available < (96 << 30):
+        pytest.skip("needs ~70 GiB of host memory for the oracle's copy of the ROM")
+    try:
+        gpu_engine.alloc(nbytes)
+    except mm.MMError:
+        pytest.skip("not enough free HBM for a 64 GiB ROM")
+    # straddlers at every 64th block boundary, partition-boundary plants and the three runs (one
+    # plant per MiB would be 65536 host-side pokes; the 4-8 GiB configurations above have those)
+    spec = mm.synth.RomSpec(42, nbytes, "relativesrch", 1, None, False, BLOCK, plants_per_mib=0)
+    spec.apply_device(gpu_engine)
+    plan = mm.plan_relative(1, "relativesrch")
+    for _ in range(3):
+        got = gpu_engine.scan(plan, block_bytes=BLOCK)
+    t = gpu_engine.timings()
+    rom = _download(gpu_engine, nbytes)
+    want = oracle_engine_parallel(oracle, oracle.plan(1, "relativesrch"), rom, BLOCK)
+    assert got.tolist() == want.tolist()
+    assert len(got) >= 2000 and int(got[-1]) > (63 << 30)
+    assert t["total_ms"] < 20.0, t                        # 64 GiB in 11 ms at the 4 GiB rate
+    gpu_engine.alloc(1 << 20)                             # give the HBM back to the other tests
