@@ -1,24 +1,29 @@
 // mm_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the relative-search engine.
 //
-// Pipeline of one scan (all launches on one stream, no host round trip between):
+// Pipeline of one scan (all launches on one stream, one host wait at the end):
 //
 //   mm_filter_u8 / mm_filter_u16   HBM-bound streaming pass over the whole ROM.
-//        Coalesced 16 B/lane loads, SWAR test of the last one or two pattern
-//        deltas on every byte position (4 positions per 32-bit VALU op), exact
-//        verification of the full match predicate for the rare survivors,
-//        wave-aggregated append of CANDIDATES (positions where the reference's
-//        compare loop would report a match IF its chain visited them).
-//   mm_resolve                     one wavefront per candidate.  The reference
+//        Coalesced 16 B/lane loads; two stages: the first two SWAR conditions
+//        (pattern deltas) on every byte position, 4 positions per 32-bit VALU
+//        op; pieces with a stage-1 hit get all conditions (up to 4) from a
+//        re-read; the survivors -- CANDIDATES: positions where the reference's
+//        compare loop may report a match IF its chain visits them -- are
+//        appended wave-aggregated to 64 lists.
+//   mm_resolve  (mm_tiles.h)       one wavefront per candidate.  The reference
 //        is not a complete matcher: it only tests the positions its skip chain
-//        visits.  The resolver decides "is h on the chain of
-//        its domain" exactly, by pulling the set of acceptable chain phases
-//        back through tile maps (phase = position mod (L-1)) until the set is
-//        empty, full, or the domain start (phase 0) is reached.  Skip table,
-//        pattern deltas and the tile bytes live in LDS.
-//   mm_chain_seq                   one lane per domain walking the chain
-//        sequentially; exact by construction, used as the dense / generic
-//        fallback and as an on-device cross-check.
-//   mm_rank_sort                   orders the (few) matches ascending.
+//        visits.  The resolver verifies the compare loop at the
+//        candidate and decides "is it on the chain of its domain" exactly, by
+//        pulling the set of acceptable chain phases (phase = position mod (L-1))
+//        back through the phase maps of one or two short windows until the set
+//        is empty, full, or the domain start (phase 0) is reached.
+//   mm_rank_count / mm_rank_scatter   order the matches ascending, straight into
+//        pinned host memory together with the scan's counters.
+//   second phase, only when mm_resolve left candidates over (host decides from the
+//   published counters): mm_resolve2 -> mm_hard_resolve (mm_tiles.h) -> ordering again.
+//
+// Other engines: mm_dense_* (mm_dense.h), the candidate-free forward engine, for
+// inputs the per-candidate path does not suit; mm_chain_seq, one lane per domain
+// walking the chain literally, as an on-device cross-check.
 //
 // No MFMA anywhere: the path is integer byte comparison (BASELINE.json).
 #include <hip/hip_runtime.h>
@@ -177,14 +182,16 @@ __device__ __forceinline__ bool mm_is_candidate(const MmGeom &g, const mmh_plan_
 //
 // One 16-byte chunk per lane (lane l of a wave reads bytes [16l, 16l+16) of a
 // 1 KiB piece -> fully coalesced dwordx4).  For every byte t the SWAR code
-// evaluates NCOND (1..4) necessary conditions for a match starting at t - iA:
-//     (x[t-k] - x[t-k-1]) mod 256 == pat[k]      delta of keyword position iA-k
-// for k = 0 .. NCOND-1 (signed equality on the simple path implies modular
-// equality, so this is a superset on both reference paths).  On random bytes
-// 2^(-8 NCOND) of the positions survive; survivors are verified exactly with
-// the reference's own compare loop.  Four conditions cost 21 VALU ops per dword
-// and leave essentially only real candidates, which keeps the divergent
-// verification (and the tail it would put on some waves) out of the picture.
+// evaluates up to four necessary conditions for a match anchored at t (starting
+// at t - iA), condition k being
+//     (x[t-s_k] - x[t-s_k-g_k]) mod 256 == pat[k]
+// the delta of keyword position iA-s_k against the literal g_k (1, or 2 over a
+// wildcard) to its left; signed equality on the simple path implies modular
+// equality, so this is a superset on both reference paths.  On random bytes
+// 2^(-8 n) of the positions pass n conditions.  All four on every dword cost 21
+// VALU instructions per dword and made the kernel VALU-limited; the streaming
+// loop therefore tests two (14 per dword) and hands the ~1.6 % of the pieces
+// with a hit to a rolled second stage that tests all of them.
 
 struct MmFilterArgs {
    MmGeom g;
