@@ -2,9 +2,10 @@
 // ownership, and the orchestration of one scan on one HIP stream.
 //
 // There is no CPU compute path here: every entry point that touches data needs
-// a HIP device and fails with MMH_E_DEVICE otherwise.  The only host work is the
-// pattern plan (mm_plan.cpp), sizing buffers and -- for match lists too long for
-// the device rank sort -- ordering the offsets like search_engine.cpp:193-197.
+// a HIP device and fails with MMH_E_DEVICE otherwise.  Host work: the pattern
+// plan (mm_plan.cpp), sizing buffers, choosing the engine from the counters a
+// scan publishes (second resolver phase, forward engine on flagged domains or
+// on everything), and merging lists of different engines in the rare mixed case.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
