@@ -211,20 +211,30 @@ class Engine:
         _check(lib().mmh_set_engine(self._h, engine))
 
     # -- scan -----------------------------------------------------------
+    def _result_buffer(self, cap):
+        # one result buffer reused from scan to scan; its ctypes pointer is cached (ndarray.ctypes
+        # builds a new object on every access, which costs more than the call itself)
+        out = getattr(self, "_out", None)
+        if out is None or out.size < cap:
+            out = self._out = np.empty(cap, np.uint64)
+            self._out_ptr = out.ctypes.data_as(C.POINTER(C.c_uint64))
+            self._count = C.c_uint64(0)
+            self._count_ref = C.byref(self._count)
+        return out
+
     def scan(self, plan, block_bytes=0, big_endian=False, base_offset=0, cap=1 << 16):
         """Returns ascending np.uint64 offsets (element indices when block_bytes == 0)."""
+        scan = lib().mmh_scan
+        plan_ref = C.byref(plan)
         while True:
-            out = getattr(self, "_out", None)
-            if out is None or out.size < cap:
-                out = self._out = np.empty(cap, np.uint64)       # reused across scans
-            n = C.c_uint64(0)
-            rc = lib().mmh_scan(self._h, C.byref(plan), block_bytes, int(big_endian), base_offset,
-                                out.ctypes.data_as(C.POINTER(C.c_uint64)), out.size, C.byref(n))
+            out = self._result_buffer(cap)
+            rc = scan(self._h, plan_ref, block_bytes, int(big_endian), base_offset, self._out_ptr, out.size, self._count_ref)
             if rc == MMH_E_CAPACITY:
-                cap = int(n.value) + 16
+                cap = int(self._count.value) + 16
                 continue
-            _check(rc)
-            return out[: n.value].copy()
+            if rc != MMH_OK:
+                _check(rc)
+            return out[: self._count.value].copy()
 
     def submit(self, plan, block_bytes=0, big_endian=False, base_offset=0):
         """Enqueue a scan (at most two outstanding); returns the ticket for collect()."""
@@ -235,16 +245,14 @@ class Engine:
     def collect(self, ticket, cap=1 << 16):
         """Wait for a submitted scan; returns what scan() would have returned."""
         while True:
-            out = getattr(self, "_out", None)
-            if out is None or out.size < cap:
-                out = self._out = np.empty(cap, np.uint64)
-            n = C.c_uint64(0)
-            rc = lib().mmh_scan_collect(self._h, ticket, out.ctypes.data_as(C.POINTER(C.c_uint64)), out.size, C.byref(n))
+            out = self._result_buffer(cap)
+            rc = lib().mmh_scan_collect(self._h, ticket, self._out_ptr, out.size, self._count_ref)
             if rc == MMH_E_CAPACITY:
-                cap = int(n.value) + 16
+                cap = int(self._count.value) + 16
                 continue
-            _check(rc)
-            return out[: n.value].copy()
+            if rc != MMH_OK:
+                _check(rc)
+            return out[: self._count.value].copy()
 
     def timings(self):
         t = (C.c_float * 4)()
