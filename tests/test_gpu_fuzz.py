@@ -8,7 +8,10 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+import os
+
 LOWER = "abcdefghijklmnopqrstuvwxyz"
+SEEDS = int(os.environ.get("MM_FUZZ_SEEDS", "40"))          # 24 cases per seed; raise for a longer soak
 PATHS_SEEN = set()
 
 
@@ -50,7 +53,7 @@ def _rom(rng, nbytes, elem, be, kw, wc, seq, alphabet):
     return np.concatenate([arr, tail])
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(SEEDS))
 def test_fuzz_against_oracle(mm, gpu_engine, oracle, seed):
     rng = np.random.default_rng(7000 + seed)
     for case in range(24):
