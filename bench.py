@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--cpu-sample-mib", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prewarm-s", type=float, default=0.3, help="device clock conditioning before the warm-up steps")
+    ap.add_argument("--sync-gather", action="store_true",
+                    help="N > 1: finish every step's offset gather before the next scan starts (no overlap)")
     ap.add_argument("--two-in-flight", action="store_true",
                     help="after the timed region, repeat the K steps through mmh_scan_submit / mmh_scan_collect and "
                          "report that as the extra 'two_in_flight' object (never the headline value)")
@@ -125,13 +127,29 @@ def main():
     torch.cuda.synchronize()
     plan = mm.plan_relative(1, KEYWORD)
 
+    # N > 1: the RCCL gather of the per-GPU offset lists (already ascending, partitions in rank
+    # order) is started right after a scan and finished after the NEXT scan has been run: the
+    # collective and its copies overlap that scan (one gather in flight; --sync-gather turns the
+    # overlap off).  Every step still delivers one merged list; drain() delivers the last one.
+    gatherer = mm.partition.OffsetGather(rank, world, dev, dist) if world > 1 else None
+    in_flight = []
+
     def step():
         offs = eng.scan(plan, block_bytes=BLOCK, base_offset=base)
         if world == 1:
             return offs
-        # RCCL gather of the per-GPU offset lists (already ascending, partitions in rank order)
-        merged = mm.partition.gather_offsets(offs, rank, world, dev, dist)
-        return merged if rank == 0 else offs
+        if args.sync_gather:
+            merged = gatherer.finish(gatherer.start(offs, async_op=False))
+            return merged if rank == 0 else offs
+        in_flight.append(gatherer.start(offs))
+        merged = gatherer.finish(in_flight.pop(0)) if len(in_flight) == 2 else None
+        return merged if (rank == 0 and merged is not None) else offs
+
+    def drain(last):
+        merged = None
+        while in_flight:
+            merged = gatherer.finish(in_flight.pop(0))
+        return merged if (rank == 0 and merged is not None) else last
 
     def fence():
         if world > 1:
@@ -147,12 +165,15 @@ def main():
     while time.perf_counter() - t_pre < args.prewarm_s:
         eng.scan(plan, block_bytes=BLOCK, base_offset=base)
         prewarm_scans += 1
+    offs = None
     for _ in range(args.warmup):
-        step()
+        offs = step()
+    drain(offs)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         offs = step()
+    offs = drain(offs)                                   # the last gather belongs to the timed region
     fence()
     elapsed = time.perf_counter() - t0
     # HIP-event timings of the timed steps: recorded on the scan's stream during the steps,
@@ -170,11 +191,11 @@ def main():
             if prev is not None:
                 last = eng.collect(prev)
                 if world > 1:
-                    last = mm.partition.gather_offsets(last, rank, world, dev, dist)
+                    last = gatherer.finish(gatherer.start(last, async_op=False))
             prev = t
         last = eng.collect(prev)
         if world > 1:
-            last = mm.partition.gather_offsets(last, rank, world, dev, dist)
+            last = gatherer.finish(gatherer.start(last, async_op=False))
         return last
     offs_pipe, elapsed_pipe = None, 0.0
     if args.two_in_flight:
@@ -223,7 +244,8 @@ def main():
                 "rom_bytes_total": total,
                 "matches": int(len(offs)),
                 "candidates_rank0": ctr["candidates"],
-                "parallelism": "%d partition(s) on block boundaries, RCCL offset gather" % world,
+                "parallelism": "%d partition(s) on block boundaries, RCCL offset gather%s" % (
+                    world, "" if world == 1 else (" (synchronous)" if args.sync_gather else " overlapped with the next scan")),
                 "prewarm_scans": prewarm_scans,
             },
             "roofline": {

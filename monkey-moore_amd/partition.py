@@ -18,69 +18,92 @@ def shard_range(total_bytes, block_bytes, keyword_len, elem_bytes, rank, world):
     return first, max(end - first, 0)
 
 
-_buffers = {}
+class OffsetGather:
+    """Gather of the per-rank offset lists to rank 0, split into start() / finish() so that the
+    collective of one scan runs while the next scan is under way.
+
+    The payload is tiny and latency-bound (8 B per match), so the common case is ONE
+    collective: an all_gather of fixed-width records [count, offsets...] (64 KiB per rank; on
+    the 8-GPU xGMI mesh every peer is one hop away) into one contiguous table, followed by ONE
+    device-to-host copy per rank.  Every rank sees every count, so all ranks agree without
+    further traffic on whether some list did not fit; only then a second, padded all_gather of
+    the full lists follows (inside finish(), on every rank alike).
+
+    Two staging sets alternate, so at most two gathers may be outstanding; finish them in the
+    order they were started.  Backend: "nccl" (= RCCL) on GPUs, "gloo" in the CPU tests."""
+
+    def __init__(self, rank, world, device, dist, width=None):
+        import torch
+        self.rank, self.world, self.device, self.dist = rank, world, device, dist
+        self.width = width or GATHER_WIDTH
+        self.sets = []
+        for _ in range(2):
+            host = torch.zeros(self.width, dtype=torch.int64)
+            if device.type == "cuda":
+                host = host.pin_memory()
+            self.sets.append(dict(host=host, view=host.numpy(),
+                                  rec=torch.zeros(self.width, dtype=torch.int64, device=device),
+                                  table=torch.zeros(world * self.width, dtype=torch.int64, device=device),
+                                  work=None, mine=None))
+        self.flat_ok = True
+        self.turn = 0
+
+    def _all_gather(self, b, async_op):
+        if self.flat_ok:
+            try:
+                return self.dist.all_gather_into_tensor(b["table"], b["rec"], async_op=async_op)
+            except (RuntimeError, NotImplementedError, AttributeError):
+                self.flat_ok = False                     # backend without all_gather_into_tensor
+        return self.dist.all_gather(list(b["table"].view(self.world, self.width).unbind(0)), b["rec"], async_op=async_op)
+
+    def start(self, offsets, async_op=True):
+        """All ranks: hand in this rank's ascending uint64 offsets (already global)."""
+        b = self.sets[self.turn]
+        if b["mine"] is not None:
+            raise RuntimeError("two gathers are already outstanding: finish() the older one first")
+        self.turn ^= 1
+        mine = np.ascontiguousarray(offsets).astype(np.int64)
+        k = min(mine.size, self.width - 1)
+        b["view"][0] = mine.size
+        b["view"][1:1 + k] = mine[:k]
+        b["rec"].copy_(b["host"], non_blocking=True)      # stream ordered before the collective
+        b["mine"] = mine
+        b["work"] = self._all_gather(b, async_op)
+        return b
+
+    def finish(self, b):
+        """All ranks, in start() order.  Rank 0 gets the concatenation in rank order (= globally
+        ascending), the others None."""
+        import torch
+        if b["work"] is not None:
+            b["work"].wait()
+        mine, b["mine"], b["work"] = b["mine"], None, None
+        width, world = self.width, self.world
+        # one contiguous device-to-host copy on every rank (a strided read of the counts column
+        # alone would cost a gather kernel plus the copy)
+        host_table = b["table"].view(world, width).cpu().numpy()
+        counts = host_table[:, 0].copy()
+        if int(counts.max()) <= width - 1:
+            if self.rank != 0:
+                return None
+            return np.concatenate([host_table[r, 1:1 + counts[r]] for r in range(world)]).astype(np.uint64)
+        longest = int(counts.max())
+        padded = torch.zeros(longest, dtype=torch.int64, device=self.device)
+        padded[: mine.size] = torch.from_numpy(mine).to(self.device)
+        full = [torch.empty(longest, dtype=torch.int64, device=self.device) for _ in range(world)]
+        self.dist.all_gather(full, padded)
+        if self.rank != 0:
+            return None
+        return torch.cat([f[:c] for f, c in zip(full, counts.tolist())]).cpu().numpy().astype(np.uint64)
 
 
-def _gather_buffers(world, device, width):
-    """Staging reused from step to step: a (pinned, on GPUs) host record, its device copy and
-    the world x width table the collective fills."""
-    import torch
-    key = (world, str(device), width)
-    b = _buffers.get(key)
-    if b is None:
-        host = torch.zeros(width, dtype=torch.int64)
-        if device.type == "cuda":
-            host = host.pin_memory()
-        b = _buffers[key] = dict(host=host, view=host.numpy(),
-                                 rec=torch.zeros(width, dtype=torch.int64, device=device),
-                                 table=torch.zeros(world * width, dtype=torch.int64, device=device), flat_ok=True)
-    return b
-
-
-def _all_gather(dist, b, world, width):
-    """One collective into the contiguous table (falls back to the list form where the
-    backend has no all_gather_into_tensor)."""
-    if b["flat_ok"]:
-        try:
-            dist.all_gather_into_tensor(b["table"], b["rec"])
-            return
-        except (RuntimeError, NotImplementedError, AttributeError):
-            b["flat_ok"] = False
-    dist.all_gather(list(b["table"].view(world, width).unbind(0)), b["rec"])
+_gatherers = {}
 
 
 def gather_offsets(offsets, rank, world, device, dist):
-    """All ranks call this with their ascending uint64 offsets (already global).  Rank 0
-    gets the concatenation in rank order (= globally ascending), the others get None.
-
-    The payload is tiny and latency-bound (8 B per match), so the common case is ONE
-    collective: an all_gather of fixed-width records [count, offsets...] (64 KiB per rank;
-    on the 8-GPU xGMI mesh every peer is one hop away) into one contiguous table, followed by
-    ONE device-to-host copy per rank.  Every
-    rank sees every count, so all ranks agree without further traffic on whether some list did
-    not fit; only then a second, padded all_gather of the full lists follows."""
-    import torch
-    width = GATHER_WIDTH
-    mine = np.ascontiguousarray(offsets).astype(np.int64)
-    b = _gather_buffers(world, device, width)
-    k = min(mine.size, width - 1)
-    b["view"][0] = mine.size
-    b["view"][1:1 + k] = mine[:k]
-    b["rec"].copy_(b["host"], non_blocking=True)          # stream ordered before the collective
-    _all_gather(dist, b, world, width)
-    # one contiguous device-to-host copy on every rank (a strided read of the counts column
-    # alone would cost a gather kernel plus the copy)
-    host_table = b["table"].view(world, width).cpu().numpy()
-    counts = host_table[:, 0].copy()
-    if int(counts.max()) <= width - 1:
-        if rank != 0:
-            return None
-        return np.concatenate([host_table[r, 1:1 + counts[r]] for r in range(world)]).astype(np.uint64)
-    longest = int(counts.max())
-    padded = torch.zeros(longest, dtype=torch.int64, device=device)
-    padded[: mine.size] = torch.from_numpy(mine).to(device)
-    full = [torch.empty(longest, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(full, padded)
-    if rank != 0:
-        return None
-    return torch.cat([f[:c] for f, c in zip(full, counts.tolist())]).cpu().numpy().astype(np.uint64)
+    """Synchronous form: start() + finish() of a cached OffsetGather."""
+    key = (rank, world, str(device), GATHER_WIDTH)
+    g = _gatherers.get(key)
+    if g is None:
+        g = _gatherers[key] = OffsetGather(rank, world, device, dist)
+    return g.finish(g.start(offsets, async_op=False))

@@ -23,6 +23,17 @@ try:
         offs = np.sort(rng.choice(1 << 40, size=n, replace=False)).astype(np.uint64)
         got = mm.partition.gather_offsets(offs, 0, 1, dev, dist)
         assert got.dtype == np.uint64 and got.tolist() == offs.tolist(), n
+    # the overlapped form bench.py uses at N > 1: start k, finish k-1
+    g = mm.partition.OffsetGather(0, 1, dev, dist)
+    lists = [np.sort(rng.choice(1 << 40, size=n, replace=False)).astype(np.uint64) for n in (4223, 0, 9000, 17, 4223)]
+    done, pending = [], None
+    for l in lists:
+        h = g.start(l)
+        if pending is not None:
+            done.append(g.finish(pending))
+        pending = h
+    done.append(g.finish(pending))
+    assert [d.tolist() for d in done] == [l.tolist() for l in lists]
     # and the engine next to torch, the way bench.py sets it up
     eng = mm.Engine(0)
     buf = torch.zeros((1 << 20) + 32, dtype=torch.uint8, device=dev)

@@ -64,6 +64,62 @@ def test_partition_and_gather_world2(elem, kw, be, width):
     assert len(got) >= 6 and got == sorted(got)
 
 
+def _pipelined_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from conftest import load_package as lp
+    mm = lp()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = mm.partition.OffsetGather(rank, world, torch.device("cpu"), dist, width=64)
+        rng = np.random.default_rng(5)                      # same stream on both ranks: both know every list
+        rounds = []
+        for k in range(9):
+            sizes = [int(rng.integers(0, 40)) if k % 3 else int(rng.integers(60, 200)) for _ in range(world)]
+            lists = [np.sort(rng.choice(1 << 30, size=n, replace=False)).astype(np.uint64) + np.uint64(r << 32)
+                     for r, n in enumerate(sizes)]
+            rounds.append(lists)
+        got, pending = [], None
+        for lists in rounds:                                # the bench's pattern: start k, then finish k-1
+            h = g.start(lists[rank])
+            if pending is not None:
+                got.append(g.finish(pending))
+            pending = h
+        got.append(g.finish(pending))
+        if rank == 0:
+            q.put([(a.tolist(), np.concatenate(l).tolist()) for a, l in zip(got, rounds)])
+        else:
+            assert all(x is None for x in got)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_gather_world2():
+    """OffsetGather.start / finish with one gather in flight while the next is started (what
+    bench.py does at N > 1), including rounds whose lists overflow the fixed-width record."""
+    import torch.multiprocessing as mp
+    load_package()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pipelined_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    pairs = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len(pairs) == 9
+    for got, want in pairs:
+        assert got == want
+
+
 def test_shard_ranges_tile_the_rom():
     mm = load_package()
     total, block, L = (64 << 20) + 12345, 524288, 12
