@@ -158,7 +158,9 @@ int mmh_timing_history(mmh_ctx *ctx, float *filter_ms, float *total_ms, int cap,
 /* Counters of the last scan: [0] candidates, [1] matches, [2] resolver tiles walked,
  * [3] path taken (0 filter + resolver, 1 sequential engine, 2 filter + resolver + hard resolver,
  * 3 dense engine, 4 filter + resolver, then the dense engine on the domains whose candidates the
- * resolvers could not settle -- [2] is the number of such domains then). */
+ * resolvers could not settle -- [2] is the number of such domains then, 5 candidate flood: the
+ * dense engine on the domains that hold most candidates, filter + resolver on the rest -- [2] is
+ * the number of flooded domains). */
 int mmh_last_counters(mmh_ctx *ctx, uint64_t *c4);
 /* How the streaming filter keys on a plan (host only, no device needed; tests and tuning):
  * info[0] number of SWAR conditions (0 = none: the dense engine runs), [1] anchor keyword

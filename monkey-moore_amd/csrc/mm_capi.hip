@@ -369,7 +369,8 @@ struct Outcome {
 // enqueue [zero counters] -> engine kernels -> ordering into pinned host memory; `ev` = the
 // scan's event triple {start, behind the streaming kernel, end}
 int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev, const MmGeom &g, const mmh_plan_desc &pl,
-                     const mm::FilterChoice &fc, bool sequential, uint64_t base_offset, uint32_t max_candidates)
+                     const mm::FilterChoice &fc, bool sequential, uint64_t base_offset, uint32_t max_candidates,
+                     const uint32_t *skip_bits = nullptr)
 {
    mm::ResolveBuffers rb;
    rb.cand = w.d_cand; rb.cand_cap = w.cand_cap; rb.out = w.d_out; rb.out_cap = w.out_cap; rb.ctrl = w.d_ctrl;
@@ -386,7 +387,7 @@ int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev,
    // The scan's three events ride on kernel dispatches (hipExtLaunchKernelGGL) where they can:
    // a hipEventRecord between dependent kernels costs ~6 us of stream time on this stack.
    if (!sequential) {
-      mm::launch_filter(st, g, pl, fc, w.d_cand, w.d_ctrl, w.cand_cap, ev[0], ev[1]);
+      mm::launch_filter(st, g, pl, fc, w.d_cand, w.d_ctrl, w.cand_cap, ev[0], ev[1], nullptr, skip_bits);
       mm::launch_resolve(st, g, pl, rb, base_offset, max_candidates);
    }
    else {
@@ -453,11 +454,11 @@ int finish_pipeline(MmWorkspace &w, hipStream_t st, hipEvent_t *ev, const MmGeom
 }
 
 int run_pipeline(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, const mm::FilterChoice &fc, bool sequential,
-                 uint64_t base_offset, uint32_t max_candidates, Outcome *oc)
+                 uint64_t base_offset, uint32_t max_candidates, Outcome *oc, const uint32_t *skip_bits = nullptr)
 {
    begin_scan_events(c, !sequential);
    c->scans_recorded++;
-   int rc = enqueue_pipeline(c, c->ws[0], c->stream, c->ev, g, pl, fc, sequential, base_offset, max_candidates);
+   int rc = enqueue_pipeline(c, c->ws[0], c->stream, c->ev, g, pl, fc, sequential, base_offset, max_candidates, skip_bits);
    if (rc != MMH_OK) {
       return rc;
    }
@@ -665,6 +666,139 @@ int run_flagged_domains(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, ui
    return MMH_OK;
 }
 
+// A scan with more candidates than the per-candidate path takes (a keyword that matches a
+// whole padding run, say: 'abcde' on a +1 ramp, 'aaaa' on zeros).  Instead of sending the whole
+// ROM to the forward engine: (1) count pass -- the filter again, counting candidates per domain;
+// (2) the fullest domains are flagged until the rest fits; (3) the filter + resolver pipeline
+// with the flagged domains masked out; (4) the forward engine over the flagged domains;
+// (5) merge.  Engine mode only.  *handled = false: no use (floods everywhere) -> caller's fallback.
+int run_candidate_floods(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, const mm::FilterChoice &fc, uint64_t base_offset,
+                         uint32_t max_candidates, std::vector<uint64_t> *merged, uint64_t *domains_flagged, bool *handled)
+{
+   hipStream_t st = c->stream;
+   MmWorkspace &w = c->ws[0];
+   *handled = false;
+   const uint64_t ndom = g.nblocks * g.S;
+   if (ndom < 2 || ndom > (1ull << 26)) {
+      return MMH_OK;
+   }
+   const uint64_t words = (ndom + 31) / 32;
+   // one scratch allocation, as u32: [ndom counts][words bitmap][ndom domain list]
+   int rc = grow(&c->d_sort_in, &c->sort_in_cap, (2 * ndom + words) / 2 + 4);
+   if (rc != MMH_OK) {
+      return rc;
+   }
+   unsigned int *d_count = reinterpret_cast<unsigned int *>(c->d_sort_in);
+   uint32_t *d_bits = reinterpret_cast<uint32_t *>(d_count + ndom);
+   uint32_t *d_list = d_bits + words;
+   HIP_TRY(hipMemsetAsync(d_count, 0, ndom * sizeof(unsigned int), st));
+   HIP_TRY(hipMemsetAsync(w.d_ctrl, 0, mm::ctrl_bytes(), st));
+   w.ctrl_clean = false;
+   mm::launch_filter(st, g, pl, fc, w.d_cand, w.d_ctrl, w.cand_cap, nullptr, nullptr, d_count, nullptr);
+   HIP_TRY(hipGetLastError());
+   std::vector<unsigned int> count(ndom);
+   HIP_TRY(hipMemcpyAsync(count.data(), d_count, ndom * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+   HIP_TRY(hipStreamSynchronize(st));
+
+   // flag the fullest domains until what is left fits the per-candidate path comfortably
+   std::vector<uint32_t> order(ndom);
+   unsigned long long total = 0;
+   for (uint64_t d = 0; d < ndom; d++) {
+      order[d] = (uint32_t)d;
+      total += count[d];
+   }
+   std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return count[x] > count[y]; });
+   std::vector<uint32_t> bits(words, 0), doms;
+   for (uint64_t k = 0; k < ndom && total > max_candidates / 2; k++) {
+      const uint32_t d = order[k];
+      bits[d >> 5] |= 1u << (d & 31);
+      doms.push_back(d);
+      total -= count[d];
+   }
+   if (doms.empty() || doms.size() > ndom / 2) {
+      return MMH_OK;                              // candidates everywhere: the forward engine on everything it is
+   }
+   std::sort(doms.begin(), doms.end());
+   HIP_TRY(hipMemcpyAsync(d_bits, bits.data(), words * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+   HIP_TRY(hipMemcpyAsync(d_list, doms.data(), doms.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+
+   Outcome oc;
+   rc = run_pipeline(c, g, pl, fc, false, base_offset, max_candidates, &oc, d_bits);
+   if (rc != MMH_OK) {
+      return rc;
+   }
+   if (oc.candidates > w.out_cap || oc.candidates > max_candidates) {
+      return MMH_OK;                              // still too much for the resolvers: caller's fallback
+   }
+   std::vector<uint64_t> sparse;
+   if (oc.hard_overflow) {
+      // On top of the flood, more undecidable candidates than the left-over lists take: flag
+      // their domains as well (the flag pass of run_flagged_domains, flooded domains masked out).
+      mm::ResolveBuffers rb;
+      rb.cand = w.d_cand; rb.cand_cap = w.cand_cap; rb.out = w.d_out; rb.out_cap = w.out_cap; rb.ctrl = w.d_ctrl;
+      rb.mid_off = w.d_mid_off; rb.mid_hi = w.d_mid_hi; rb.mid_set = w.d_mid_set; rb.mid_slot = w.d_mid_slot;
+      rb.hard_off = w.d_hard_off; rb.hard_hi = w.d_hard_hi; rb.hard_set = w.d_hard_set; rb.hard_slot = w.d_hard_slot;
+      rb.scratch = w.d_scratch;
+      // (the second resolver phase may have run and left the control block zeroed: filter again)
+      HIP_TRY(hipMemsetAsync(w.d_ctrl, 0, mm::ctrl_bytes(), st));
+      mm::launch_filter(st, g, pl, fc, w.d_cand, w.d_ctrl, w.cand_cap, nullptr, nullptr, nullptr, d_bits);
+      mm::launch_resolve(st, g, pl, rb, base_offset, max_candidates, d_bits);
+      HIP_TRY(hipGetLastError());
+      std::vector<uint64_t> slots(oc.candidates);
+      HIP_TRY(hipMemcpyAsync(bits.data(), d_bits, words * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(slots.data(), w.d_out, slots.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      w.ctrl_clean = false;
+      doms.clear();
+      for (uint64_t d = 0; d < ndom; d++) {
+         if ((bits[d >> 5] >> (d & 31)) & 1u) {
+            doms.push_back((uint32_t)d);
+         }
+      }
+      if (doms.size() > ndom / 2) {
+         return MMH_OK;
+      }
+      HIP_TRY(hipMemcpyAsync(d_list, doms.data(), doms.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+      for (uint64_t v : slots) {
+         if (v == ~0ull) {
+            continue;
+         }
+         const uint64_t o = v - base_offset;
+         const uint64_t blk = o / g.block_bytes;
+         const uint64_t d = blk * g.S + (o - blk * g.block_bytes) % g.S;
+         if (((bits[d >> 5] >> (d & 31)) & 1u) == 0) {
+            sparse.push_back(v);
+         }
+      }
+      std::sort(sparse.begin(), sparse.end());
+   }
+   else if (oc.sorted_on_device) {
+      sparse.assign(w.h_result + kHeaderWords, w.h_result + kHeaderWords + oc.matches);
+   }
+   else {
+      rc = sort_to_host(c, w.d_out, oc.listed, &sparse);
+      if (rc != MMH_OK) {
+         return rc;
+      }
+   }
+   std::vector<uint64_t> dense;
+   for (int attempt = 0; attempt < 4; attempt++) {
+      bool grew = false;
+      rc = run_dense(c, g, pl, base_offset, &dense, &grew, d_list, doms.size());
+      if (rc != MMH_OK) {
+         return rc;
+      }
+      if (!grew) {
+         break;
+      }
+   }
+   merged->resize(sparse.size() + dense.size());
+   std::merge(sparse.begin(), sparse.end(), dense.begin(), dense.end(), merged->begin());
+   *domains_flagged = doms.size();
+   *handled = true;
+   return MMH_OK;
+}
+
 int check_scan_args(const mmh_ctx *c, const mmh_plan_desc *plan, const char *who)
 {
    if (!c->rom) {
@@ -741,7 +875,7 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
 
    Outcome oc;
    std::vector<uint64_t> long_list;
-   bool host_list = false, flagged_domains = false;
+   bool host_list = false, flagged_domains = false, flooded_domains = false;
    for (int attempt = 0; attempt < 6; attempt++) {
       if (mode == DENSE) {
          bool grew = false;
@@ -757,7 +891,7 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
          host_list = true;
          break;
       }
-      rc = run_pipeline(c, g, *plan, fc, mode == SEQUENTIAL, base_offset, max_candidates, &oc);
+         rc = run_pipeline(c, g, *plan, fc, mode == SEQUENTIAL, base_offset, max_candidates, &oc);
       if (rc != MMH_OK) {
          return rc;
       }
@@ -771,6 +905,20 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
          host_list = true;
          flagged_domains = true;
          break;
+      }
+      if (mode == FAST && !g.whole && (oc.candidates > c->ws[0].out_cap || oc.candidates > max_candidates)) {
+         // candidate flood: forward engine on the flooded domains, the per-candidate path on the rest
+         bool handled = false;
+         rc = run_candidate_floods(c, g, *plan, fc, base_offset, max_candidates, &long_list, &oc.tiles, &handled);
+         if (rc != MMH_OK) {
+            return rc;
+         }
+         if (handled) {
+            oc.matches = long_list.size();
+            host_list = true;
+            flooded_domains = true;
+            break;
+         }
       }
       if (mode == FAST && (oc.candidates > c->ws[0].out_cap || oc.candidates > max_candidates || oc.hard_overflow)) {
          mode = DENSE;                            // too dense / too long for the per-candidate resolvers
@@ -799,7 +947,7 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
    c->counters[0] = oc.candidates;
    c->counters[1] = oc.matches;
    c->counters[2] = oc.tiles;
-   c->counters[3] = mode == SEQUENTIAL ? 1 : (mode == DENSE ? 3 : (flagged_domains ? 4 : (oc.hard ? 2 : 0)));
+   c->counters[3] = mode == SEQUENTIAL ? 1 : (mode == DENSE ? 3 : (flooded_domains ? 5 : (flagged_domains ? 4 : (oc.hard ? 2 : 0))));
 
    *out_count = oc.matches;
    if (oc.matches > cap) {

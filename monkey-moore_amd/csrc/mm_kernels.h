@@ -31,10 +31,12 @@ bool choose_filter(const mmh_plan_desc &pl, FilterChoice *fc);
 // true: the filter kernel runs the full compare loop on its survivors; false: mm_resolve does
 bool filter_verifies(const mmh_plan_desc &pl, const FilterChoice &fc);
 
-// start / stop (optional): HIP events carried by the first / last filter kernel's own dispatch
+// start / stop (optional): HIP events carried by the first / last filter kernel's own dispatch.
+// dom_count: count pass (candidates per domain, nothing listed); skip_bits: candidates of the
+// flagged domains are dropped (both for candidate floods, engine mode)
 void launch_filter(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc,
                    uint64_t *cand, unsigned long long *ctrl, uint64_t cand_cap, hipEvent_t start = nullptr,
-                   hipEvent_t stop = nullptr);
+                   hipEvent_t stop = nullptr, unsigned int *dom_count = nullptr, const uint32_t *skip_bits = nullptr);
 
 // Device buffers of one scan.  ctrl is zeroed before every scan; layout: MM_CTRL_* in
 // mm_internal.h.  cand holds MM_CAND_LISTS candidate lists of cand_cap / MM_CAND_LISTS entries.

@@ -138,6 +138,13 @@ __device__ __forceinline__ bool mm_locate(const MmGeom &g, uint64_t o, uint64_t 
    return *j < mm_domain_nv(g, *b, *p);
 }
 
+// first active lane's value (wave uniform)
+__device__ __forceinline__ uint64_t mm_uniform64_k(uint64_t v)
+{
+   return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) |
+          ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32);
+}
+
 // wave-aggregated append (ballot + prefix popcount -> one atomic per wave)
 __device__ __forceinline__ void mm_append(uint64_t *list, unsigned long long *count, uint64_t cap, bool want, uint64_t value)
 {
@@ -205,6 +212,10 @@ struct MmFilterArgs {
    uint64_t *cand;         // MM_CAND_LISTS lists of candidate byte offsets, list_cap entries each
    unsigned long long *list_count;   // their counters, MM_LIST_STRIDE words apart (mm_internal.h)
    uint64_t list_cap;
+   // candidate floods (engine mode, see run_candidate_floods in mm_capi.hip); both null in a normal scan
+   unsigned int *dom_count;          // count pass: candidates per domain instead of the lists
+   const uint32_t *skip_bits;        // filtered pass: candidates of flagged domains are dropped
+
    uint64_t ngroups;       // span kernel: number of whole 4 KiB groups it covers
    uint32_t groups_per_span;
    uint64_t edge_first;    // edge kernel: 16-byte chunks [edge_first, nchunks)
@@ -215,6 +226,59 @@ __device__ __forceinline__ void mm_cand_append(const MmFilterArgs &a, bool want,
 {
    const uint32_t c = blockIdx.x & (MM_CAND_LISTS - 1);
    mm_append(a.cand + (uint64_t)c * a.list_cap, a.list_count + c * MM_LIST_STRIDE, a.list_cap, want, off);
+}
+
+// Where the survivors go: the candidate lists -- or, in the two passes that deal with candidate
+// floods, a per-domain count (one atomic per wave and domain) / the lists minus the flagged domains.
+__device__ __forceinline__ void mm_cand_emit(const MmFilterArgs &a, bool want, uint64_t off)
+{
+   if (a.dom_count || a.skip_bits) {                       // wave uniform
+      uint64_t b = 0; uint32_t p = 0; int64_t j = 0;
+      const bool located = want && mm_locate(a.g, off, &b, &p, &j);
+      const uint32_t dom = located ? (uint32_t)(b * a.g.S + p) : 0u;
+      if (a.dom_count) {
+         unsigned long long todo = __ballot(located);
+         while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t d = (uint32_t)__shfl((int)dom, leader);
+            const unsigned long long same = __ballot(located && dom == d);
+            if ((int)__lane_id() == leader) {
+               atomicAdd(a.dom_count + d, (unsigned int)__popcll(same));
+            }
+            todo &= ~same;
+         }
+         return;
+      }
+      want = located && ((a.skip_bits[dom >> 5] >> (dom & 31)) & 1u) == 0;
+   }
+   mm_cand_append(a, want, off);
+}
+
+// All survivors of a piece at once: every lane brings `cnt` candidates; one atomic for the wave
+// reserves their slots and returns this lane's first one (the caller stores while slot < cap).
+// A padding run that matches the keyword wholesale has 16 survivors per lane and piece: one
+// round trip per piece instead of sixteen.
+__device__ __forceinline__ uint64_t *mm_cand_reserve(const MmFilterArgs &a, uint32_t cnt, uint32_t *first, uint32_t *room)
+{
+   // returns (wave uniform) the address of the wave's first reserved slot; *first = this lane's
+   // first slot relative to it, *room = how many of the wave's slots exist at all (list capacity)
+   const uint32_t c = blockIdx.x & (MM_CAND_LISTS - 1);
+   uint32_t incl = cnt;
+#pragma unroll
+   for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t v = (uint32_t)__shfl_up((int)incl, d);
+      incl += (int)__lane_id() >= d ? v : 0u;
+   }
+   const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+   unsigned long long base = 0;
+   if (__lane_id() == 0) {
+      base = atomicAdd(a.list_count + c * MM_LIST_STRIDE, (unsigned long long)total);
+   }
+   const uint64_t b = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base) |
+                      ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32);
+   *first = incl - cnt;
+   *room = b >= a.list_cap ? 0u : (uint32_t)((a.list_cap - b) > 0xFFFFFFFFull ? 0xFFFFFFFFull : (a.list_cap - b));
+   return a.cand + (uint64_t)c * a.list_cap + b;
 }
 
 __device__ __forceinline__ uint4 mm_load_chunk(const uint8_t *rom, uint64_t nbytes, uint64_t byte0)
@@ -315,6 +379,47 @@ __device__ __forceinline__ uint32_t mm_f8_pack(const uint32_t (&h)[4])
 // and append the real candidates; the whole wave takes part (ballots inside)
 __device__ __forceinline__ void mm_f8_survivors(const MmFilterArgs &a, uint64_t chunk0, uint32_t bits)
 {
+   const bool head = __ballot(bits != 0 && chunk0 < MMH_MAX_KEYWORD) != 0;   // a survivor may lie in front of the anchor
+   bool batch = !a.verify && !a.dom_count && !a.skip_bits && !head;
+   if (!a.verify && !head && !batch && !a.g.whole) {
+      // Flood handling passes, 8-bit: a piece lies in ONE block (= domain) nearly always.  Then
+      // the count pass adds the piece's survivors with one atomic and the filtered pass drops
+      // or keeps them wholesale, instead of locating every survivor on its own.
+      const uint64_t blk = (chunk0 - a.iA) / a.g.block_bytes;
+      const uint64_t blk_last = (chunk0 + 15 - a.iA) / a.g.block_bytes;
+      const uint64_t lead = mm_uniform64_k(blk);
+      if (__ballot(bits != 0 && (blk != lead || blk_last != lead)) == 0) {
+         if (a.dom_count) {
+            uint32_t n = (uint32_t)__popc(bits);
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+               n += (uint32_t)__shfl_xor((int)n, d);
+            }
+            if (__lane_id() == 0 && n) {
+               atomicAdd(a.dom_count + lead, n);
+            }
+            return;
+         }
+         if ((a.skip_bits[lead >> 5] >> (lead & 31)) & 1u) {
+            return;                              // a flagged domain: the forward engine has it
+         }
+         batch = true;
+      }
+   }
+   // the usual case (the resolver verifies, not the ROM's first bytes): everything in one go
+   if (batch) {
+      uint32_t slot, room;
+      uint64_t *list = mm_cand_reserve(a, (uint32_t)__popc(bits), &slot, &room);
+      while (bits) {
+         const int bit = __ffs((int)bits) - 1;
+         bits &= bits - 1;
+         if (slot < room) {
+            list[slot] = chunk0 + 4 * (bit & 3) + (bit >> 3) - a.iA;
+         }
+         slot++;
+      }
+      return;
+   }
    while (__ballot(bits != 0) != 0) {
       bool want = false;
       uint64_t off = 0;
@@ -323,7 +428,7 @@ __device__ __forceinline__ void mm_f8_survivors(const MmFilterArgs &a, uint64_t 
          bits &= bits - 1;
          const int64_t t = (int64_t)(chunk0 + 4 * (bit & 3) + (bit >> 3));
          const int64_t o = t - (int64_t)a.iA;
-         // With four SWAR conditions practically every survivor is a real candidate and the
+         // With enough SWAR conditions practically every survivor is a real candidate and the
          // resolver (which stages the bytes anyway) verifies it; running the dependent-load
          // compare loop here would stall this wave's stream for microseconds per survivor.
          if (a.verify ? mm_is_candidate(a.g, a.plan, o) : (o >= 0)) {
@@ -331,7 +436,7 @@ __device__ __forceinline__ void mm_f8_survivors(const MmFilterArgs &a, uint64_t 
             off = (uint64_t)o;
          }
       }
-      mm_cand_append(a, want, off);
+      mm_cand_emit(a, want, off);
    }
 }
 
@@ -554,6 +659,20 @@ __device__ __forceinline__ uint32_t mm_f16_pack(const uint32_t (&he)[4], const u
 
 __device__ __forceinline__ void mm_f16_survivors(const MmFilterArgs &a, uint64_t chunk0, uint32_t bits)
 {
+   if (!a.verify && !a.dom_count && !a.skip_bits && __ballot(bits != 0 && chunk0 < 2 * MMH_MAX_KEYWORD + 2) == 0) {
+      uint32_t slot, room;
+      uint64_t *list = mm_cand_reserve(a, (uint32_t)__popc(bits), &slot, &room);
+      while (bits) {
+         const int bit = __ffs((int)bits) - 1;
+         bits &= bits - 1;
+         const int j = bit >> 2, odd = (bit >> 1) & 1, half = bit & 1;
+         if (slot < room) {
+            list[slot] = chunk0 + 4 * j + 2 * half - odd - 2 * (uint64_t)a.iA;
+         }
+         slot++;
+      }
+      return;
+   }
    while (__ballot(bits != 0) != 0) {
       bool want = false;
       uint64_t off = 0;
@@ -568,7 +687,7 @@ __device__ __forceinline__ void mm_f16_survivors(const MmFilterArgs &a, uint64_t
             off = (uint64_t)o;
          }
       }
-      mm_cand_append(a, want, off);
+      mm_cand_emit(a, want, off);
    }
 }
 
@@ -1092,7 +1211,8 @@ static bool launch_filter_u8_masks(uint32_t mask2, std::integer_sequence<int, M2
 }
 
 void launch_filter(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc,
-                   uint64_t *cand, unsigned long long *ctrl, uint64_t cand_cap, hipEvent_t start, hipEvent_t stop)
+                   uint64_t *cand, unsigned long long *ctrl, uint64_t cand_cap, hipEvent_t start, hipEvent_t stop,
+                   unsigned int *dom_count, const uint32_t *skip_bits)
 {
    MmFilterArgs a;
    a.g = g; a.plan = pl; a.iA = fc.iA; a.ncond = fc.ncond;
@@ -1102,6 +1222,7 @@ void launch_filter(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, con
       a.sh[k] = 32u - 8u * fc.shift[k];
    }
    a.cand = cand; a.list_count = ctrl + MM_CTRL_LISTS; a.list_cap = cand_cap / MM_CAND_LISTS;
+   a.dom_count = dom_count; a.skip_bits = skip_bits;
    // whole 4 KiB groups go to the span kernel, the ragged end to the bounds-checked one
    a.ngroups = g.nbytes / 4096;
    a.groups_per_span = filter_groups_per_span();

@@ -470,3 +470,33 @@ def test_flood_of_undecidable_candidates_uses_flagged_domains(mm, gpu_engine, or
     assert _scan_both(gpu_engine, plan, block_bytes=block).tolist() == want.tolist()
     t = gpu_engine.submit(plan, block_bytes=block)
     assert gpu_engine.collect(t).tolist() == want.tolist()
+
+
+@pytest.mark.parametrize("kw,elem,hard", [("abcde", 1, 0), ("aaaa", 1, 0), ("aaaa", 2, 0), ("abcde", 1, 360)])
+def test_candidate_flood_in_a_padding_run(mm, gpu_engine, oracle, kw, elem, hard):
+    # The bench ROM has 1 MiB runs of 0x00, 0xFF and a +1 ramp.  A keyword that matches a whole run
+    # ('abcde' on the ramp, 'aaaa' on the constants) floods the candidate lists from two or three
+    # domains: the forward engine takes those domains, the per-candidate path the rest (path 5).
+    # hard > 0: on top of that, more undecidable candidates ('abcde' plants, test_hard_candidates)
+    # than the hard list takes, in 12 more domains -- those domains join the flooded ones.
+    n, block = 64 << 20, 524288
+    spec = mm.synth.RomSpec(42, n, kw, elem, None, False, block, plants_per_mib=0 if kw in ("abcde", "aaaa") else 4)   # (plants of these two are undecidable one by one)
+    gpu_engine.alloc(n)
+    spec.apply_device(gpu_engine)
+    word = np.array([ord(c) + 20 for c in kw], dtype=np.uint8 if elem == 1 else "<u2").view(np.uint8)
+    for k in range(hard):
+        gpu_engine.poke((40 + k % 12) * block + 3000 + 7777 * (k // 12), word)
+    rom = gpu_engine.download(0, n)
+    plan, oplan = mm.plan_relative(elem, kw), oracle.plan(elem, kw)
+    got = gpu_engine.scan(plan, block_bytes=block, cap=1 << 21)
+    ctr = gpu_engine.counters()
+    want = oracle.engine(oplan, rom, block)
+    assert got.tolist() == want.tolist()
+    assert len(want) > 100000                                  # the run(s) matched wholesale
+    lo, hi = (1, 8) if not hard else (10, 40)
+    assert ctr["path"] == 5 and lo <= ctr["tiles_walked"] <= hi, ctr      # [2] = domains given to the forward engine
+    gpu_engine.set_engine(2)
+    assert gpu_engine.scan(plan, block_bytes=block, cap=1 << 21).tolist() == want.tolist()
+    gpu_engine.set_engine(0)
+    t = gpu_engine.submit(plan, block_bytes=block)
+    assert gpu_engine.collect(t, cap=1 << 21).tolist() == want.tolist()
