@@ -142,6 +142,54 @@ int mmh_scan_submit(mmh_ctx *ctx, const mmh_plan_desc *plan, uint64_t block_byte
                     uint64_t base_offset, int *ticket);
 int mmh_scan_collect(mmh_ctx *ctx, int ticket, uint64_t *out, uint64_t cap, uint64_t *out_count);
 
+/* ---- multi-GPU: block-aligned partitions + RCCL gather of the offset lists ----------------
+ * Replaces the reference's thread dispatcher and merge (src/core/search_engine.cpp:66-188,
+ * :193-197).  Every SearchBlock is an independent chain, so the file is dealt out in whole
+ * blocks and the only communication is the gather of the ascending per-GPU lists (partitions
+ * are in rank order: concatenation is globally ascending).  The collective is issued by this
+ * library (librccl, ncclAllGather over xGMI) from the device-side copy of the ordered list every
+ * scan leaves in HBM; see csrc/mm_multi.hip. */
+
+/* Rank's partition of a file of total_bytes: the blocks [rank*nb/nranks, (rank+1)*nb/nranks)
+ * plus (keyword_len-1)*elem_bytes bytes of pattern-length overlap into the next partition
+ * (search_engine.cpp:227-230), clipped to the file.  Host only. */
+int mmh_partition(uint64_t total_bytes, uint64_t block_bytes, uint32_t keyword_len, uint32_t elem_bytes, int rank,
+                  int nranks, uint64_t *first_byte, uint64_t *nbytes);
+
+/* Communicator of a context.  One process per GPU: rank 0 calls mmh_comm_unique_id, the
+ * launcher distributes the MMH_COMM_ID_BYTES bytes (torch.distributed store, MPI, a file ...),
+ * every rank calls mmh_comm_init_rank (collective: returns when all ranks have joined).
+ * One process, several GPUs: mmh_comm_init_all over contexts on distinct devices (context i
+ * becomes rank i).  mmh_destroy releases the communicator. */
+#define MMH_COMM_ID_BYTES 128
+int mmh_comm_unique_id(void *id128);
+int mmh_comm_init_rank(mmh_ctx *ctx, const void *id128, int nranks, int rank);
+int mmh_comm_init_all(mmh_ctx *const *ctxs, int n);
+int mmh_comm_info(mmh_ctx *ctx, int *rank, int *nranks);     /* nranks 0: no communicator */
+void mmh_comm_destroy(mmh_ctx *ctx);
+
+/* Gather of the offset lists of all ranks, split in two so that the collective overlaps the
+ * next scan: mmh_gather_start enqueues it on the context's communication stream and returns;
+ * mmh_gather_finish waits and delivers the concatenation in rank order.  Every rank calls both,
+ * in the same order; at most two gathers may be outstanding; finish them oldest first.
+ *   offsets == NULL, n == 0 : the list of the most recent mmh_scan of this context, sent from
+ *                             HBM without a host round trip (the usual case);
+ *   offsets != NULL         : n ascending offsets in host memory.
+ *   want_list               : 0 on ranks that only need the total (finish with out == NULL).
+ * MMH_E_CAPACITY from finish leaves the gather outstanding: finish again with more room. */
+int mmh_gather_start(mmh_ctx *ctx, const uint64_t *offsets, uint64_t n, int want_list);
+int mmh_gather_finish(mmh_ctx *ctx, uint64_t *out, uint64_t cap, uint64_t *out_count);
+/* of the last finished gather, in ms: [0] collective + packing on the device (HIP events on the
+ * communication stream), [1] host time inside mmh_gather_start + mmh_gather_finish */
+int mmh_last_gather_timings(mmh_ctx *ctx, float *ms2);
+
+/* One process driving n GPUs: context i (rank i of an mmh_comm_init_all communicator) scans the
+ * ROM partition attached to it with base_offsets[i] -- one host thread per device -- then the
+ * lists are gathered (one grouped collective) and delivered ascending through out, exactly as
+ * mmh_scan delivers one device's.  Engine semantics only make sense here (block_bytes > 0). */
+int mmh_scan_multi(mmh_ctx *const *ctxs, int n, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian,
+                   const uint64_t *base_offsets, uint64_t *out, uint64_t cap, uint64_t *out_count);
+
 /* Engine selection (tests / cross-checks): 0 = auto -- streaming filter + per-candidate
  * resolvers, falling back to the forward "dense" engine for inputs they do not suit;
  * 1 = force the sequential one-lane-per-domain chain kernel; 2 = force the dense engine.

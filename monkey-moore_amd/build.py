@@ -17,6 +17,7 @@ CAPI_SO = os.path.join(LIB_DIR, "libmmoore_hip.so")
 CORE_SO = os.path.join(LIB_DIR, "libmonkey-core.so")
 
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+ROCM_LIB = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")
 ARCH = "gfx950"
 
 
@@ -41,7 +42,7 @@ def build_capi(force=False):
     os.makedirs(LIB_DIR, exist_ok=True)
     obj_dir = os.path.join(LIB_DIR, "obj")
     os.makedirs(obj_dir, exist_ok=True)
-    units = ("mm_kernels.hip", "mm_capi.hip", "mm_ingest.hip", "mm_sort.hip", "mm_plan.cpp")
+    units = ("mm_kernels.hip", "mm_capi.hip", "mm_multi.hip", "mm_ingest.hip", "mm_sort.hip", "mm_plan.cpp")
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(ROOT, "include", "mmoore_hip.h")]
     flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
@@ -54,7 +55,8 @@ def build_capi(force=False):
     with ThreadPoolExecutor(max_workers=4) as pool:
         objs = list(pool.map(compile_unit, units))
     if force or _newer(CAPI_SO, objs):
-        _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", *objs, "-pthread", "-o", CAPI_SO])
+        # librccl: the multi-GPU offset gather (mm_multi.hip) calls RCCL itself
+        _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", *objs, "-pthread", "-L" + ROCM_LIB, "-lrccl", "-o", CAPI_SO])
     return CAPI_SO
 
 

@@ -24,8 +24,8 @@ namespace {
 
 thread_local std::string g_error;
 
-constexpr uint64_t kHeaderWords = 8;                 // counters in front of the ordered list (pinned host memory)
-constexpr uint32_t kMaxRankSort = 16384;             // longest list the device orders
+constexpr uint64_t kHeaderWords = MM_RESULT_HEADER_WORDS;   // counters in front of the ordered list (pinned host memory)
+constexpr uint32_t kMaxRankSort = MM_MAX_RANK_SORT;         // longest list the device orders
 constexpr uint64_t kInitialCap = 1u << 20;
 
 bool hip_ok(hipError_t e, const char *what)
@@ -78,6 +78,9 @@ int ensure_workspace(mmh_ctx *c, MmWorkspace &w, uint64_t out_cap)
       HIP_TRY(hipMalloc(&w.d_scratch, mm::hard_scratch_bytes()));
       HIP_TRY(hipMalloc(&w.d_partials, mm::rank_partials_bytes(kMaxRankSort)));
       HIP_TRY(hipHostMalloc(&w.h_result, (kHeaderWords + kMaxRankSort) * sizeof(uint64_t), hipHostMallocDefault));
+      for (auto &d : w.d_result) {
+         HIP_TRY(hipMalloc(&d, (kHeaderWords + kMaxRankSort) * sizeof(uint64_t)));
+      }
       w.ctrl_clean = false;
    }
    if (out_cap > w.out_cap) {
@@ -114,6 +117,9 @@ void free_workspace(MmWorkspace &w)
    if (w.d_scratch) (void)hipFree(w.d_scratch);
    if (w.d_partials) (void)hipFree(w.d_partials);
    if (w.h_result) (void)hipHostFree(w.h_result);
+   for (auto d : w.d_result) {
+      if (d) (void)hipFree(d);
+   }
    w = MmWorkspace();
 }
 
@@ -197,6 +203,7 @@ extern "C" void mmh_destroy(mmh_ctx *c)
    }
    (void)hipSetDevice(c->device);
    (void)hipStreamSynchronize(c->stream);
+   mmh_comm_destroy(c);
    release_rom(c);
    for (auto &p : c->pending) {
       p.active = false;
@@ -380,6 +387,7 @@ int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev,
    const int count_index = sequential ? 1 : 0;
 
    w.h_result[6] = 0;                          // mm_rank_scatter publishes "matches + 1" here
+   w.result_turn ^= 1;                         // the other device-side copy may still be feeding a gather
    if (!w.ctrl_clean) {
       HIP_TRY(hipMemsetAsync(w.d_ctrl, 0, mm::ctrl_bytes(), st));
    }
@@ -397,8 +405,8 @@ int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev,
    }
    // (first phase: when mm_resolve leaves candidates over, the ordering kernel keeps the control
    // block for the second phase, see finish_pipeline)
-   mm::launch_rank_sort(st, w.d_out, w.d_ctrl, count_index, w.out_cap, kMaxRankSort, w.d_partials, w.h_result, ev[2],
-                        !sequential);
+   mm::launch_rank_sort(st, w.d_out, w.d_ctrl, count_index, w.out_cap, kMaxRankSort, w.d_partials, w.h_result,
+                        w.d_result[w.result_turn], ev[2], !sequential);
    HIP_TRY(hipGetLastError());
    (void)c;
    return MMH_OK;
@@ -444,7 +452,7 @@ int finish_pipeline(MmWorkspace &w, hipStream_t st, hipEvent_t *ev, const MmGeom
    rb.scratch = w.d_scratch;
    w.h_result[6] = 0;
    mm::launch_leftovers(st, g, pl, rb, base_offset);
-   mm::launch_rank_sort(st, w.d_out, w.d_ctrl, 0, w.out_cap, kMaxRankSort, w.d_partials, w.h_result);
+   mm::launch_rank_sort(st, w.d_out, w.d_ctrl, 0, w.out_cap, kMaxRankSort, w.d_partials, w.h_result, w.d_result[w.result_turn]);
    HIP_TRY(hipGetLastError());
    HIP_TRY(hipEventRecord(ev[2], st));
    HIP_TRY(hipEventSynchronize(ev[2]));
@@ -584,6 +592,22 @@ int run_dense(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, uint64_t bas
    return sort_to_host(c, c->d_sort_in, total, found);
 }
 
+// run_dense until its output lists fit (each retry sizes them for the fullest list seen, so the
+// second attempt fits); running out of attempts is an error, never a truncated list
+int run_dense_settled(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, uint64_t base_offset, std::vector<uint64_t> *found,
+                      const uint32_t *dom_list, uint64_t listed_domains)
+{
+   for (int attempt = 0; attempt < 4; attempt++) {
+      bool grew = false;
+      int rc = run_dense(c, g, pl, base_offset, found, &grew, dom_list, listed_domains);
+      if (rc != MMH_OK || !grew) {
+         return rc;
+      }
+   }
+   mmh_set_error("forward engine: the output lists still overflow after 4 attempts");
+   return MMH_E_STATE;
+}
+
 } // namespace
 
 namespace {
@@ -649,15 +673,9 @@ int run_flagged_domains(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, ui
       uint32_t *d_list = d_bits + words + (words & 1);
       HIP_TRY(hipMemcpyAsync(d_list, doms.data(), doms.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
       std::vector<uint64_t> dense;
-      for (int attempt = 0; attempt < 4; attempt++) {
-         bool grew = false;
-         rc = run_dense(c, g, pl, base_offset, &dense, &grew, d_list, doms.size());
-         if (rc != MMH_OK) {
-            return rc;
-         }
-         if (!grew) {
-            break;
-         }
+      rc = run_dense_settled(c, g, pl, base_offset, &dense, d_list, doms.size());
+      if (rc != MMH_OK) {
+         return rc;
       }
       merged->insert(merged->end(), dense.begin(), dense.end());
    }
@@ -782,15 +800,9 @@ int run_candidate_floods(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, c
       }
    }
    std::vector<uint64_t> dense;
-   for (int attempt = 0; attempt < 4; attempt++) {
-      bool grew = false;
-      rc = run_dense(c, g, pl, base_offset, &dense, &grew, d_list, doms.size());
-      if (rc != MMH_OK) {
-         return rc;
-      }
-      if (!grew) {
-         break;
-      }
+   rc = run_dense_settled(c, g, pl, base_offset, &dense, d_list, doms.size());
+   if (rc != MMH_OK) {
+      return rc;
    }
    merged->resize(sparse.size() + dense.size());
    std::merge(sparse.begin(), sparse.end(), dense.begin(), dense.end(), merged->begin());
@@ -841,8 +853,11 @@ uint32_t candidate_limit(const MmWorkspace &w)
 
 } // namespace
 
-extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian,
-                        uint64_t base_offset, uint64_t *out, uint64_t cap, uint64_t *out_count)
+namespace {
+// *kept: the list when it only exists in host memory (long lists, forward engine); *on_device: the
+// list sits ordered in ws[0].d_result[result_turn]
+int scan_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian, uint64_t base_offset, uint64_t *out,
+              uint64_t cap, uint64_t *out_count, std::vector<uint64_t> *kept, bool *on_device)
 {
    if (!c || !plan || !out_count || (!out && cap)) {
       mmh_set_error("mmh_scan: bad argument");
@@ -862,7 +877,7 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
    }
    std::memset(c->counters, 0, sizeof(c->counters));
    if (g.nbytes == 0) {
-      return MMH_OK;
+      return MMH_OK;                              // (an empty host list: the gather sends a count of 0)
    }
 
    mm::FilterChoice fc;
@@ -876,7 +891,8 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
    Outcome oc;
    std::vector<uint64_t> long_list;
    bool host_list = false, flagged_domains = false, flooded_domains = false;
-   for (int attempt = 0; attempt < 6; attempt++) {
+   bool settled = false;                          // the loop ended with a complete result (not by running out of attempts)
+   for (int attempt = 0; attempt < 6 && !settled; attempt++) {
       if (mode == DENSE) {
          bool grew = false;
          rc = run_dense(c, g, *plan, base_offset, &long_list, &grew);
@@ -889,9 +905,10 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
          oc = Outcome();
          oc.matches = long_list.size();
          host_list = true;
+         settled = true;
          break;
       }
-         rc = run_pipeline(c, g, *plan, fc, mode == SEQUENTIAL, base_offset, max_candidates, &oc);
+      rc = run_pipeline(c, g, *plan, fc, mode == SEQUENTIAL, base_offset, max_candidates, &oc);
       if (rc != MMH_OK) {
          return rc;
       }
@@ -904,6 +921,7 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
          oc.matches = long_list.size();
          host_list = true;
          flagged_domains = true;
+         settled = true;
          break;
       }
       if (mode == FAST && !g.whole && (oc.candidates > c->ws[0].out_cap || oc.candidates > max_candidates)) {
@@ -917,6 +935,7 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
             oc.matches = long_list.size();
             host_list = true;
             flooded_domains = true;
+            settled = true;
             break;
          }
       }
@@ -931,7 +950,15 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
          }
          continue;
       }
-      break;
+      settled = true;
+   }
+   if (!settled) {
+      // every retry grows a buffer or switches to an engine that cannot overflow, so two attempts
+      // are the most a scan needs today; running out means that invariant broke -- say so instead
+      // of publishing a truncated list
+      mmh_set_error("mmh_scan: no engine settled the scan in 6 attempts (candidates %llu, listed %llu, capacity %llu)",
+                    (unsigned long long)oc.candidates, (unsigned long long)oc.listed, (unsigned long long)c->ws[0].out_cap);
+      return MMH_E_STATE;
    }
 
    // lists too long for the rank kernels: radix sort on the device, "not a match" slots dropped
@@ -950,21 +977,51 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
    c->counters[3] = mode == SEQUENTIAL ? 1 : (mode == DENSE ? 3 : (flooded_domains ? 5 : (flagged_domains ? 4 : (oc.hard ? 2 : 0))));
 
    *out_count = oc.matches;
+   *on_device = !host_list;
+   rc = MMH_OK;
    if (oc.matches > cap) {
       mmh_set_error("mmh_scan: %llu matches do not fit the caller's buffer of %llu",
                     (unsigned long long)oc.matches, (unsigned long long)cap);
-      return MMH_E_CAPACITY;
+      rc = MMH_E_CAPACITY;
    }
-   if (oc.matches == 0) {
-      return MMH_OK;
+   else if (oc.matches != 0) {
+      std::memcpy(out, host_list ? long_list.data() : c->ws[0].h_result + kHeaderWords, oc.matches * sizeof(uint64_t));
    }
    if (host_list) {
-      std::memcpy(out, long_list.data(), oc.matches * sizeof(uint64_t));
+      kept->swap(long_list);
    }
-   else {
-      std::memcpy(out, c->ws[0].h_result + kHeaderWords, oc.matches * sizeof(uint64_t));
+   return rc;
+}
+} // namespace
+
+// mmh_scan proper + what the multi-GPU gather needs to know about its list (mm_multi.hip)
+extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian,
+                        uint64_t base_offset, uint64_t *out, uint64_t cap, uint64_t *out_count)
+{
+   if (c) {
+      c->mg.last_on_device = false;
+      c->mg.last_count = 0;
+      c->mg.last_list.clear();
+      // an outstanding gather may still be sending the device-side result copy this scan is about
+      // to overwrite (two scans ago): wait for its collective
+      for (auto &s : c->mg.slot) {
+         if (s.busy && !s.from_host && s.src_turn == (c->ws[0].result_turn ^ 1)) {
+            HIP_TRY(hipSetDevice(c->device));
+            HIP_TRY(hipEventSynchronize(s.end));
+         }
+      }
    }
-   return MMH_OK;
+   std::vector<uint64_t> host_list;
+   bool on_device = false;
+   int rc = scan_impl(c, plan, block_bytes, big_endian, base_offset, out, cap, out_count, &host_list, &on_device);
+   if (c && (rc == MMH_OK || rc == MMH_E_CAPACITY)) {
+      c->mg.last_count = *out_count;
+      c->mg.last_on_device = on_device;
+      if (!on_device && c->mg.comm) {
+         c->mg.last_list.swap(host_list);            // only kept when a communicator may ask for it
+      }
+   }
+   return rc;
 }
 
 // ---- two scans in flight ------------------------------------------------------------------

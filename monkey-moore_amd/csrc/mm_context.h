@@ -10,6 +10,14 @@
 
 #include "mmoore_hip.h"
 
+// layout of the block a scan publishes (pinned host memory and its device-side copies):
+// MM_RESULT_HEADER_WORDS counters, then the ordered matches.  Header words: [0] candidates (= result
+// slots of the filter + resolver path), [1] matches appended by the sequential engine, [2] windows
+// mapped, [3] hard candidates / overflow flag, [5] left-overs, [6] matches + 1 (0: not ordered on the
+// device), [7] which of words 0 / 1 is the list length.
+constexpr uint64_t MM_RESULT_HEADER_WORDS = 8;
+constexpr uint32_t MM_MAX_RANK_SORT = 16384;      // longest list the device orders (and a gather record holds)
+
 // pinned staging of mmh_rom_load_file (mm_ingest.hip): two pieces per reader thread
 struct MmIngest {
    static constexpr size_t kPiece = 4u << 20;
@@ -40,7 +48,47 @@ struct MmWorkspace {
    uint8_t *d_scratch = nullptr;    // tile maps of hard candidates
    uint32_t *d_partials = nullptr;  // rank sort partial counts
    uint64_t *h_result = nullptr;    // pinned: [kHeaderWords counters][kMaxRankSort ordered matches], written by the device
+   // Device-side copies of that block, written by the same kernel: what the multi-GPU offset
+   // gather (mm_multi.hip) sends -- the collective never waits for a host round trip.  Two of
+   // them, alternating from scan to scan: the gather of scan k may still be reading its copy
+   // while scan k+1 publishes (the gather overlaps the next scan).
+   uint64_t *d_result[2] = {nullptr, nullptr};
+   int result_turn = 0;             // d_result[result_turn] belongs to the most recent scan
    bool ctrl_clean = false;         // the previous scan's last kernel left d_ctrl zeroed
+};
+
+// One offset gather in flight (mm_multi.hip): the all-gather's receive table, the pinned block the
+// merged list is packed into, and the events that bracket the collective on the comm stream.
+struct MmGatherSlot {
+   uint64_t *d_table = nullptr;     // [nranks][kGatherRecordWords]
+   uint64_t *h_merged = nullptr;    // pinned: [kGatherHeaderWords + nranks counts][merged offsets]
+   uint64_t merged_cap = 0;         // offsets h_merged has room for
+   hipEvent_t begin = nullptr, end = nullptr;
+   bool busy = false;
+   bool from_host = false;          // the local list came from host memory (long lists, forward engine)
+   int src_turn = 0;                // else: which device-side result copy of the scan workspace it sends
+   uint64_t local_count = 0;        // this rank's list length
+   double start_wall_s = 0;         // host time spent in mmh_gather_start
+};
+
+// Multi-GPU state of a context: its RCCL communicator and the gather buffers.
+struct MmComm {
+   void *comm = nullptr;            // ncclComm_t
+   int rank = 0, nranks = 1;
+   hipStream_t stream = nullptr;    // the collective runs here, behind the scan it belongs to
+   MmGatherSlot slot[2];
+   int turn = 0;                    // slot of the next mmh_gather_start
+   int oldest = 0;                  // slot of the next mmh_gather_finish
+   uint64_t *d_send = nullptr;      // record built from a host list: [header][offsets]
+   uint64_t *d_long = nullptr;      // second phase (some list longer than a record): padded lists
+   uint64_t long_cap = 0;
+   uint64_t *d_long_table = nullptr;
+   uint64_t long_table_cap = 0;
+   std::vector<uint64_t> last_list; // host copy of the most recent scan's list when it is not device resident
+   bool last_on_device = false;     // the most recent scan's list sits in ws[0].d_result[result_turn]
+   uint64_t last_count = 0;
+   float last_device_ms = 0;        // collective + packing of the last finished gather (HIP events)
+   double last_wall_ms = 0;         // host time inside mmh_gather_start + mmh_gather_finish of it
 };
 
 // a scan submitted with mmh_scan_submit and not collected yet
@@ -90,6 +138,7 @@ struct mmh_ctx {
    int engine = 0;
    uint64_t counters[4] = {0, 0, 0, 0};
    MmIngest ingest;
+   MmComm mg;
 };
 
 // defined in mm_capi.hip

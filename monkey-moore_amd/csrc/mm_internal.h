@@ -47,6 +47,7 @@ enum {
    MM_CTRL_MID = 2,          // lo 32: candidates handed from mm_resolve to mm_resolve2
    MM_CTRL_HARD = 3,         // lo 32: hard candidates, hi 32: "prefix too long" flag
    MM_CTRL_TICKET = 4,       // arrival ticket of mm_rank_scatter's blocks (the last one re-zeroes the block)
+   MM_CTRL_NOMATCH = 6,      // keys of the ordered list that are "not a match" slots (counted by mm_rank_scatter's blocks)
    MM_CTRL_TILES = 8,        // MM_STAT_STRIPES striped counters of tiles walked
    MM_STAT_STRIPES = 16,
    MM_CTRL_LISTS = 32,       // MM_CAND_LISTS list counters, MM_LIST_STRIDE words apart

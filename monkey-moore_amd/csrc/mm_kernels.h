@@ -89,12 +89,13 @@ void launch_dense(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, cons
                   uint64_t base_offset, const uint32_t *dom_list = nullptr);
 void launch_chain_seq(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, uint64_t *out,
                       unsigned long long *out_count, uint64_t out_cap, uint64_t base_offset);
-// orders the ctrl[count_index] keys of `in` into host_result[8..] (pinned host memory),
-// publishes the counters in host_result[0..8) and leaves ctrl zeroed -- unless keep_leftovers
-// is set and mm_resolve left candidates over (the second phase follows); see mm_rank_scatter
+// orders the ctrl[count_index] keys of `in` into host_result[8..] (pinned host memory) and
+// dev_result[8..] (its device-side copy, for the multi-GPU gather), publishes the counters in
+// words [0..8) of both and leaves ctrl zeroed -- unless keep_leftovers is set and mm_resolve
+// left candidates over (the second phase follows); see mm_rank_scatter
 void launch_rank_sort(hipStream_t st, const uint64_t *in, unsigned long long *ctrl, int count_index, uint64_t cap,
-                      uint32_t max_n, uint32_t *partials, uint64_t *host_result, hipEvent_t stop = nullptr,
-                      bool keep_leftovers = false);
+                      uint32_t max_n, uint32_t *partials, uint64_t *host_result, uint64_t *dev_result,
+                      hipEvent_t stop = nullptr, bool keep_leftovers = false);
 // ascending order of n 64-bit keys (mm_sort.hip, rocPRIM radix sort); in and out must not overlap
 size_t sort_temp_bytes(uint64_t n);
 hipError_t sort_keys(hipStream_t st, const uint64_t *in, uint64_t *out, uint64_t n, void *temp, size_t temp_bytes);

@@ -902,19 +902,26 @@ __global__ __launch_bounds__(256) void mm_rank_count(const uint64_t *in, const u
 }
 
 // `in` holds ctrl[count_index] keys; MM_NO_MATCH keys (candidates that are not on the
-// chain) sort behind everything else, so their common rank IS the number of matches:
-// it is published as host_result[6] = rank + 1 (the host zeroes that word before the
-// scan; 0 afterwards means "every key is a match").
+// chain) sort behind everything else and are dropped.  Every block counts the ones it meets
+// into ctrl[MM_CTRL_NOMATCH]; the last block to finish publishes "matches + 1" as word 6 of the
+// header (0 = the list was too long to be ordered here: the host sorts the slots itself).
+// The block is written twice: to pinned host memory (what mmh_scan returns) and to device
+// memory (dev_result: what the multi-GPU gather sends without a host round trip).
 __global__ __launch_bounds__(256) void mm_rank_scatter(const uint64_t *in, unsigned long long *ctrl, int count_index,
                                                        uint64_t cap, uint32_t max_n, const uint32_t *partials,
-                                                       uint64_t *host_result, uint32_t ctrl_words, uint32_t keep_leftovers)
+                                                       uint64_t *host_result, uint64_t *dev_result, uint32_t ctrl_words,
+                                                       uint32_t keep_leftovers)
 {
    __shared__ int last_block;
+   __shared__ unsigned int holes;
    const unsigned long long n64 = ctrl[count_index];
    // keep_leftovers: the scan's first phase -- when mm_resolve left candidates over, the host
    // launches the second phase (mm_resolve2, mm_hard_resolve, this ordering again), which needs
    // the control block as it is
    const bool leftovers = keep_leftovers && (ctrl[MM_CTRL_MID] & 0xFFFFFFFFull) != 0;
+   if (threadIdx.x == 0) {
+      holes = 0;
+   }
    if (blockIdx.x == 0 && threadIdx.x < 8 && threadIdx.x != 6) {
       unsigned long long v = ctrl[threadIdx.x];            // counters travel with the results
       if (threadIdx.x == 2) {
@@ -926,10 +933,17 @@ __global__ __launch_bounds__(256) void mm_rank_scatter(const uint64_t *in, unsig
       if (threadIdx.x == 5) {
          v = ctrl[MM_CTRL_MID];                            // word 2 of the header carries the tile count
       }
+      if (threadIdx.x == 7) {
+         v = (unsigned long long)count_index;              // which header word holds the list length
+      }
       host_result[threadIdx.x] = v;
+      dev_result[threadIdx.x] = v;
    }
-   if (n64 <= cap && n64 <= max_n) {
+   __syncthreads();
+   const bool ordered = n64 <= cap && n64 <= max_n;
+   if (ordered) {
       const uint32_t n = (uint32_t)n64;
+      unsigned int mine = 0;
       for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
          uint32_t r = 0;
 #pragma unroll
@@ -938,26 +952,42 @@ __global__ __launch_bounds__(256) void mm_rank_scatter(const uint64_t *in, unsig
          }
          const uint64_t key = in[i];
          if (key == MM_NO_MATCH) {
-            host_result[6] = (uint64_t)r + 1;
+            mine++;
          }
          else {
             host_result[8 + r] = key;
+            dev_result[8 + r] = key;
          }
       }
+      if (mine) {
+         atomicAdd(&holes, mine);
+      }
    }
-   // The last block to get here leaves the control block zeroed for the next scan (this is
-   // the last kernel of a scan), which saves a memset launch + its stream gap per scan.
-   // (No fence needed: every block has consumed the ctrl words it reads before it takes
-   // its ticket, and nothing else is ordered against the zeroing.)
+   // The last block to get here publishes the number of matches and leaves the control block
+   // zeroed for the next scan (this is the last kernel of a scan), which saves a memset launch
+   // + its stream gap per scan.
    __syncthreads();
    if (threadIdx.x == 0) {
+      if (holes) {
+         atomicAdd(ctrl + MM_CTRL_NOMATCH, (unsigned long long)holes);
+      }
+      __threadfence();
       last_block = atomicAdd(ctrl + MM_CTRL_TICKET, 1ull) == gridDim.x - 1;
    }
    __syncthreads();
    if (last_block) {
+      if (threadIdx.x == 0) {
+         __threadfence();
+         const unsigned long long nomatch = atomicAdd(ctrl + MM_CTRL_NOMATCH, 0ull);
+         const unsigned long long word6 = ordered ? n64 - nomatch + 1 : 0ull;
+         host_result[6] = word6;
+         dev_result[6] = word6;
+      }
+      __syncthreads();
       if (leftovers) {
          if (threadIdx.x == 0) {
             ctrl[MM_CTRL_TICKET] = 0;                        // the second phase's ordering counts arrivals again
+            ctrl[MM_CTRL_NOMATCH] = 0;
          }
       }
       else {
@@ -1378,7 +1408,8 @@ void launch_chain_seq(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, 
 }
 
 void launch_rank_sort(hipStream_t st, const uint64_t *in, unsigned long long *ctrl, int count_index, uint64_t cap,
-                      uint32_t max_n, uint32_t *partials, uint64_t *host_result, hipEvent_t stop, bool keep_leftovers)
+                      uint32_t max_n, uint32_t *partials, uint64_t *host_result, uint64_t *dev_result, hipEvent_t stop,
+                      bool keep_leftovers)
 {
    const uint32_t keep = keep_leftovers ? 1u : 0u;
    hipLaunchKernelGGL(mm_rank_count, dim3(16, MM_RANK_SLICES), dim3(256), 0, st, in, ctrl + count_index, cap, max_n,
@@ -1386,11 +1417,11 @@ void launch_rank_sort(hipStream_t st, const uint64_t *in, unsigned long long *ct
    const uint32_t ctrl_words = (uint32_t)(ctrl_bytes() / sizeof(unsigned long long));
    if (stop) {
       hipExtLaunchKernelGGL(mm_rank_scatter, dim3(64), dim3(256), 0, st, nullptr, stop, 0, in, ctrl, count_index, cap, max_n,
-                            partials, host_result, ctrl_words, keep);
+                            partials, host_result, dev_result, ctrl_words, keep);
    }
    else {
       hipLaunchKernelGGL(mm_rank_scatter, dim3(64), dim3(256), 0, st, in, ctrl, count_index, cap, max_n, partials,
-                         host_result, ctrl_words, keep);
+                         host_result, dev_result, ctrl_words, keep);
    }
 }
 

@@ -1,0 +1,671 @@
+// mm_multi.hip -- the multi-GPU half of the C ABI: block-aligned partitions and the RCCL
+// gather of the per-GPU offset lists over xGMI.
+//
+// Replaces the reference's thread dispatcher + merge (src/core/search_engine.cpp:66-188,
+// :193-197): every SearchBlock (x byte alignment) is an independent chain, so GPU g of G scans
+// the blocks [g*nb/G, (g+1)*nb/G) of the file -- a block-aligned partition plus (L-1)*S bytes of
+// pattern-length overlap -- with no exchange at all, and the only communication is the gather
+// of the ascending per-GPU offset lists.  Partitions are in rank order, so the concatenation
+// is globally ascending: there is no merge step.
+//
+// The collective is issued by this library itself (librccl), from DEVICE memory: mm_rank_scatter
+// leaves every scan's ordered list in HBM next to the copy it publishes to the host, and
+// ncclAllGather sends that block as it is -- a fixed-width record [8 counters][<= 16 K offsets]
+// per rank, one collective, latency bound (8 B per match).  A small kernel then packs the
+// records of all ranks into ONE ascending list in pinned host memory; the host only waits for an
+// event.  Lists longer than a record (short keywords, padding floods: rare) take a second,
+// padded all-gather; every rank sees every count in the first one, so all ranks agree on that
+// without further traffic.
+//
+// Two deployment shapes, same code:
+//   * one process per GPU (bench.py under torch.distributed.run): rank 0 makes an id with
+//     mmh_comm_unique_id, the launcher's rendezvous distributes it, every rank calls
+//     mmh_comm_init_rank;
+//   * one process driving several GPUs (SearchEngine<T>::run): mmh_comm_init_all over the
+//     contexts, mmh_scan_multi runs the scans on one host thread per device and the collective
+//     inside ncclGroupStart / ncclGroupEnd.
+// The gather runs on its own stream and is split into start / finish, so that the collective of
+// scan k overlaps scan k+1.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "mm_context.h"
+#include "mm_internal.h"
+#include "mm_kernels.h"
+
+namespace {
+
+constexpr uint64_t kRecordWords = MM_RESULT_HEADER_WORDS + MM_MAX_RANK_SORT;   // what a scan leaves in HBM, sent as it is
+constexpr int kMaxRanks = 64;
+constexpr uint64_t kMergedHeader = 8 + kMaxRanks;     // [total, longest, nranks, long flag, ...][count of every rank]
+
+bool hip_ok(hipError_t e, const char *what)
+{
+   if (e == hipSuccess) {
+      return true;
+   }
+   mmh_set_error("%s: %s", what, hipGetErrorString(e));
+   return false;
+}
+
+bool nccl_ok(ncclResult_t r, const char *what)
+{
+   if (r == ncclSuccess) {
+      return true;
+   }
+   mmh_set_error("%s: %s", what, ncclGetErrorString(r));
+   return false;
+}
+
+#define HIP_TRY(expr)                       \
+   do {                                     \
+      if (!hip_ok((expr), #expr)) {         \
+         return MMH_E_DEVICE;               \
+      }                                     \
+   } while (0)
+
+#define NCCL_TRY(expr)                      \
+   do {                                     \
+      if (!nccl_ok((expr), #expr)) {        \
+         return MMH_E_DEVICE;               \
+      }                                     \
+   } while (0)
+
+double now_s()
+{
+   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+} // namespace
+
+// --------------------------------------------------------------------------
+// kernels
+// --------------------------------------------------------------------------
+
+// Record of a list that lives in host memory (already copied to rec + 8 when it fits): only the
+// word the receivers read needs writing -- "count + 1", as mm_rank_scatter publishes it.
+__global__ void mm_gather_stamp(uint64_t *rec, uint64_t count)
+{
+   if (threadIdx.x < MM_RESULT_HEADER_WORDS) {
+      rec[threadIdx.x] = threadIdx.x == 6 ? count + 1 : 0;
+   }
+}
+
+// table: nranks records of `words` words as the all-gather left them.  Block r copies the list of
+// rank r behind the lists of the ranks before it -- one ascending list in pinned host memory --
+// and block 0 writes the header: [0] total, [1] longest list, [2] nranks, [3] 1 when some list is
+// longer than a record (then nothing is copied: the second phase follows), [8 + r] count of rank r.
+__global__ __launch_bounds__(256) void mm_gather_pack(const uint64_t *table, uint32_t nranks, uint64_t words, uint64_t *merged,
+                                                      uint64_t merged_cap, uint32_t want_list)
+{
+   __shared__ unsigned long long sh_before, sh_total, sh_longest;
+   const uint32_t r = blockIdx.x;
+   if (threadIdx.x == 0) {
+      unsigned long long before = 0, total = 0, longest = 0;
+      for (uint32_t q = 0; q < nranks; q++) {
+         const unsigned long long w6 = table[(uint64_t)q * words + 6];
+         const unsigned long long n = w6 ? w6 - 1 : 0;
+         before += q < r ? n : 0;
+         total += n;
+         longest = n > longest ? n : longest;
+         if (r == 0) {
+            merged[8 + q] = n;
+         }
+      }
+      sh_before = before; sh_total = total; sh_longest = longest;
+      if (r == 0) {
+         merged[0] = total; merged[1] = longest; merged[2] = nranks;
+         merged[3] = longest > MM_MAX_RANK_SORT ? 1 : 0;
+      }
+   }
+   __syncthreads();
+   if (!want_list || sh_longest > MM_MAX_RANK_SORT || sh_total > merged_cap) {
+      return;
+   }
+   const uint64_t *rec = table + (uint64_t)r * words;
+   const unsigned long long n = rec[6] ? rec[6] - 1 : 0;
+   uint64_t *dst = merged + kMergedHeader + sh_before;
+   for (unsigned long long i = threadIdx.x; i < n; i += blockDim.x) {
+      dst[i] = rec[MM_RESULT_HEADER_WORDS + i];
+   }
+}
+
+// --------------------------------------------------------------------------
+// partitions (host only)
+// --------------------------------------------------------------------------
+
+extern "C" int mmh_partition(uint64_t total_bytes, uint64_t block_bytes, uint32_t keyword_len, uint32_t elem_bytes, int rank,
+                             int nranks, uint64_t *first_byte, uint64_t *nbytes)
+{
+   if (!first_byte || !nbytes || block_bytes == 0 || keyword_len == 0 || (elem_bytes != 1 && elem_bytes != 2) || nranks < 1 ||
+       rank < 0 || rank >= nranks) {
+      mmh_set_error("mmh_partition: bad argument");
+      return MMH_E_ARG;
+   }
+   // whole reference blocks (search_engine.cpp:218-253), dealt out evenly in rank order
+   const uint64_t nblocks = (total_bytes + block_bytes - 1) / block_bytes;
+   const uint64_t b0 = (unsigned __int128)nblocks * (uint64_t)rank / (uint64_t)nranks;
+   const uint64_t b1 = (unsigned __int128)nblocks * (uint64_t)(rank + 1) / (uint64_t)nranks;
+   const uint64_t first = b0 * block_bytes;
+   // pattern-length overlap into the next partition: the last block of this one reads it (:227-230)
+   uint64_t end = b1 * block_bytes + (uint64_t)(keyword_len - 1) * elem_bytes;
+   end = end > total_bytes ? total_bytes : end;
+   *first_byte = first;
+   *nbytes = end > first ? end - first : 0;
+   return MMH_OK;
+}
+
+// --------------------------------------------------------------------------
+// communicator
+// --------------------------------------------------------------------------
+
+namespace {
+
+int comm_buffers(mmh_ctx *c)
+{
+   MmComm &m = c->mg;
+   HIP_TRY(hipSetDevice(c->device));
+   int rc = mmh_workspace(c);                       // the scan workspace (and its device-side result copies)
+   if (rc != MMH_OK) {
+      return rc;
+   }
+   if (!m.stream) {
+      HIP_TRY(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
+   }
+   if (!m.d_send) {
+      HIP_TRY(hipMalloc(&m.d_send, kRecordWords * sizeof(uint64_t)));
+   }
+   for (auto &s : m.slot) {
+      if (!s.d_table) {
+         HIP_TRY(hipMalloc(&s.d_table, (uint64_t)m.nranks * kRecordWords * sizeof(uint64_t)));
+         s.merged_cap = (uint64_t)m.nranks * MM_MAX_RANK_SORT;
+         HIP_TRY(hipHostMalloc(&s.h_merged, (kMergedHeader + s.merged_cap) * sizeof(uint64_t), hipHostMallocDefault));
+         HIP_TRY(hipEventCreate(&s.begin));
+         HIP_TRY(hipEventCreate(&s.end));
+      }
+      s.busy = false;
+   }
+   m.turn = m.oldest = 0;
+   return MMH_OK;
+}
+
+void comm_release(mmh_ctx *c)
+{
+   MmComm &m = c->mg;
+   (void)hipSetDevice(c->device);
+   if (m.stream) {
+      (void)hipStreamSynchronize(m.stream);
+   }
+   if (m.comm) {
+      (void)ncclCommDestroy(static_cast<ncclComm_t>(m.comm));
+      m.comm = nullptr;
+   }
+   for (auto &s : m.slot) {
+      if (s.d_table) (void)hipFree(s.d_table);
+      if (s.h_merged) (void)hipHostFree(s.h_merged);
+      if (s.begin) (void)hipEventDestroy(s.begin);
+      if (s.end) (void)hipEventDestroy(s.end);
+      s = MmGatherSlot();
+   }
+   if (m.d_send) (void)hipFree(m.d_send);
+   if (m.d_long) (void)hipFree(m.d_long);
+   if (m.d_long_table) (void)hipFree(m.d_long_table);
+   if (m.stream) (void)hipStreamDestroy(m.stream);
+   m.d_send = m.d_long = m.d_long_table = nullptr;
+   m.long_cap = m.long_table_cap = 0;
+   m.stream = nullptr;
+   m.rank = 0;
+   m.nranks = 1;
+   m.last_list.clear();
+   m.last_on_device = false;
+}
+
+} // namespace
+
+extern "C" int mmh_comm_unique_id(void *id128)
+{
+   if (!id128) {
+      mmh_set_error("mmh_comm_unique_id: null argument");
+      return MMH_E_ARG;
+   }
+   static_assert(MMH_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+   ncclUniqueId id;
+   NCCL_TRY(ncclGetUniqueId(&id));
+   std::memcpy(id128, id.internal, NCCL_UNIQUE_ID_BYTES);
+   return MMH_OK;
+}
+
+extern "C" int mmh_comm_init_rank(mmh_ctx *c, const void *id128, int nranks, int rank)
+{
+   if (!c || !id128 || nranks < 1 || nranks > kMaxRanks || rank < 0 || rank >= nranks) {
+      mmh_set_error("mmh_comm_init_rank: bad argument (1 <= nranks <= %d)", kMaxRanks);
+      return MMH_E_ARG;
+   }
+   comm_release(c);
+   HIP_TRY(hipSetDevice(c->device));
+   ncclUniqueId id;
+   std::memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+   ncclComm_t comm = nullptr;
+   NCCL_TRY(ncclCommInitRank(&comm, nranks, id, rank));
+   c->mg.comm = comm;
+   c->mg.rank = rank;
+   c->mg.nranks = nranks;
+   return comm_buffers(c);
+}
+
+extern "C" int mmh_comm_init_all(mmh_ctx *const *ctxs, int n)
+{
+   if (!ctxs || n < 1 || n > kMaxRanks) {
+      mmh_set_error("mmh_comm_init_all: bad argument (1 <= n <= %d)", kMaxRanks);
+      return MMH_E_ARG;
+   }
+   std::vector<int> devices(n);
+   for (int i = 0; i < n; i++) {
+      if (!ctxs[i]) {
+         mmh_set_error("mmh_comm_init_all: null context %d", i);
+         return MMH_E_ARG;
+      }
+      devices[i] = ctxs[i]->device;
+      for (int k = 0; k < i; k++) {
+         if (devices[k] == devices[i]) {
+            mmh_set_error("mmh_comm_init_all: contexts %d and %d are on the same device", k, i);
+            return MMH_E_ARG;
+         }
+      }
+      comm_release(ctxs[i]);
+   }
+   std::vector<ncclComm_t> comms(n, nullptr);
+   NCCL_TRY(ncclCommInitAll(comms.data(), n, devices.data()));
+   for (int i = 0; i < n; i++) {
+      ctxs[i]->mg.comm = comms[i];
+      ctxs[i]->mg.rank = i;
+      ctxs[i]->mg.nranks = n;
+   }
+   for (int i = 0; i < n; i++) {
+      int rc = comm_buffers(ctxs[i]);
+      if (rc != MMH_OK) {
+         return rc;
+      }
+   }
+   return MMH_OK;
+}
+
+extern "C" int mmh_comm_info(mmh_ctx *c, int *rank, int *nranks)
+{
+   if (!c || !rank || !nranks) {
+      mmh_set_error("mmh_comm_info: bad argument");
+      return MMH_E_ARG;
+   }
+   *rank = c->mg.rank;
+   *nranks = c->mg.comm ? c->mg.nranks : 0;
+   return MMH_OK;
+}
+
+extern "C" void mmh_comm_destroy(mmh_ctx *c)
+{
+   if (c && (c->mg.comm || c->mg.stream)) {
+      comm_release(c);
+   }
+}
+
+// --------------------------------------------------------------------------
+// the gather, step by step (so that several devices of one process can take the
+// collective step together inside ncclGroupStart / ncclGroupEnd)
+// --------------------------------------------------------------------------
+
+namespace {
+
+// step 1: the record to send.  offsets == nullptr: the list of the most recent mmh_scan -- in
+// place in HBM when the scan ordered it there, else from the host copy the scan kept.
+int gather_prepare(mmh_ctx *c, const uint64_t *offsets, uint64_t n, const uint64_t **send)
+{
+   MmComm &m = c->mg;
+   if (!m.comm) {
+      mmh_set_error("mmh_gather_start: the context has no communicator (mmh_comm_init_rank / mmh_comm_init_all)");
+      return MMH_E_STATE;
+   }
+   MmGatherSlot &s = m.slot[m.turn];
+   if (s.busy) {
+      mmh_set_error("mmh_gather_start: two gathers are already outstanding, finish the older one first");
+      return MMH_E_STATE;
+   }
+   HIP_TRY(hipSetDevice(c->device));
+   const double t0 = now_s();
+   s.from_host = true;
+   if (!offsets && n == 0) {
+      if (m.last_on_device) {
+         s.from_host = false;
+         s.src_turn = c->ws[0].result_turn;
+         s.local_count = m.last_count;
+         *send = c->ws[0].d_result[c->ws[0].result_turn];
+      }
+      else {
+         offsets = m.last_list.data();
+         n = m.last_list.size();
+      }
+   }
+   HIP_TRY(hipEventRecord(s.begin, m.stream));
+   if (s.from_host) {
+      s.local_count = n;
+      if (n && n <= MM_MAX_RANK_SORT) {
+         HIP_TRY(hipMemcpyAsync(m.d_send + MM_RESULT_HEADER_WORDS, offsets, n * sizeof(uint64_t), hipMemcpyHostToDevice, m.stream));
+      }
+      hipLaunchKernelGGL(mm_gather_stamp, dim3(1), dim3(64), 0, m.stream, m.d_send, n);
+      HIP_TRY(hipGetLastError());
+      if (n > MM_MAX_RANK_SORT && offsets != m.last_list.data()) {
+         m.last_list.assign(offsets, offsets + n);      // the second phase sends it from here
+      }
+      *send = m.d_send;
+   }
+   s.start_wall_s = now_s() - t0;
+   return MMH_OK;
+}
+
+// step 2: the collective (non-blocking enqueue on the comm stream)
+int gather_collective(mmh_ctx *c, const uint64_t *send)
+{
+   MmComm &m = c->mg;
+   MmGatherSlot &s = m.slot[m.turn];
+   NCCL_TRY(ncclAllGather(send, s.d_table, kRecordWords, ncclUint64, static_cast<ncclComm_t>(m.comm), m.stream));
+   return MMH_OK;
+}
+
+// step 3: pack the records into one list in pinned memory
+int gather_pack(mmh_ctx *c, int want_list)
+{
+   MmComm &m = c->mg;
+   MmGatherSlot &s = m.slot[m.turn];
+   HIP_TRY(hipSetDevice(c->device));
+   const double t0 = now_s();
+   hipLaunchKernelGGL(mm_gather_pack, dim3((unsigned)m.nranks), dim3(256), 0, m.stream, s.d_table, (uint32_t)m.nranks, kRecordWords,
+                      s.h_merged, s.merged_cap, want_list ? 1u : 0u);
+   HIP_TRY(hipGetLastError());
+   HIP_TRY(hipEventRecord(s.end, m.stream));
+   s.busy = true;
+   s.start_wall_s += now_s() - t0;
+   m.turn ^= 1;
+   return MMH_OK;
+}
+
+// second phase, step 1: this rank's whole list, padded to the longest one, in d_long
+int long_prepare(mmh_ctx *c, MmGatherSlot &s, uint64_t longest)
+{
+   MmComm &m = c->mg;
+   HIP_TRY(hipSetDevice(c->device));
+   if (longest > m.long_cap) {
+      if (m.d_long) {
+         HIP_TRY(hipFree(m.d_long));
+         m.d_long = nullptr;
+      }
+      HIP_TRY(hipMalloc(&m.d_long, longest * sizeof(uint64_t)));
+      m.long_cap = longest;
+   }
+   const uint64_t need = (uint64_t)m.nranks * longest;
+   if (need > m.long_table_cap) {
+      if (m.d_long_table) {
+         HIP_TRY(hipFree(m.d_long_table));
+         m.d_long_table = nullptr;
+      }
+      HIP_TRY(hipMalloc(&m.d_long_table, need * sizeof(uint64_t)));
+      m.long_table_cap = need;
+   }
+   if (s.local_count) {
+      if (s.from_host) {
+         if (m.last_list.size() != s.local_count) {
+            mmh_set_error("mmh_gather_finish: the list handed to mmh_gather_start is gone (a scan ran in between)");
+            return MMH_E_STATE;
+         }
+         HIP_TRY(hipMemcpyAsync(m.d_long, m.last_list.data(), s.local_count * sizeof(uint64_t), hipMemcpyHostToDevice, m.stream));
+      }
+      else {
+         // (its record in the table is intact whatever the scans did since)
+         HIP_TRY(hipMemcpyAsync(m.d_long, s.d_table + (uint64_t)m.rank * kRecordWords + MM_RESULT_HEADER_WORDS,
+                                s.local_count * sizeof(uint64_t), hipMemcpyDeviceToDevice, m.stream));
+      }
+   }
+   return MMH_OK;
+}
+
+int long_collective(mmh_ctx *c, uint64_t longest)
+{
+   MmComm &m = c->mg;
+   NCCL_TRY(ncclAllGather(m.d_long, m.d_long_table, longest, ncclUint64, static_cast<ncclComm_t>(m.comm), m.stream));
+   return MMH_OK;
+}
+
+// wait for the first phase of the oldest gather; *longest > MM_MAX_RANK_SORT: second phase needed
+int gather_wait(mmh_ctx *c, uint64_t *total, uint64_t *longest)
+{
+   MmComm &m = c->mg;
+   MmGatherSlot &s = m.slot[m.oldest];
+   if (!m.comm || !s.busy) {
+      mmh_set_error("mmh_gather_finish: no gather is outstanding");
+      return MMH_E_STATE;
+   }
+   HIP_TRY(hipSetDevice(c->device));
+   HIP_TRY(hipEventSynchronize(s.end));
+   *total = s.h_merged[0];
+   *longest = s.h_merged[1];
+   return MMH_OK;
+}
+
+// deliver the oldest gather (first phase waited for; second phase, if any, enqueued) and retire it
+int gather_deliver(mmh_ctx *c, uint64_t *out, uint64_t cap, uint64_t *out_count, double t0)
+{
+   MmComm &m = c->mg;
+   MmGatherSlot &s = m.slot[m.oldest];
+   const uint64_t total = s.h_merged[0], longest = s.h_merged[1];
+   *out_count = total;
+   if (out && total > cap) {
+      mmh_set_error("mmh_gather_finish: %llu offsets do not fit the caller's buffer of %llu (finish again)",
+                    (unsigned long long)total, (unsigned long long)cap);
+      return MMH_E_CAPACITY;                         // the gather stays outstanding
+   }
+   if (longest > MM_MAX_RANK_SORT) {
+      if (out) {
+         uint64_t at = 0;
+         for (int r = 0; r < m.nranks; r++) {
+            const uint64_t n = s.h_merged[8 + r];
+            if (n) {
+               HIP_TRY(hipMemcpyAsync(out + at, m.d_long_table + (uint64_t)r * longest, n * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                                      m.stream));
+            }
+            at += n;
+         }
+      }
+      HIP_TRY(hipStreamSynchronize(m.stream));
+   }
+   else if (out && total) {
+      std::memcpy(out, s.h_merged + kMergedHeader, total * sizeof(uint64_t));
+   }
+   float ms = 0;
+   if (hipEventElapsedTime(&ms, s.begin, s.end) == hipSuccess) {
+      m.last_device_ms = ms;
+   }
+   m.last_wall_ms = (s.start_wall_s + (now_s() - t0)) * 1e3;
+   s.busy = false;
+   m.oldest ^= 1;
+   return MMH_OK;
+}
+
+} // namespace
+
+extern "C" int mmh_gather_start(mmh_ctx *c, const uint64_t *offsets, uint64_t n, int want_list)
+{
+   if (!c || (!offsets && n)) {
+      mmh_set_error("mmh_gather_start: bad argument");
+      return MMH_E_ARG;
+   }
+   const uint64_t *send = nullptr;
+   int rc = gather_prepare(c, offsets, n, &send);
+   if (rc == MMH_OK) {
+      rc = gather_collective(c, send);
+   }
+   if (rc == MMH_OK) {
+      rc = gather_pack(c, want_list);
+   }
+   return rc;
+}
+
+extern "C" int mmh_gather_finish(mmh_ctx *c, uint64_t *out, uint64_t cap, uint64_t *out_count)
+{
+   if (!c || !out_count || (!out && cap)) {
+      mmh_set_error("mmh_gather_finish: bad argument");
+      return MMH_E_ARG;
+   }
+   *out_count = 0;
+   const double t0 = now_s();
+   uint64_t total = 0, longest = 0;
+   int rc = gather_wait(c, &total, &longest);
+   if (rc != MMH_OK) {
+      return rc;
+   }
+   MmGatherSlot &s = c->mg.slot[c->mg.oldest];
+   if (longest > MM_MAX_RANK_SORT && !(out && total > cap)) {
+      // some rank's list did not fit its record: every rank saw that in the table it received,
+      // so all of them are here now -- the whole lists, padded to the longest
+      rc = long_prepare(c, s, longest);
+      if (rc == MMH_OK) {
+         rc = long_collective(c, longest);
+      }
+      if (rc != MMH_OK) {
+         return rc;
+      }
+   }
+   return gather_deliver(c, out, cap, out_count, t0);
+}
+
+extern "C" int mmh_last_gather_timings(mmh_ctx *c, float *ms2)
+{
+   if (!c || !ms2) {
+      mmh_set_error("mmh_last_gather_timings: bad argument");
+      return MMH_E_ARG;
+   }
+   ms2[0] = c->mg.last_device_ms;
+   ms2[1] = (float)c->mg.last_wall_ms;
+   return MMH_OK;
+}
+
+// --------------------------------------------------------------------------
+// one process, several GPUs
+// --------------------------------------------------------------------------
+
+extern "C" int mmh_scan_multi(mmh_ctx *const *ctxs, int n, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian,
+                              const uint64_t *base_offsets, uint64_t *out, uint64_t cap, uint64_t *out_count)
+{
+   if (!ctxs || n < 1 || n > kMaxRanks || !plan || !base_offsets || !out_count || (!out && cap)) {
+      mmh_set_error("mmh_scan_multi: bad argument");
+      return MMH_E_ARG;
+   }
+   *out_count = 0;
+   for (int i = 0; i < n; i++) {
+      if (!ctxs[i] || !ctxs[i]->mg.comm || ctxs[i]->mg.nranks != n || ctxs[i]->mg.rank != i) {
+         mmh_set_error("mmh_scan_multi: context %d is not rank %d of a communicator of %d (mmh_comm_init_all)", i, i, n);
+         return MMH_E_STATE;
+      }
+   }
+   // the scans: one host thread per device (a scan ends in a host wait); nothing is exchanged
+   std::vector<int> rcs(n, MMH_OK);
+   std::vector<std::string> errors(n);
+   auto scan_one = [&](int i) {
+      std::vector<uint64_t> local(4096);
+      uint64_t count = 0;
+      for (;;) {
+         rcs[i] = mmh_scan(ctxs[i], plan, block_bytes, big_endian, base_offsets[i], local.data(), local.size(), &count);
+         if (rcs[i] != MMH_E_CAPACITY) {
+            break;
+         }
+         local.resize(count + 16);
+      }
+      if (rcs[i] != MMH_OK) {
+         errors[i] = mmh_last_error();
+      }
+   };
+   std::vector<std::thread> workers;
+   for (int i = 1; i < n; i++) {
+      workers.emplace_back(scan_one, i);
+   }
+   scan_one(0);
+   for (auto &t : workers) {
+      t.join();
+   }
+   for (int i = 0; i < n; i++) {
+      if (rcs[i] != MMH_OK) {
+         mmh_set_error("mmh_scan_multi: device %d: %s", ctxs[i]->device, errors[i].c_str());
+         return rcs[i];                               // before any collective: nobody is left waiting
+      }
+   }
+   // the gather: every device's collective call inside one group
+   std::vector<const uint64_t *> send(n, nullptr);
+   for (int i = 0; i < n; i++) {
+      int rc = gather_prepare(ctxs[i], nullptr, 0, &send[i]);
+      if (rc != MMH_OK) {
+         return rc;
+      }
+   }
+   NCCL_TRY(ncclGroupStart());
+   for (int i = 0; i < n; i++) {
+      int rc = gather_collective(ctxs[i], send[i]);
+      if (rc != MMH_OK) {
+         (void)ncclGroupEnd();
+         return rc;
+      }
+   }
+   NCCL_TRY(ncclGroupEnd());
+   for (int i = 0; i < n; i++) {
+      int rc = gather_pack(ctxs[i], i == 0);
+      if (rc != MMH_OK) {
+         return rc;
+      }
+   }
+   const double t0 = now_s();
+   uint64_t total = 0, longest = 0;
+   for (int i = 0; i < n; i++) {
+      int rc = gather_wait(ctxs[i], &total, &longest);
+      if (rc != MMH_OK) {
+         return rc;
+      }
+   }
+   const bool fits = !(out && total > cap);
+   if (longest > MM_MAX_RANK_SORT && fits) {
+      for (int i = 0; i < n; i++) {
+         int rc = long_prepare(ctxs[i], ctxs[i]->mg.slot[ctxs[i]->mg.oldest], longest);
+         if (rc != MMH_OK) {
+            return rc;
+         }
+      }
+      NCCL_TRY(ncclGroupStart());
+      for (int i = 0; i < n; i++) {
+         int rc = long_collective(ctxs[i], longest);
+         if (rc != MMH_OK) {
+            (void)ncclGroupEnd();
+            return rc;
+         }
+      }
+      NCCL_TRY(ncclGroupEnd());
+   }
+   int result = MMH_OK;
+   for (int i = n - 1; i >= 0; i--) {
+      uint64_t count = 0;
+      int rc = gather_deliver(ctxs[i], i == 0 ? out : nullptr, i == 0 ? cap : 0, &count, t0);
+      if (i == 0) {
+         *out_count = count;
+         if (rc == MMH_E_CAPACITY) {
+            // the caller scans again with a larger buffer: retire the gather
+            ctxs[0]->mg.slot[ctxs[0]->mg.oldest].busy = false;
+            ctxs[0]->mg.oldest ^= 1;
+         }
+      }
+      if (rc != MMH_OK) {
+         result = rc;
+      }
+   }
+   return result;
+}
