@@ -28,7 +28,10 @@ EXPORTS = [
     "mmh_rom_poke", "mmh_rom_fill", "mmh_scan", "mmh_set_engine", "mmh_last_timings", "mmh_last_counters",
     "mmh_timing_history", "mmh_filter_shape", "mmh_rom_load_file", "mmh_last_load_stats", "mmh_rom_gather",
     "mmh_scan_submit", "mmh_scan_collect",
+    "mmh_partition", "mmh_comm_unique_id", "mmh_comm_init_rank", "mmh_comm_init_all", "mmh_comm_info", "mmh_comm_destroy",
+    "mmh_gather_start", "mmh_gather_finish", "mmh_last_gather_timings", "mmh_scan_multi",
 ]
+MMH_COMM_ID_BYTES = 128
 
 
 class PlanDesc(C.Structure):
@@ -52,12 +55,33 @@ class MMError(RuntimeError):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch wheels ship their own libamdhip64.so / librccl.so under the same SONAMEs as the
+    system ROCm.  Whichever copy is loaded first serves the whole process: loading this library
+    first would hand torch the SYSTEM runtime, under which its kernels find no device.  With
+    MMOORE_PRELOAD_TORCH_HIP=1 the torch copies are loaded (globally) before libmmoore_hip.so, so
+    that either import order works; without it, import torch first (as bench.py does)."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("MMOORE_PRELOAD_TORCH_HIP", "0") in ("", "0"):
+        return
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libamdhip64.so", "librccl.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """Load libmmoore_hip.so; raises if it has not been built (no silent fallback)."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise MMError(MMH_E_DEVICE, "libmmoore_hip.so is not built (run __graft_entry__.build()): " + LIB_PATH)
+        _share_hip_runtime_with_torch()
         L = C.CDLL(LIB_PATH)
         u32p, u64p, i16p = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_int16)
         L.mmh_last_error.restype = C.c_char_p
@@ -86,6 +110,17 @@ def lib():
         L.mmh_last_load_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double), u64p, C.POINTER(C.c_int)]
         L.mmh_rom_gather.argtypes = [C.c_void_p, u64p, C.c_uint64, C.c_uint32, C.c_void_p]
         L.mmh_timing_history.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
+        L.mmh_partition.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int, u64p, u64p]
+        L.mmh_comm_unique_id.argtypes = [C.c_void_p]
+        L.mmh_comm_init_rank.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.mmh_comm_init_all.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+        L.mmh_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.mmh_comm_destroy.argtypes = [C.c_void_p]
+        L.mmh_comm_destroy.restype = None
+        L.mmh_gather_start.argtypes = [C.c_void_p, u64p, C.c_uint64, C.c_int]
+        L.mmh_gather_finish.argtypes = [C.c_void_p, u64p, C.c_uint64, u64p]
+        L.mmh_last_gather_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.mmh_scan_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(PlanDesc), C.c_uint64, C.c_int, u64p, u64p, C.c_uint64, u64p]
         _lib = L
     return _lib
 
@@ -131,6 +166,42 @@ def filter_shape(plan):
     n = info[0]
     return {"ncond": n, "anchor": info[1], "shape": info[2], "verify_in_filter": bool(info[3]),
             "conditions": [(info[4 + 2 * k], info[5 + 2 * k]) for k in range(n)]}
+
+
+def partition_range(total_bytes, block_bytes, keyword_len, elem_bytes, rank, nranks):
+    """(first_byte, nbytes) of rank's block-aligned partition incl. the pattern-length overlap (host only)."""
+    first, n = C.c_uint64(0), C.c_uint64(0)
+    _check(lib().mmh_partition(total_bytes, block_bytes, keyword_len, elem_bytes, rank, nranks, C.byref(first), C.byref(n)))
+    return first.value, n.value
+
+
+def comm_unique_id():
+    """Rank 0: the id every rank passes to Engine.comm_init_rank (distribute it through the launcher's rendezvous)."""
+    buf = (C.c_uint8 * MMH_COMM_ID_BYTES)()
+    _check(lib().mmh_comm_unique_id(buf))
+    return bytes(buf)
+
+
+def comm_init_all(engines):
+    """One process, several GPUs: engine i becomes rank i of one communicator."""
+    arr = (C.c_void_p * len(engines))(*[e._h for e in engines])
+    _check(lib().mmh_comm_init_all(arr, len(engines)))
+
+
+def scan_multi(engines, plan, block_bytes, base_offsets, big_endian=False, cap=1 << 16):
+    """mmh_scan_multi: every engine scans its attached partition, the lists are gathered over RCCL."""
+    arr = (C.c_void_p * len(engines))(*[e._h for e in engines])
+    bases = np.ascontiguousarray(base_offsets, dtype=np.uint64)
+    count = C.c_uint64(0)
+    while True:
+        out = np.empty(cap, np.uint64)
+        rc = lib().mmh_scan_multi(arr, len(engines), C.byref(plan), block_bytes, int(big_endian), _p(bases, C.c_uint64),
+                                  _p(out, C.c_uint64), out.size, C.byref(count))
+        if rc == MMH_E_CAPACITY:
+            cap = int(count.value) + 16
+            continue
+        _check(rc)
+        return out[: count.value].copy()
 
 
 def device_count():
@@ -253,6 +324,52 @@ class Engine:
             if rc != MMH_OK:
                 _check(rc)
             return out[: self._count.value].copy()
+
+    # -- multi-GPU ------------------------------------------------------
+    def comm_init_rank(self, unique_id, nranks, rank):
+        """One process per GPU: join the communicator (collective over all ranks)."""
+        buf = (C.c_uint8 * MMH_COMM_ID_BYTES).from_buffer_copy(unique_id)
+        _check(lib().mmh_comm_init_rank(self._h, buf, nranks, rank))
+
+    def comm_info(self):
+        r, n = C.c_int(0), C.c_int(0)
+        _check(lib().mmh_comm_info(self._h, C.byref(r), C.byref(n)))
+        return r.value, n.value
+
+    def gather_start(self, offsets=None, want_list=True):
+        """Enqueue the RCCL gather of the offset lists: offsets None = the last scan's list, straight from HBM."""
+        if offsets is None:
+            _check(lib().mmh_gather_start(self._h, C.cast(None, C.POINTER(C.c_uint64)), 0, int(want_list)))
+        else:
+            a = np.ascontiguousarray(offsets, dtype=np.uint64)
+            n = a.size
+            if n == 0:
+                a = np.zeros(1, np.uint64)                   # (NULL, 0) would mean "the last scan's list": an empty list needs a pointer
+            self._gather_keep = a                            # stays alive until the copy is enqueued (synchronous for pageable memory)
+            _check(lib().mmh_gather_start(self._h, a.ctypes.data_as(C.POINTER(C.c_uint64)), n, int(want_list)))
+
+    def gather_finish(self, want_list=True, cap=1 << 16):
+        """Wait for the oldest outstanding gather; the merged ascending list (or just its length when not want_list)."""
+        count = C.c_uint64(0)
+        if not want_list:
+            _check(lib().mmh_gather_finish(self._h, C.cast(None, C.POINTER(C.c_uint64)), 0, C.byref(count)))
+            return int(count.value)
+        while True:
+            out = getattr(self, "_gout", None)
+            if out is None or out.size < cap:
+                out = self._gout = np.empty(cap, np.uint64)
+            rc = lib().mmh_gather_finish(self._h, _p(out, C.c_uint64), out.size, C.byref(count))
+            if rc == MMH_E_CAPACITY:
+                cap = int(count.value) + 16
+                continue
+            if rc != MMH_OK:
+                _check(rc)
+            return out[: count.value].copy()
+
+    def gather_timings(self):
+        t = (C.c_float * 2)()
+        _check(lib().mmh_last_gather_timings(self._h, t))
+        return dict(device_ms=t[0], host_ms=t[1])
 
     def timings(self):
         t = (C.c_float * 4)()

@@ -135,6 +135,7 @@ void begin_scan_events(mmh_ctx *c, bool has_filter)
    const int slot = (int)(c->scans_recorded % mmh_ctx::kRing);
    c->ev = c->ring[slot];
    c->ring_has_filter[slot] = has_filter;
+   c->ring_is_ms[slot] = false;
 }
 
 void release_rom(mmh_ctx *c)
@@ -215,6 +216,11 @@ extern "C" void mmh_destroy(mmh_ctx *c)
       }
    }
    if (c->lane_fence) (void)hipEventDestroy(c->lane_fence);
+   for (auto &triple : c->lane_ev) {
+      for (auto &e : triple) {
+         if (e) (void)hipEventDestroy(e);
+      }
+   }
    for (auto &w : c->ws) {
       free_workspace(w);
    }
@@ -395,7 +401,10 @@ int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev,
    // The scan's three events ride on kernel dispatches (hipExtLaunchKernelGGL) where they can:
    // a hipEventRecord between dependent kernels costs ~6 us of stream time on this stack.
    if (!sequential) {
-      mm::launch_filter(st, g, pl, fc, w.d_cand, w.d_ctrl, w.cand_cap, ev[0], ev[1], nullptr, skip_bits);
+      // (with ranks to gather from, the streaming kernel leaves a workgroup slot per CU to the RCCL
+      // kernel of the previous scan's gather, which would otherwise wait for this kernel's end)
+      const uint64_t block_cap = (c->mg.comm && c->mg.nranks > 1) ? mm::tuning().filter_blocks_comm : 0;
+      mm::launch_filter(st, g, pl, fc, w.d_cand, w.d_ctrl, w.cand_cap, ev[0], ev[1], nullptr, skip_bits, block_cap);
       mm::launch_resolve(st, g, pl, rb, base_offset, max_candidates);
    }
    else {
@@ -408,7 +417,6 @@ int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev,
    mm::launch_rank_sort(st, w.d_out, w.d_ctrl, count_index, w.out_cap, kMaxRankSort, w.d_partials, w.h_result,
                         w.d_result[w.result_turn], ev[2], !sequential);
    HIP_TRY(hipGetLastError());
-   (void)c;
    return MMH_OK;
 }
 
@@ -1083,9 +1091,12 @@ extern "C" int mmh_scan_submit(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t b
       // (Making this lane's filter wait for the other lane's "filter done" event was tried, with
       // filter grids of 1024 .. 2048 workgroups: 766-913 us per scan instead of 697 -- the
       // hardware interleaves the two queues better on its own.)
-      begin_scan_events(c, true);
-      c->scans_recorded++;
-      p.ev = c->ev;
+      for (auto &e : c->lane_ev[lane]) {
+         if (!e) {
+            HIP_TRY(hipEventCreate(&e));
+         }
+      }
+      std::copy(c->lane_ev[lane], c->lane_ev[lane] + 3, p.ev);
       rc = enqueue_pipeline(c, w, c->lane_stream[lane], p.ev, g, *plan, fc, false, base_offset, p.max_candidates);
       if (rc != MMH_OK) {
          return rc;
@@ -1120,6 +1131,15 @@ extern "C" int mmh_scan_collect(mmh_ctx *c, int ticket, uint64_t *out, uint64_t 
          return rc;
       }
       rescan = oc.candidates > w.out_cap || oc.candidates > p.max_candidates || oc.hard_overflow || !oc.sorted_on_device;
+      // the lane's timings enter the history now that its events have completed
+      const int slot = (int)(c->scans_recorded % mmh_ctx::kRing);
+      float filter_ms = 0, total_ms = 0;
+      if (hipEventElapsedTime(&filter_ms, p.ev[0], p.ev[1]) == hipSuccess && hipEventElapsedTime(&total_ms, p.ev[0], p.ev[2]) == hipSuccess) {
+         c->ring_is_ms[slot] = true;
+         c->ring_ms[slot][0] = filter_ms;
+         c->ring_ms[slot][1] = total_ms;
+         c->scans_recorded++;
+      }
    }
    if (rescan) {
       // (the ticket stays outstanding when the caller's buffer turns out too small: collect again)
@@ -1151,9 +1171,18 @@ void scan_timings(mmh_ctx *c, uint64_t k, float *ms4)
    const int slot = (int)(k % mmh_ctx::kRing);
    hipEvent_t *e = c->ring[slot];
    ms4[0] = ms4[1] = ms4[2] = ms4[3] = 0;
-   (void)hipEventElapsedTime(&ms4[3], e[0], e[2]);
-   if (c->ring_has_filter[slot]) {
-      (void)hipEventElapsedTime(&ms4[0], e[0], e[1]);
+   if (c->ring_is_ms[slot]) {
+      ms4[0] = c->ring_ms[slot][0];
+      ms4[3] = c->ring_ms[slot][1];
+   }
+   else {
+      // (an event that has not completed or was never recorded leaves its figure at 0)
+      if (hipEventElapsedTime(&ms4[3], e[0], e[2]) != hipSuccess) {
+         ms4[3] = 0;
+      }
+      if (c->ring_has_filter[slot] && hipEventElapsedTime(&ms4[0], e[0], e[1]) != hipSuccess) {
+         ms4[0] = 0;
+      }
    }
    ms4[1] = ms4[3] - ms4[0];                    // everything behind the streaming kernel
 }

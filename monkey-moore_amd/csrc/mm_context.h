@@ -101,7 +101,7 @@ struct MmPending {
    int big_endian = 0;
    uint64_t base_offset = 0;
    uint32_t max_candidates = 0;
-   hipEvent_t *ev = nullptr;        // its event triple in the ring
+   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // the lane's own event triple {start, behind the filter, end}
 };
 
 struct mmh_ctx {
@@ -129,10 +129,16 @@ struct mmh_ctx {
    static constexpr int kRing = 64;
    hipEvent_t ring[kRing][3] = {};
    bool ring_has_filter[kRing] = {};
+   // a slot may instead hold finished numbers: scans of the submit lanes use their own events (a
+   // ring slot could be re-recorded by 64 later scans before the lane is collected) and copy
+   // their timings in here when they are collected
+   bool ring_is_ms[kRing] = {};
+   float ring_ms[kRing][2] = {};    // {streaming kernel, whole scan}
    uint64_t scans_recorded = 0;     // slot of scan k is k % kRing
    hipEvent_t *ev = nullptr;        // the current scan's triple
    hipStream_t lane_stream[2] = {nullptr, nullptr};   // streams of the submit lanes
    hipEvent_t lane_fence = nullptr;                     // orders a lane behind earlier work on `stream`
+   hipEvent_t lane_ev[2][3] = {};                       // event triples of the two lanes
    MmPending pending[2];
    int next_ticket = 0;
    int engine = 0;

@@ -1068,6 +1068,8 @@ const Tuning &tuning()
       Tuning k;
       k.filter_max_conditions = (int)number("MMOORE_FILTER_MAXCOND", 4);
       k.filter_blocks = (uint64_t)number("MMOORE_FILTER_BLOCKS", 256 * 8);
+      k.filter_blocks_comm = (uint64_t)number("MMOORE_FILTER_BLOCKS_COMM", 256 * 6);
+      k.filter_gps_comm = (uint32_t)number("MMOORE_FILTER_GPS_COMM", 7);
       k.filter_groups_per_span = (uint32_t)number("MMOORE_FILTER_GPS", 8);
       k.resolve_blocks = (unsigned)number("MMOORE_RESOLVE_BLOCKS", 4096);
       k.max_candidates = (uint32_t)number("MMOORE_MAX_CANDIDATES", 262144);
@@ -1181,7 +1183,10 @@ bool filter_verifies(const mmh_plan_desc &pl, const FilterChoice &fc)
 // Launch geometry of the span kernels: 8 workgroups (32 waves) per CU fill the chip with the
 // kernels' <= 64 VGPRs; a wave streams spans of 8 groups = 32 KiB.  Measured on 4 GiB (u8):
 // spans of 4 / 8 / 16 / 32 groups -> 0.732 / 0.695 / 0.711 / 0.712 ms; 1024 .. 4096 workgroups
-// are within 0.5 % of each other.  The environment knobs are for such experiments only.
+// are within 0.5 % of each other (round 2, tools/geometry_times2.py: 2048 x 8 -> 0.700 ms,
+// 1536 x 7 -> 0.695, 1536 x 8 -> 0.705, 1024 x 8 -> 0.702), which is why a context with a
+// multi-rank communicator can leave a workgroup slot per CU to the RCCL kernel for free.
+// The environment knobs are for such experiments only.
 static uint64_t filter_max_blocks() { return tuning().filter_blocks; }
 static uint32_t filter_groups_per_span() { return tuning().filter_groups_per_span; }
 
@@ -1201,6 +1206,8 @@ static void launch_timed(Kernel kernel, dim3 grid, dim3 block, hipStream_t st, h
 
 // span kernel over the whole 4 KiB groups + bounds-checked edge kernel over the ragged end:
 // `start` goes to whichever runs first, `stop` to whichever runs last
+static thread_local uint64_t g_filter_block_cap = 0;     // launch_filter's block_cap for the launch under way (0 = none)
+
 template <class Span, class Edge>
 static void launch_filter_pair(Span span, Edge edge, hipStream_t st, const MmFilterArgs &a, const MmGeom &g, hipEvent_t start,
                                hipEvent_t stop)
@@ -1210,8 +1217,9 @@ static void launch_filter_pair(Span span, Edge edge, hipStream_t st, const MmFil
    if (have_span) {
       uint64_t spans = (a.ngroups + a.groups_per_span - 1) / a.groups_per_span;
       uint64_t blocks = (spans + 3) / 4;
-      if (blocks > filter_max_blocks()) {
-         blocks = filter_max_blocks();
+      const uint64_t most = g_filter_block_cap ? std::min(g_filter_block_cap, filter_max_blocks()) : filter_max_blocks();
+      if (blocks > most) {
+         blocks = most;
       }
       launch_timed(span, dim3((unsigned)blocks), dim3(256), st, start, have_edge ? nullptr : stop, a);
    }
@@ -1242,8 +1250,9 @@ static bool launch_filter_u8_masks(uint32_t mask2, std::integer_sequence<int, M2
 
 void launch_filter(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc,
                    uint64_t *cand, unsigned long long *ctrl, uint64_t cand_cap, hipEvent_t start, hipEvent_t stop,
-                   unsigned int *dom_count, const uint32_t *skip_bits)
+                   unsigned int *dom_count, const uint32_t *skip_bits, uint64_t block_cap)
 {
+   g_filter_block_cap = block_cap;
    MmFilterArgs a;
    a.g = g; a.plan = pl; a.iA = fc.iA; a.ncond = fc.ncond;
    a.verify = filter_verifies(pl, fc) ? 1u : 0u;
@@ -1255,7 +1264,7 @@ void launch_filter(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, con
    a.dom_count = dom_count; a.skip_bits = skip_bits;
    // whole 4 KiB groups go to the span kernel, the ragged end to the bounds-checked one
    a.ngroups = g.nbytes / 4096;
-   a.groups_per_span = filter_groups_per_span();
+   a.groups_per_span = block_cap ? tuning().filter_gps_comm : filter_groups_per_span();
    a.edge_first = a.ngroups * 256;
    const uint32_t shape = fc.shape;
    if (pl.elem_bytes == 1) {

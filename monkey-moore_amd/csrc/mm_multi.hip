@@ -158,7 +158,9 @@ extern "C" int mmh_partition(uint64_t total_bytes, uint64_t block_bytes, uint32_
    uint64_t end = b1 * block_bytes + (uint64_t)(keyword_len - 1) * elem_bytes;
    end = end > total_bytes ? total_bytes : end;
    *first_byte = first;
-   *nbytes = end > first ? end - first : 0;
+   // (more ranks than blocks: a rank without a block scans nothing -- the overlap alone would be
+   // taken for a block of its own and report its matches a second time)
+   *nbytes = (b1 > b0 && end > first) ? end - first : 0;
    return MMH_OK;
 }
 
@@ -177,7 +179,11 @@ int comm_buffers(mmh_ctx *c)
       return rc;
    }
    if (!m.stream) {
-      HIP_TRY(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
+      // highest priority: when a wave slot frees up while a scan is streaming, the collective's
+      // kernel gets it first
+      int least = 0, greatest = 0;
+      HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      HIP_TRY(hipStreamCreateWithPriority(&m.stream, hipStreamNonBlocking, greatest));
    }
    if (!m.d_send) {
       HIP_TRY(hipMalloc(&m.d_send, kRecordWords * sizeof(uint64_t)));

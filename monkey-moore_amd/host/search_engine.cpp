@@ -8,9 +8,12 @@
 #include "mmoore/search_engine.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <fstream>
+#include <mutex>
 #include <sstream>
 #include <stdexcept>
+#include <thread>
 #include <unordered_map>
 
 #include "matcher_state.hpp"
@@ -114,6 +117,82 @@ std::string make_preview(const mmoore::SearchConfig &cfg, std::ifstream &file, u
 
 } // namespace
 
+namespace {
+
+// ---- the GPUs a run() fans its partitions over ---------------------------------------------
+//
+// The reference keeps `preferred_num_threads` workers busy with blocks (search_engine.cpp:66-188);
+// here the unit of work is a block-aligned partition of the file and the workers are GPUs: every
+// device streams its own partition over its own PCIe link, scans it, and the ascending offset
+// lists are gathered over RCCL (mmh_scan_multi).  Small files stay on one device -- bringing up
+// eight contexts and a communicator for a 16 MiB ROM would cost more than the search.
+//   MMOORE_HIP_DEVICES=n   use at most n devices (default: all visible)
+//   MMOORE_HIP_MULTI=1     take the multi-device path even with one device (tests: communicator of one)
+constexpr uint64_t kMinBytesPerDevice = 1ull << 30;
+
+struct DeviceSet {
+   std::mutex lock;                         // one run() at a time drives the set
+   std::vector<mmh_ctx *> ctx;
+   ~DeviceSet()
+   {
+      for (mmh_ctx *c : ctx) {
+         mmh_destroy(c);
+      }
+   }
+};
+
+DeviceSet &device_set()
+{
+   static DeviceSet set;
+   return set;
+}
+
+int devices_wanted(uint64_t file_size, bool *forced)
+{
+   const char *multi = std::getenv("MMOORE_HIP_MULTI");
+   *forced = multi && *multi && *multi != '0';
+   int visible = 0;
+   if (mmh_device_count(&visible) != MMH_OK || visible < 1) {
+      return 1;                             // thread_context() reports the missing device properly
+   }
+   const char *cap = std::getenv("MMOORE_HIP_DEVICES");
+   int most = cap && std::atoi(cap) > 0 ? std::min(visible, std::atoi(cap)) : visible;
+   const uint64_t by_size = std::max<uint64_t>(1, file_size / kMinBytesPerDevice);
+   return (int)std::min<uint64_t>((uint64_t)most, by_size);
+}
+
+// contexts 0 .. n-1 of the set, rank i of one communicator of n (rebuilt when n changes)
+void ensure_devices(DeviceSet &set, int n)
+{
+   using mmoore_amd::throw_last_error;
+   int rank = 0, nranks = 0;
+   if ((int)set.ctx.size() == n && mmh_comm_info(set.ctx[0], &rank, &nranks) == MMH_OK && nranks == n) {
+      return;
+   }
+   for (mmh_ctx *c : set.ctx) {
+      mmh_destroy(c);
+   }
+   set.ctx.clear();
+   const char *env = std::getenv("MMOORE_HIP_DEVICE");
+   const int first = env ? std::atoi(env) : 0;
+   for (int i = 0; i < n; i++) {
+      mmh_ctx *c = nullptr;
+      if (mmh_create(first + i, &c) != MMH_OK) {
+         throw_last_error("MI355X engine unavailable (there is no CPU fallback)");
+      }
+      set.ctx.push_back(c);
+   }
+   if (mmh_comm_init_all(set.ctx.data(), n) != MMH_OK) {
+      throw_last_error("RCCL communicator over the visible GPUs failed");
+   }
+}
+
+struct Partition {
+   uint64_t base = 0, bytes = 0, blocks = 0;
+};
+
+} // namespace
+
 template <typename DataType>
 std::vector<mmoore::SearchResult<DataType>> mmoore::SearchEngine<DataType>::run(ProgressCallback on_progress,
                                                                                 std::atomic<bool> &abort_flag,
@@ -145,33 +224,80 @@ std::vector<mmoore::SearchResult<DataType>> mmoore::SearchEngine<DataType>::run(
 
    on_progress(0, SearchStep::Searching);
 
-   std::ifstream file(config.file_path, std::ios::binary);
-   if (!file.is_open() && file_size) {
-      throw std::runtime_error("Failed to open file: " + config.file_path.string());
+   bool forced_multi = false;
+   const int ndev = devices_wanted(file_size, &forced_multi);
+   const bool multi = ndev > 1 || forced_multi;
+   DeviceSet &set = device_set();
+   std::unique_lock<std::mutex> hold(set.lock, std::defer_lock);
+   std::vector<mmh_ctx *> ctxs;
+   if (multi) {
+      hold.lock();
+      ensure_devices(set, ndev);
+      ctxs = set.ctx;
    }
-   mmh_ctx *ctx = thread_context();
+   else {
+      ctxs.push_back(thread_context());
+   }
    std::vector<uint64_t> offsets(4096), rom_offsets;
-   std::vector<uint8_t> under;                              // the elements under every match of a partition
+   std::vector<uint8_t> under;                              // the elements under every match of a round
    const int big_endian = config.endianness == Endianness::Big ? 1 : 0;
    const uint32_t match_bytes = st.plan.L * static_cast<uint32_t>(sizeof(DataType));
    const std::string path = config.file_path.string();
-   file.close();
 
-   for (uint64_t first_block = 0; first_block < num_blocks; first_block += blocks_per_partition) {
-      const uint64_t nblk = std::min(blocks_per_partition, num_blocks - first_block);
-      const uint64_t base = first_block * block;                                 // 64-bit, unlike the reference
-      const uint64_t want = std::min(nblk * block + overlap, file_size - base);  // pattern-length overlap
-      // file -> HBM through parallel readers and overlapped copies (mm_ingest.hip); no host copy is kept
-      if (mmh_rom_load_file(ctx, path.c_str(), base, want, 0) != MMH_OK) {
-         const std::string why = mmh_last_error();
+   // a round = one partition per device, consecutive in the file; rounds follow each other
+   for (uint64_t first_block = 0; first_block < num_blocks; first_block += blocks_per_partition * ctxs.size()) {
+      const uint64_t round_blocks = std::min<uint64_t>(blocks_per_partition * ctxs.size(), num_blocks - first_block);
+      std::vector<Partition> parts(ctxs.size());
+      for (size_t i = 0; i < ctxs.size(); i++) {
+         // whole blocks, dealt out evenly in device order (the rule of mmh_partition), 64-bit offsets unlike the reference
+         const uint64_t b0 = first_block + round_blocks * i / ctxs.size();
+         const uint64_t b1 = first_block + round_blocks * (i + 1) / ctxs.size();
+         parts[i].blocks = b1 - b0;
+         parts[i].base = b0 * block;
+         parts[i].bytes = b1 > b0 ? std::min((b1 - b0) * block + overlap, file_size - parts[i].base) : 0;   // pattern-length overlap
+      }
+      // file -> HBM through parallel readers and overlapped copies (mm_ingest.hip), every device
+      // at once over its own PCIe link; no host copy is kept
+      std::vector<std::string> load_error(ctxs.size());
+      auto load = [&](size_t i) {
+         if (mmh_rom_load_file(ctxs[i], path.c_str(), parts[i].base, parts[i].bytes, 0) != MMH_OK) {
+            load_error[i] = mmh_last_error();
+         }
+      };
+      std::vector<std::thread> loaders;
+      for (size_t i = 1; i < ctxs.size(); i++) {
+         loaders.emplace_back(load, i);
+      }
+      load(0);
+      for (auto &t : loaders) {
+         t.join();
+      }
+      for (const std::string &why : load_error) {
+         if (why.empty()) {
+            continue;
+         }
          if (why.find("short read") != std::string::npos) {
             throw std::runtime_error("Short read from " + path);
          }
-         throw_last_error("streaming a file partition to the GPU failed");
+         throw std::runtime_error("streaming a file partition to the GPU failed: " + why);
+      }
+      if (abort_flag) {                                       // polled between ingest, scan and gather (search_engine.cpp:177-187)
+         return {};
       }
       uint64_t count = 0;
       for (;;) {
-         int rc = mmh_scan(ctx, &st.plan, block, big_endian, base, offsets.data(), offsets.size(), &count);
+         int rc;
+         if (multi) {
+            std::vector<uint64_t> bases;
+            for (const Partition &p : parts) {
+               bases.push_back(p.base);
+            }
+            rc = mmh_scan_multi(ctxs.data(), (int)ctxs.size(), &st.plan, block, big_endian, bases.data(), offsets.data(),
+                                offsets.size(), &count);
+         }
+         else {
+            rc = mmh_scan(ctxs[0], &st.plan, block, big_endian, parts[0].base, offsets.data(), offsets.size(), &count);
+         }
          if (rc == MMH_E_CAPACITY) {
             offsets.resize(count + 16);
             continue;
@@ -181,14 +307,28 @@ std::vector<mmoore::SearchResult<DataType>> mmoore::SearchEngine<DataType>::run(
          }
          break;
       }
+      if (abort_flag) {
+         return {};
+      }
       if (count && !st.value_scan) {
-         rom_offsets.resize(count);
-         for (uint64_t i = 0; i < count; i++) {
-            rom_offsets[i] = offsets[i] - base;
-         }
+         // the elements under the matches, from the device that holds them: a match that starts in
+         // partition i lies entirely inside it (that is what the overlap is for)
          under.resize(count * match_bytes);
-         if (mmh_rom_gather(ctx, rom_offsets.data(), count, match_bytes, under.data()) != MMH_OK) {
-            throw_last_error("fetching the matched elements failed");
+         uint64_t at = 0;
+         for (size_t i = 0; i < ctxs.size() && at < count; i++) {
+            const uint64_t limit = i + 1 < ctxs.size() ? parts[i + 1].base : ~0ull;
+            uint64_t end = at;
+            while (end < count && offsets[end] < limit) {
+               end++;
+            }
+            rom_offsets.resize(end - at);
+            for (uint64_t k = at; k < end; k++) {
+               rom_offsets[k - at] = offsets[k] - parts[i].base;
+            }
+            if (end > at && mmh_rom_gather(ctxs[i], rom_offsets.data(), end - at, match_bytes, under.data() + at * match_bytes) != MMH_OK) {
+               throw_last_error("fetching the matched elements failed");
+            }
+            at = end;
          }
       }
       for (uint64_t i = 0; i < count; i++) {
@@ -198,15 +338,12 @@ std::vector<mmoore::SearchResult<DataType>> mmoore::SearchEngine<DataType>::run(
          results.push_back({offsets[i], build_values_map<DataType>(st, elem), std::string()});
       }
       // one progress tick per reference block, then the abort poll (search_engine.cpp:161-187)
-      for (uint64_t b = 0; b < nblk; b++) {
+      for (uint64_t b = 0; b < round_blocks; b++) {
          progress += progress_step;
          on_progress(static_cast<int>(progress), SearchStep::Searching);
          if (abort_flag) {
             return {};
          }
-      }
-      if (abort_flag) {
-         return {};
       }
    }
    if (abort_flag) {
@@ -214,8 +351,8 @@ std::vector<mmoore::SearchResult<DataType>> mmoore::SearchEngine<DataType>::run(
    }
 
    on_progress(100, SearchStep::GeneratingPreviews);
-   // partitions are scanned in file order and each returns ascending offsets, so the list
-   // is already ordered the way the reference's std::sort leaves it (:193-197)
+   // rounds follow the file and each returns ascending offsets, so the list is already ordered
+   // the way the reference's std::sort leaves it (:193-197)
 
    if (generate_previews && !results.empty()) {
       std::ifstream preview_file(config.file_path, std::ios::binary);

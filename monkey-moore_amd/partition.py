@@ -1,7 +1,9 @@
-"""Multi-GPU plumbing: block-aligned partitions of a ROM and the gather of the per-rank
-offset lists.  torch.distributed only -- backend "nccl" (= RCCL over xGMI) on
-GPUs, "gloo" in the CPU tests; the scan itself never needs a collective because every
-reference block (x byte alignment) is an independent chain."""
+"""Test double of the multi-GPU plumbing.  The product path is in the C ABI (csrc/mm_multi.hip:
+mmh_partition, mmh_comm_*, mmh_gather_start / _finish, mmh_scan_multi -- RCCL called from the
+library itself, lists sent from HBM).  This module restates the same protocol on top of
+torch.distributed so that the CPU suite can run it with "gloo" and two processes
+(tests/test_multi_gpu_host.py), and bench.py keeps it as a loudly flagged fallback should the
+native communicator fail to come up on a box the builder could not test on."""
 import numpy as np
 
 GATHER_WIDTH = 8192     # int64 words per rank in the fixed-width record: [count, offsets...]
@@ -14,6 +16,8 @@ def shard_range(total_bytes, block_bytes, keyword_len, elem_bytes, rank, world):
     b0 = rank * nblocks // world
     b1 = (rank + 1) * nblocks // world
     first = b0 * block_bytes
+    if b1 == b0:
+        return first, 0                                  # more ranks than blocks: nothing to scan here
     end = min(b1 * block_bytes + (keyword_len - 1) * elem_bytes, total_bytes)
     return first, max(end - first, 0)
 

@@ -1,0 +1,3 @@
+// main() of the Catch2 stand-in (the reference links Catch2::Catch2WithMain, tests/CMakeLists.txt)
+#include <catch2/catch_test_macros.hpp>
+int main() { return catch_shim::run_all(); }

@@ -1,0 +1,145 @@
+"""The multi-GPU half of the C ABI (csrc/mm_multi.hip) on the one GPU this suite has: a
+communicator of one.  Everything a real 8-rank run does is exercised except the wire --
+communicator bring-up through librccl, the all-gather sent from the device-side copy of the
+scan's list, the packing kernel, the second (padded) phase for long lists, start / finish
+overlap with two gathers in flight, mmh_scan_multi, and SearchEngine<T>::run's multi-device
+path.  Needs a real MI355X: run with `pytest -m gpu`."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+BLOCK = 65536
+
+
+@pytest.fixture(scope="module")
+def comm_engine(mm):
+    if mm.device_count() == 0:
+        pytest.fail("no HIP device: the gpu tests need a real MI355X (there is no CPU fallback)")
+    eng = mm.Engine(0)
+    assert eng.comm_info() == (0, 0)                       # no communicator yet
+    with pytest.raises(mm.MMError):
+        eng.gather_start(None)                             # ... so no gather
+    mm.comm_init_all([eng])
+    assert eng.comm_info() == (0, 1)
+    yield eng
+    eng.close()
+
+
+def _rom(mm, eng, nbytes, kw, elem=1, be=False, **spec_kw):
+    spec = mm.synth.RomSpec(11, nbytes, kw, elem, None, be, BLOCK, **spec_kw)
+    eng.alloc(nbytes)
+    spec.apply_device(eng)
+    return eng.download(0, nbytes)
+
+
+def test_scan_then_gather_from_device(mm, comm_engine, oracle):
+    eng = comm_engine
+    rom = _rom(mm, eng, (8 << 20) + 777, "relativesrch")
+    plan = mm.plan_relative(1, "relativesrch")
+    want = oracle.engine(oracle.plan(1, "relativesrch"), rom, BLOCK)
+    local = eng.scan(plan, block_bytes=BLOCK, base_offset=1 << 40)
+    eng.gather_start(None)                                 # the list of that scan, straight from HBM
+    merged = eng.gather_finish()
+    assert merged.tolist() == local.tolist() == (want + np.uint64(1 << 40)).tolist()
+    assert len(merged) >= 8
+    t = eng.gather_timings()
+    assert t["device_ms"] > 0 and t["host_ms"] > 0
+    # ranks that only need the total
+    eng.scan(plan, block_bytes=BLOCK)
+    eng.gather_start(None, want_list=False)
+    assert eng.gather_finish(want_list=False) == len(want)
+
+
+@pytest.mark.parametrize("elem,kw,be", [(1, "relativesrch", False), (2, "textsrch", True), (1, "re*ative*ear*hxy", False)])
+def test_scan_multi_communicator_of_one(mm, comm_engine, oracle, elem, kw, be):
+    eng = comm_engine
+    wc = ord("*") if "*" in kw else 0
+    spec = mm.synth.RomSpec(5, (6 << 20) + 4099, kw, elem, wc or None, be, BLOCK)
+    eng.alloc(spec.nbytes)
+    spec.apply_device(eng)
+    rom = eng.download(0, spec.nbytes)
+    want = oracle.engine(oracle.plan(elem, kw, wc), rom, BLOCK, be)
+    got = mm.scan_multi([eng], mm.plan_relative(elem, kw, wc), BLOCK, [0], big_endian=be, cap=4)   # cap 4: the capacity retry
+    assert got.tolist() == want.tolist() and len(got) >= 6
+
+
+def test_gather_of_host_lists_short_long_and_empty(mm, comm_engine):
+    eng = comm_engine
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 4223, 16384, 16385, 50000):
+        offs = np.sort(rng.choice(1 << 40, size=n, replace=False)).astype(np.uint64)
+        eng.gather_start(offs)
+        got = eng.gather_finish(cap=16)
+        assert got.dtype == np.uint64 and got.tolist() == offs.tolist(), n
+
+
+def test_long_scan_lists_take_the_second_phase(mm, comm_engine, oracle):
+    # a short keyword on constant data: far more matches than a gather record holds, and the
+    # list only exists in host memory after the scan (radix sort / forward engine)
+    eng = comm_engine
+    n = 1 << 20
+    eng.alloc(n)
+    eng.fill(0, n, 7)
+    rom = eng.download(0, n)
+    want = oracle.engine(oracle.plan(1, "aaa"), rom, BLOCK)
+    local = eng.scan(mm.plan_relative(1, "aaa"), block_bytes=BLOCK, cap=1 << 20)
+    assert len(want) > 100000 and local.tolist() == want.tolist()
+    eng.gather_start(None)
+    assert eng.gather_finish(cap=1 << 20).tolist() == want.tolist()
+
+
+def test_two_gathers_in_flight_overlap_the_next_scan(mm, comm_engine, oracle):
+    # bench.py's pattern at N > 1: scan k, start gather k, finish gather k-1
+    eng = comm_engine
+    rom = _rom(mm, eng, 4 << 20, "relativesrch")
+    plans = [("relativesrch", 0), ("elativesrch", 0), ("re*ativesrch", ord("*")), ("relativesrc", 0), ("srch", 0)]
+    wants = [oracle.engine(oracle.plan(1, kw, wc), rom, BLOCK) for kw, wc in plans]
+    done, pending = [], 0
+    for kw, wc in plans:
+        eng.scan(mm.plan_relative(1, kw, wc), block_bytes=BLOCK)
+        eng.gather_start(None)
+        pending += 1
+        if pending == 2:
+            done.append(eng.gather_finish())
+            pending -= 1
+    done.append(eng.gather_finish())
+    assert [d.tolist() for d in done] == [w.tolist() for w in wants]
+    with pytest.raises(mm.MMError):
+        eng.gather_finish()                                # nothing outstanding
+    # a third start without a finish is refused, and leaves the two outstanding ones intact
+    eng.scan(mm.plan_relative(1, "relativesrch"), block_bytes=BLOCK)
+    eng.gather_start(None)
+    eng.gather_start(np.arange(5, dtype=np.uint64))
+    with pytest.raises(mm.MMError):
+        eng.gather_start(None)
+    assert eng.gather_finish().tolist() == wants[0].tolist()
+    assert eng.gather_finish().tolist() == [0, 1, 2, 3, 4]
+
+
+def test_native_gather_next_to_torch_nccl():
+    # the way bench.py runs at N > 1: torch.distributed ("nccl") owns the rendezvous and the
+    # barriers, the library brings up its OWN RCCL communicator from an id that travels through
+    # torch.distributed, both in one process
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_native_gather_check.py")], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "native gather ok" in r.stdout
+
+
+def test_search_engine_run_multi_device_path(mm):
+    # SearchEngine<T>::run through mmh_comm_init_all + mmh_scan_multi (MMOORE_HIP_MULTI=1 takes that
+    # path with the one device there is): the reference's own engine vectors, previews, progress, abort
+    from test_facade import _build_tests
+    exe = _build_tests(mm)
+    env = dict(os.environ, MMOORE_HIP_MULTI="1")
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, env=env)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert " 0 failures" in r.stdout

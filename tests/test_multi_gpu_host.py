@@ -132,3 +132,44 @@ def test_shard_ranges_tile_the_rom():
             assert first + n == min(nxt + L - 1, total)
             covered = nxt
         assert covered == total
+
+
+def test_c_abi_partition_matches_the_double_and_tiles_the_rom():
+    """mmh_partition (the product's rule, C) == partition.shard_range (the test double), and the
+    partitions tile the file on block boundaries with the pattern-length overlap."""
+    mm = load_package()
+    for total in (0, 1, 100, 524288, 524289, (64 << 20) + 12345, 7 * 524288, (8 << 30) * 8, (1 << 44) + 3):
+        for block in (4096, 524288, 8388608):
+            for L, S in ((12, 1), (8, 2), (2, 1)):
+                for world in (1, 2, 3, 8, 64):
+                    covered = 0
+                    for r in range(world):
+                        first, n = mm.partition_range(total, block, L, S, r, world)
+                        assert (first, n) == mm.partition.shard_range(total, block, L, S, r, world)
+                        assert first % block == 0 and first == covered
+                        nxt = mm.partition_range(total, block, L, S, r + 1, world)[0] if r + 1 < world else total
+                        assert first + n == min(nxt + (L - 1) * S, total) or (n == 0 and nxt == first)
+                        covered = nxt
+                    assert covered == total or total == 0
+    with pytest.raises(mm.MMError):
+        mm.partition_range(100, 0, 12, 1, 0, 1)
+    with pytest.raises(mm.MMError):
+        mm.partition_range(100, 16, 12, 1, 2, 2)
+
+
+def test_partition_rule_in_cpp():
+    """tests/cpp/partition_tests.cpp: the same properties from C++ through the C ABI header, plus the
+    per-device attribution of merged offsets SearchEngine<T>::run relies on (a match that starts in
+    partition i lies wholly inside the bytes partition i holds)."""
+    import subprocess
+    mm = load_package()
+    mm.build.build_all()
+    build = os.path.join(ROOT, "tests", "cpp", "build")
+    os.makedirs(build, exist_ok=True)
+    exe = os.path.join(build, "partition_tests")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "partition_tests.cpp"), "-L" + mm.build.LIB_DIR, "-lmmoore_hip",
+                           "-Wl,-rpath," + mm.build.LIB_DIR, "-o", exe])
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert " 0 failures" in r.stdout
