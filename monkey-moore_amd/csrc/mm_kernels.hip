@@ -200,9 +200,20 @@ __device__ __forceinline__ bool mm_is_candidate(const MmGeom &g, const mmh_plan_
 // loop therefore tests two (14 per dword) and hands the ~1.6 % of the pieces
 // with a hit to a rolled second stage that tests all of them.
 
-struct MmFilterArgs {
+// wave-uniform constants shared by the tile kernels (kernel arguments -> SGPRs)
+struct MmTileArgs {
    MmGeom g;
    mmh_plan_desc plan;
+   uint32_t inv_d;          // ceil(65536 / D): x / D == (x * inv_d) >> 16 for x < 2100
+   uint32_t inv_d32;        // floor(2^32 / D) + 1: quotient estimate for 32-bit x, at most one too big
+   uint32_t block_shift;    // log2(block_bytes) when that is a power of two, else ~0
+   uint64_t skip_bloom;     // bit (d & 63) set for every listed bad-character diff
+};
+
+// Arguments of the streaming code.  The span / edge kernels take this struct; the fused scan kernel
+// (mm_fused.h) takes a struct with the same member names (the streaming code is templated on it).
+struct MmFilterArgs {
+   MmTileArgs t;           // geometry + plan (the tile constants are only used by the fused kernel's resolver)
    uint32_t pat[4];        // condition k, replicated over the SWAR lanes
    uint32_t sh[4];         // 8-bit shapes with run-time shifts: v_alignbit amount 32 - 8 s_k of condition k
    uint32_t iA;            // keyword index of the element whose delta is pat[0]
@@ -222,7 +233,8 @@ struct MmFilterArgs {
 };
 
 // a workgroup always appends to the same list: no two lists share an atomic address
-__device__ __forceinline__ void mm_cand_append(const MmFilterArgs &a, bool want, uint64_t off)
+template <class A>
+__device__ __forceinline__ void mm_cand_append(const A &a, bool want, uint64_t off)
 {
    const uint32_t c = blockIdx.x & (MM_CAND_LISTS - 1);
    mm_append(a.cand + (uint64_t)c * a.list_cap, a.list_count + c * MM_LIST_STRIDE, a.list_cap, want, off);
@@ -230,12 +242,13 @@ __device__ __forceinline__ void mm_cand_append(const MmFilterArgs &a, bool want,
 
 // Where the survivors go: the candidate lists -- or, in the two passes that deal with candidate
 // floods, a per-domain count (one atomic per wave and domain) / the lists minus the flagged domains.
-__device__ __forceinline__ void mm_cand_emit(const MmFilterArgs &a, bool want, uint64_t off)
+template <class A>
+__device__ __forceinline__ void mm_cand_emit(const A &a, bool want, uint64_t off)
 {
    if (a.dom_count || a.skip_bits) {                       // wave uniform
       uint64_t b = 0; uint32_t p = 0; int64_t j = 0;
-      const bool located = want && mm_locate(a.g, off, &b, &p, &j);
-      const uint32_t dom = located ? (uint32_t)(b * a.g.S + p) : 0u;
+      const bool located = want && mm_locate(a.t.g, off, &b, &p, &j);
+      const uint32_t dom = located ? (uint32_t)(b * a.t.g.S + p) : 0u;
       if (a.dom_count) {
          unsigned long long todo = __ballot(located);
          while (todo) {
@@ -258,7 +271,8 @@ __device__ __forceinline__ void mm_cand_emit(const MmFilterArgs &a, bool want, u
 // reserves their slots and returns this lane's first one (the caller stores while slot < cap).
 // A padding run that matches the keyword wholesale has 16 survivors per lane and piece: one
 // round trip per piece instead of sixteen.
-__device__ __forceinline__ uint64_t *mm_cand_reserve(const MmFilterArgs &a, uint32_t cnt, uint32_t *first, uint32_t *room)
+template <class A>
+__device__ __forceinline__ uint64_t *mm_cand_reserve(const A &a, uint32_t cnt, uint32_t *first, uint32_t *room)
 {
    // returns (wave uniform) the address of the wave's first reserved slot; *first = this lane's
    // first slot relative to it, *room = how many of the wave's slots exist at all (list capacity)
@@ -377,16 +391,17 @@ __device__ __forceinline__ uint32_t mm_f8_pack(const uint32_t (&h)[4])
 
 // verify the survivors flagged in `bits` (bit 8*b + k of this lane's chunk at byte `chunk0`)
 // and append the real candidates; the whole wave takes part (ballots inside)
-__device__ __forceinline__ void mm_f8_survivors(const MmFilterArgs &a, uint64_t chunk0, uint32_t bits)
+template <class A>
+__device__ __forceinline__ void mm_f8_survivors(const A &a, uint64_t chunk0, uint32_t bits)
 {
    const bool head = __ballot(bits != 0 && chunk0 < MMH_MAX_KEYWORD) != 0;   // a survivor may lie in front of the anchor
    bool batch = !a.verify && !a.dom_count && !a.skip_bits && !head;
-   if (!a.verify && !head && !batch && !a.g.whole) {
+   if (!a.verify && !head && !batch && !a.t.g.whole) {
       // Flood handling passes, 8-bit: a piece lies in ONE block (= domain) nearly always.  Then
       // the count pass adds the piece's survivors with one atomic and the filtered pass drops
       // or keeps them wholesale, instead of locating every survivor on its own.
-      const uint64_t blk = (chunk0 - a.iA) / a.g.block_bytes;
-      const uint64_t blk_last = (chunk0 + 15 - a.iA) / a.g.block_bytes;
+      const uint64_t blk = (chunk0 - a.iA) / a.t.g.block_bytes;
+      const uint64_t blk_last = (chunk0 + 15 - a.iA) / a.t.g.block_bytes;
       const uint64_t lead = mm_uniform64_k(blk);
       if (__ballot(bits != 0 && (blk != lead || blk_last != lead)) == 0) {
          if (a.dom_count) {
@@ -431,7 +446,7 @@ __device__ __forceinline__ void mm_f8_survivors(const MmFilterArgs &a, uint64_t 
          // With enough SWAR conditions practically every survivor is a real candidate and the
          // resolver (which stages the bytes anyway) verifies it; running the dependent-load
          // compare loop here would stall this wave's stream for microseconds per survivor.
-         if (a.verify ? mm_is_candidate(a.g, a.plan, o) : (o >= 0)) {
+         if (a.verify ? mm_is_candidate(a.t.g, a.t.plan, o) : (o >= 0)) {
             want = true;
             off = (uint64_t)o;
          }
@@ -442,20 +457,21 @@ __device__ __forceinline__ void mm_f8_survivors(const MmFilterArgs &a, uint64_t 
 
 // bounds-checked version for the ragged end of the ROM (everything behind the last
 // whole 4 KiB group): one chunk per lane per iteration, look-back by a second load
-template <int SHAPE>
-__global__ __launch_bounds__(256) void mm_filter_u8_edge(MmFilterArgs a)
+// (nblocks workgroups take part, this one is number `block` of them)
+template <int SHAPE, class A>
+__device__ __forceinline__ void mm_edge_u8(const A &a, uint32_t block, uint32_t nblocks)
 {
-   const uint64_t nchunks = (a.g.nbytes + 15) / 16;
-   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+   const uint64_t nchunks = (a.t.g.nbytes + 15) / 16;
+   const uint64_t stride = (uint64_t)nblocks * blockDim.x;
    // same trip count in every lane: the ballots must see whole waves
    const uint64_t iters = (nchunks - a.edge_first + stride - 1) / stride;
    for (uint64_t it = 0; it < iters; it++) {
-      const uint64_t c = a.edge_first + it * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+      const uint64_t c = a.edge_first + it * stride + (uint64_t)block * blockDim.x + threadIdx.x;
       uint32_t h[4] = {0, 0, 0, 0};
       uint32_t any = 0;
       if (c < nchunks) {
-         const uint4 w = mm_load_chunk(a.g.rom, a.g.nbytes, c * 16);
-         const uint32_t back = c ? *reinterpret_cast<const uint32_t *>(a.g.rom + c * 16 - 4) : 0u;
+         const uint4 w = mm_load_chunk(a.t.g.rom, a.t.g.nbytes, c * 16);
+         const uint32_t back = c ? *reinterpret_cast<const uint32_t *>(a.t.g.rom + c * 16 - 4) : 0u;
          any = mm_f8_chunk<SHAPE>(w, back, a.pat, a.sh, h);
       }
       if (__ballot(any != 0) != 0) {
@@ -472,15 +488,21 @@ __global__ __launch_bounds__(256) void mm_filter_u8_edge(MmFilterArgs a)
 // chunk comes from the neighbouring lane (DPP wave_shr:1), lane 0 takes it from
 // lane 63 of the previous piece (v_readlane) -- no second memory access.
 template <int SHAPE>
-__global__ __launch_bounds__(256) void mm_filter_u8(MmFilterArgs a)
+__global__ __launch_bounds__(256) void mm_filter_u8_edge(MmFilterArgs a)
+{
+   mm_edge_u8<SHAPE>(a, blockIdx.x, gridDim.x);
+}
+
+template <int SHAPE, class A>
+__device__ __forceinline__ void mm_stream_u8(const A &a)
 {
    constexpr int DEPTH = 2;
    const uint32_t lane = threadIdx.x & 63;
    const uint64_t wave = __builtin_amdgcn_readfirstlane((uint32_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
    const uint64_t gps = a.groups_per_span;
-   const uint4 *rom4 = reinterpret_cast<const uint4 *>(a.g.rom);
-   const uint32_t *rom1 = reinterpret_cast<const uint32_t *>(a.g.rom);
+   const uint4 *rom4 = reinterpret_cast<const uint4 *>(a.t.g.rom);
+   const uint32_t *rom1 = reinterpret_cast<const uint32_t *>(a.t.g.rom);
 
    // Round i hands span i*nwaves + ((wave + 2731 i) mod nwaves) to this wave: neighbouring waves
    // still stream neighbouring spans, but anything periodic in the ROM (candidates at every
@@ -531,8 +553,8 @@ __global__ __launch_bounds__(256) void mm_filter_u8(MmFilterArgs a)
             const uint32_t bit = (uint32_t)__builtin_ctz(pending);
             pending &= pending - 1;
             const uint64_t byte0 = (g + (bit >> 2)) * 4096 + (uint64_t)(bit & 3) * 1024 + lane * 16;
-            const uint4 wu = *reinterpret_cast<const uint4 *>(a.g.rom + byte0);
-            const uint32_t back = byte0 ? *reinterpret_cast<const uint32_t *>(a.g.rom + byte0 - 4) : 0u;
+            const uint4 wu = *reinterpret_cast<const uint4 *>(a.t.g.rom + byte0);
+            const uint32_t back = byte0 ? *reinterpret_cast<const uint32_t *>(a.t.g.rom + byte0 - 4) : 0u;
             uint32_t h[4];
             if (__ballot(mm_f8_chunk<SHAPE>(wu, back, a.pat, a.sh, h) != 0) != 0) {
                mm_f8_survivors(a, byte0, mm_f8_pack(h));
@@ -657,7 +679,8 @@ __device__ __forceinline__ uint32_t mm_f16_pack(const uint32_t (&he)[4], const u
    return bits;
 }
 
-__device__ __forceinline__ void mm_f16_survivors(const MmFilterArgs &a, uint64_t chunk0, uint32_t bits)
+template <class A>
+__device__ __forceinline__ void mm_f16_survivors(const A &a, uint64_t chunk0, uint32_t bits)
 {
    if (!a.verify && !a.dom_count && !a.skip_bits && __ballot(bits != 0 && chunk0 < 2 * MMH_MAX_KEYWORD + 2) == 0) {
       uint32_t slot, room;
@@ -682,7 +705,7 @@ __device__ __forceinline__ void mm_f16_survivors(const MmFilterArgs &a, uint64_t
          const int j = bit >> 2, odd = (bit >> 1) & 1, half = bit & 1;
          const int64_t u = (int64_t)(chunk0 + 4 * j + 2 * half) - odd;
          const int64_t o = u - 2 * (int64_t)a.iA;
-         if (a.verify ? mm_is_candidate(a.g, a.plan, o) : (o >= 0)) {
+         if (a.verify ? mm_is_candidate(a.t.g, a.t.plan, o) : (o >= 0)) {
             want = true;
             off = (uint64_t)o;
          }
@@ -692,20 +715,20 @@ __device__ __forceinline__ void mm_f16_survivors(const MmFilterArgs &a, uint64_t
 }
 
 // bounds-checked version for the ragged end of the ROM
-template <int SHAPE>
-__global__ __launch_bounds__(256) void mm_filter_u16_edge(MmFilterArgs a)
+template <int SHAPE, class A>
+__device__ __forceinline__ void mm_edge_u16(const A &a, uint32_t block, uint32_t nblocks)
 {
-   const uint64_t nchunks = (a.g.nbytes + 15) / 16;
-   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-   const bool be = a.g.big_endian != 0;
+   const uint64_t nchunks = (a.t.g.nbytes + 15) / 16;
+   const uint64_t stride = (uint64_t)nblocks * blockDim.x;
+   const bool be = a.t.g.big_endian != 0;
    const uint64_t iters = (nchunks - a.edge_first + stride - 1) / stride;
-   const uint32_t *rom1 = reinterpret_cast<const uint32_t *>(a.g.rom);
+   const uint32_t *rom1 = reinterpret_cast<const uint32_t *>(a.t.g.rom);
    for (uint64_t it = 0; it < iters; it++) {
-      const uint64_t c = a.edge_first + it * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+      const uint64_t c = a.edge_first + it * stride + (uint64_t)block * blockDim.x + threadIdx.x;
       uint32_t he[4] = {0, 0, 0, 0}, ho[4] = {0, 0, 0, 0};
       uint32_t any = 0;
       if (c < nchunks) {
-         const uint4 w = mm_load_chunk(a.g.rom, a.g.nbytes, c * 16);
+         const uint4 w = mm_load_chunk(a.t.g.rom, a.t.g.nbytes, c * 16);
          uint32_t r[7] = {0, 0, 0, w.x, w.y, w.z, w.w};
          if (c) {
             r[0] = rom1[c * 4 - 3]; r[1] = rom1[c * 4 - 2]; r[2] = rom1[c * 4 - 1];
@@ -721,16 +744,22 @@ __global__ __launch_bounds__(256) void mm_filter_u16_edge(MmFilterArgs a)
 // span kernel: same streaming structure as mm_filter_u8 (4 KiB groups, two groups of
 // look-ahead, look-back through DPP wave_shr:1 / v_readlane instead of a second load)
 template <int SHAPE>
-__global__ __launch_bounds__(256) void mm_filter_u16(MmFilterArgs a)
+__global__ __launch_bounds__(256) void mm_filter_u16_edge(MmFilterArgs a)
+{
+   mm_edge_u16<SHAPE>(a, blockIdx.x, gridDim.x);
+}
+
+template <int SHAPE, class A>
+__device__ __forceinline__ void mm_stream_u16(const A &a)
 {
    constexpr int DEPTH = 2;
    const uint32_t lane = threadIdx.x & 63;
-   const bool be = a.g.big_endian != 0;
+   const bool be = a.t.g.big_endian != 0;
    const uint64_t wave = __builtin_amdgcn_readfirstlane((uint32_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
    const uint64_t gps = a.groups_per_span;
-   const uint4 *rom4 = reinterpret_cast<const uint4 *>(a.g.rom);
-   const uint32_t *rom1 = reinterpret_cast<const uint32_t *>(a.g.rom);
+   const uint4 *rom4 = reinterpret_cast<const uint4 *>(a.t.g.rom);
+   const uint32_t *rom1 = reinterpret_cast<const uint32_t *>(a.t.g.rom);
 
    // Round i hands span i*nwaves + ((wave + 2731 i) mod nwaves) to this wave: neighbouring waves
    // still stream neighbouring spans, but anything periodic in the ROM (candidates at every
@@ -801,6 +830,18 @@ __global__ __launch_bounds__(256) void mm_filter_u16(MmFilterArgs a)
          }
       }
    }
+}
+
+template <int SHAPE>
+__global__ __launch_bounds__(256) void mm_filter_u8(MmFilterArgs a)
+{
+   mm_stream_u8<SHAPE>(a);
+}
+
+template <int SHAPE>
+__global__ __launch_bounds__(256) void mm_filter_u16(MmFilterArgs a)
+{
+   mm_stream_u16<SHAPE>(a);
 }
 
 #include "mm_tiles.h"
@@ -1206,6 +1247,8 @@ static void launch_timed(Kernel kernel, dim3 grid, dim3 block, hipStream_t st, h
 
 // span kernel over the whole 4 KiB groups + bounds-checked edge kernel over the ragged end:
 // `start` goes to whichever runs first, `stop` to whichever runs last
+static MmTileArgs tile_args(const MmGeom &g, const mmh_plan_desc &pl);
+
 static thread_local uint64_t g_filter_block_cap = 0;     // launch_filter's block_cap for the launch under way (0 = none)
 
 template <class Span, class Edge>
@@ -1254,7 +1297,7 @@ void launch_filter(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, con
 {
    g_filter_block_cap = block_cap;
    MmFilterArgs a;
-   a.g = g; a.plan = pl; a.iA = fc.iA; a.ncond = fc.ncond;
+   a.t = tile_args(g, pl); a.iA = fc.iA; a.ncond = fc.ncond;
    a.verify = filter_verifies(pl, fc) ? 1u : 0u;
    for (int k = 0; k < 4; k++) {
       a.pat[k] = fc.pat[k];

@@ -51,16 +51,6 @@ constexpr int MM_HARD_CAP = 32;               // hard candidates handled per sca
 constexpr int MM_HARD_MAX_TILES = 8192;       // longest prefix (in tiles) mm_hard_resolve maps
 constexpr int MM_JUMP_MATCH = 0x80;           // flag in a stored jump: the compare loop reported a match here
 
-// wave-uniform constants shared by the tile kernels (kernel arguments -> SGPRs)
-struct MmTileArgs {
-   MmGeom g;
-   mmh_plan_desc plan;
-   uint32_t inv_d;          // ceil(65536 / D): x / D == (x * inv_d) >> 16 for x < 2100
-   uint32_t inv_d32;        // floor(2^32 / D) + 1: quotient estimate for 32-bit x, at most one too big
-   uint32_t block_shift;    // log2(block_bytes) when that is a power of two, else ~0
-   uint64_t skip_bloom;     // bit (d & 63) set for every listed bad-character diff
-};
-
 struct MmPlanLds {
    int32_t expected[MMH_MAX_KEYWORD];
    uint32_t cmp_mask[MMH_MAX_KEYWORD];

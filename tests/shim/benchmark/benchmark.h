@@ -53,7 +53,10 @@ inline Benchmark *Register(const char *name, void (*fn)(State &)) { all().push_b
 inline int RunAll() {
    std::printf("%-52s %14s %12s %14s\n", "Benchmark", "Time", "Iterations", "bytes_per_second");
    for (Benchmark *b : all()) {
-      for (int64_t r = b->lo; r <= b->hi; r *= b->mult) {
+      std::vector<int64_t> sizes;                     // lo, lo*mult, ... and the upper end itself, as google-benchmark's Range
+      for (int64_t r = b->lo; r < b->hi && b->mult > 1; r *= b->mult) sizes.push_back(r);
+      sizes.push_back(b->hi);
+      for (int64_t r : sizes) {
          int64_t iters = 1;
          for (;;) {                               // grow the iteration count until a run lasts long enough to time
             State st(r, iters);
@@ -65,7 +68,6 @@ inline int RunAll() {
             }
             iters = st.seconds() > 0.005 ? (int64_t)(iters * 0.3 / st.seconds()) + 1 : iters * 10;
          }
-         if (b->mult <= 1) break;
       }
    }
    return 0;
