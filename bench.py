@@ -319,6 +319,7 @@ def main():
         ctr = eng.counters()
         assert (np.diff(offs.astype(np.int64)) > 0).all(), "gathered offsets are not ascending"
         filt = float(np.mean(filt_ms))
+        assert filt > 0, "the library reported no streaming-phase timing"
         achieved = shard / (filt * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(mm.LIB_PATH, shard)
         res = {

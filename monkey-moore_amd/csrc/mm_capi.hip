@@ -9,10 +9,13 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -77,9 +80,10 @@ int ensure_workspace(mmh_ctx *c, MmWorkspace &w, uint64_t out_cap)
       HIP_TRY(hipMalloc(&w.d_hard_slot, mm::hard_cap() * sizeof(uint32_t)));
       HIP_TRY(hipMalloc(&w.d_scratch, mm::hard_scratch_bytes()));
       HIP_TRY(hipMalloc(&w.d_partials, mm::rank_partials_bytes(kMaxRankSort)));
-      HIP_TRY(hipHostMalloc(&w.h_result, (kHeaderWords + kMaxRankSort) * sizeof(uint64_t), hipHostMallocDefault));
+      HIP_TRY(hipHostMalloc(&w.h_result, MM_RESULT_BLOCK_WORDS * sizeof(uint64_t), hipHostMallocDefault));
+      std::memset(w.h_result, 0, MM_RESULT_BLOCK_WORDS * sizeof(uint64_t));
       for (auto &d : w.d_result) {
-         HIP_TRY(hipMalloc(&d, (kHeaderWords + kMaxRankSort) * sizeof(uint64_t)));
+         HIP_TRY(hipMalloc(&d, MM_RESULT_BLOCK_WORDS * sizeof(uint64_t)));
       }
       w.ctrl_clean = false;
    }
@@ -381,9 +385,23 @@ struct Outcome {
 
 // enqueue [zero counters] -> engine kernels -> ordering into pinned host memory; `ev` = the
 // scan's event triple {start, behind the streaming kernel, end}
+// One fused scan kernel at a time per process: its grid barrier needs all of its workgroups
+// resident, and two such grids in flight could keep each other's stragglers out (mm_fused.h).
+// A scan that finds the lock taken simply runs the plain kernels.
+std::mutex g_fused_lock;
+
+bool fused_enabled()
+{
+   static const bool on = [] {
+      const char *v = getenv("MMOORE_FUSED");
+      return !(v && *v == '0');
+   }();
+   return on;
+}
+
 int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev, const MmGeom &g, const mmh_plan_desc &pl,
                      const mm::FilterChoice &fc, bool sequential, uint64_t base_offset, uint32_t max_candidates,
-                     const uint32_t *skip_bits = nullptr)
+                     const uint32_t *skip_bits = nullptr, bool allow_fused = false)
 {
    mm::ResolveBuffers rb;
    rb.cand = w.d_cand; rb.cand_cap = w.cand_cap; rb.out = w.d_out; rb.out_cap = w.out_cap; rb.ctrl = w.d_ctrl;
@@ -398,6 +416,22 @@ int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev,
       HIP_TRY(hipMemsetAsync(w.d_ctrl, 0, mm::ctrl_bytes(), st));
    }
    w.ctrl_clean = false;
+   w.fused = false;
+   if (allow_fused && !sequential && !skip_bits && c->fused_ok && fused_enabled() && g_fused_lock.try_lock()) {
+      // the whole first phase in one launch; its end is announced in pinned memory (finish_pipeline polls)
+      w.seq++;
+      if (mm::launch_fused(st, g, pl, fc, rb, base_offset, max_candidates, w.h_result, w.d_result[w.result_turn], kMaxRankSort,
+                           w.seq, ev[0], ev[2])) {
+         if (!hip_ok(hipGetLastError(), "launching the fused scan kernel")) {
+            g_fused_lock.unlock();
+            return MMH_E_DEVICE;
+         }
+         w.fused = true;
+         return MMH_OK;
+      }
+      g_fused_lock.unlock();
+      c->fused_ok = false;                      // the occupancy query failed: plain kernels from now on
+   }
    // The scan's three events ride on kernel dispatches (hipExtLaunchKernelGGL) where they can:
    // a hipEventRecord between dependent kernels costs ~6 us of stream time on this stack.
    if (!sequential) {
@@ -437,13 +471,113 @@ void read_outcome(const MmWorkspace &w, bool sequential, Outcome *oc)
 // (rare: low-entropy neighbourhoods, degenerate keywords) the second phase runs here:
 // mm_resolve2 -> mm_hard_resolve -> the ordering again.  Launching those two kernels with every
 // scan cost ~10 us of launch latency for nothing in the usual case.
-int finish_pipeline(MmWorkspace &w, hipStream_t st, hipEvent_t *ev, const MmGeom &g, const mmh_plan_desc &pl,
+// A fused scan announces its end by raising its sequence number in pinned memory: the host spins
+// on that word (no event, no interrupt: the results are a PCIe write away) and only falls back to
+// the kernel's completion event should the word never change.
+int wait_fused(MmWorkspace &w, hipEvent_t done)
+{
+   volatile uint64_t *flag = w.h_result + MM_HDR_FLAG_WORD;
+   const auto t0 = std::chrono::steady_clock::now();
+   for (uint64_t spins = 1;; spins++) {
+      if (*flag == w.seq) {
+         break;
+      }
+      __builtin_ia32_pause();
+      if ((spins & 0xFFFF) == 0) {
+         const hipError_t q = hipEventQuery(done);
+         if (q == hipSuccess) {
+            if (*flag == w.seq) {
+               break;
+            }
+            mmh_set_error("fused scan kernel ended without publishing its results");
+            return MMH_E_DEVICE;
+         }
+         if (q != hipErrorNotReady) {
+            mmh_set_error("fused scan kernel: %s", hipGetErrorString(q));
+            return MMH_E_DEVICE;
+         }
+         if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
+            mmh_set_error("fused scan kernel: no result after 60 s");
+            return MMH_E_DEVICE;
+         }
+      }
+   }
+   std::atomic_thread_fence(std::memory_order_acquire);
+   return MMH_OK;
+}
+
+int finish_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev, const MmGeom &g, const mmh_plan_desc &pl,
                     uint64_t base_offset, uint32_t max_candidates, bool sequential, Outcome *oc)
 {
-   // waiting on the scan's last event returns ~6 us sooner than hipStreamSynchronize on this
-   // stack (measured: 12 vs 18-20 us between the end of the device work and the caller)
-   HIP_TRY(hipEventSynchronize(ev[2]));
-   read_outcome(w, sequential, oc);
+   if (w.fused) {
+      w.fused = false;
+      const int rc = wait_fused(w, ev[2]);
+      g_fused_lock.unlock();
+      if (rc != MMH_OK) {
+         return rc;
+      }
+      const uint64_t flags = w.h_result[4];
+      w.fused_filter_ms = (float)((double)(flags >> 8) * 1e-5);          // 100 MHz ticks -> ms
+      static const bool trace = getenv("MMOORE_FUSED_TRACE") != nullptr;
+      if (trace) {
+         const uint64_t st = w.h_result[1];
+         fprintf(stderr, "fused scan: streaming %.2f us; after the last arrival: wg0 past the barrier %.2f us, wg0 done %.2f us, header %.2f us; %llu candidates\n",
+                 (double)(flags >> 8) * 1e-2, (double)(st & 0xFFFFF) * 1e-2, (double)((st >> 20) & 0xFFFFF) * 1e-2,
+                 (double)((st >> 40) & 0xFFFFF) * 1e-2, (unsigned long long)w.h_result[0]);
+      }
+      if (flags & 2) {
+         // a grid barrier timed out (the GPU is shared with something that kept workgroups out):
+         // correct results come from the plain kernels below; do not try again on this context
+         c->fused_ok = false;
+      }
+      if (flags & 1) {
+         // one slot per candidate, in offset order; ~0 = a candidate the reference does not report
+         oc->candidates = w.h_result[0];
+         oc->listed = oc->candidates;
+         oc->tiles = w.h_result[2];
+         oc->hard = 0;
+         oc->hard_overflow = (w.h_result[5] & 0xFFFFFFFFu) > mm::mid_cap();
+         oc->sorted_on_device = true;
+         oc->matches = w.h_result[6] - 1;
+         if ((w.h_result[5] & 0xFFFFFFFFu) == 0) {
+            if (oc->matches != oc->candidates) {
+               uint64_t *slots = w.h_result + kHeaderWords;
+               uint64_t kept = 0;
+               for (uint64_t i = 0; i < oc->candidates; i++) {
+                  if (slots[i] != ~0ull) {
+                     slots[kept++] = slots[i];
+                  }
+               }
+            }
+            w.ctrl_clean = true;                  // the kernel's last workgroup re-zeroed the control block
+            return MMH_OK;
+         }
+         // left-overs: the second phase below orders the slots again with the rank kernels
+      }
+      else {
+         // too many candidates for the in-kernel ranking, or the kernel gave up: the plain
+         // kernels take over on the candidate lists it left (control block kept)
+         mm::ResolveBuffers rb;
+         rb.cand = w.d_cand; rb.cand_cap = w.cand_cap; rb.out = w.d_out; rb.out_cap = w.out_cap; rb.ctrl = w.d_ctrl;
+         rb.mid_off = w.d_mid_off; rb.mid_hi = w.d_mid_hi; rb.mid_set = w.d_mid_set; rb.mid_slot = w.d_mid_slot;
+         rb.hard_off = w.d_hard_off; rb.hard_hi = w.d_hard_hi; rb.hard_set = w.d_hard_set; rb.hard_slot = w.d_hard_slot;
+         rb.scratch = w.d_scratch;
+         w.h_result[6] = 0;
+         mm::launch_resolve(st, g, pl, rb, base_offset, max_candidates);
+         mm::launch_rank_sort(st, w.d_out, w.d_ctrl, 0, w.out_cap, kMaxRankSort, w.d_partials, w.h_result, w.d_result[w.result_turn],
+                              nullptr, true);
+         HIP_TRY(hipGetLastError());
+         HIP_TRY(hipEventRecord(ev[2], st));
+         HIP_TRY(hipEventSynchronize(ev[2]));
+         read_outcome(w, sequential, oc);
+      }
+   }
+   else {
+      // waiting on the scan's last event returns ~6 us sooner than hipStreamSynchronize on this
+      // stack (measured: 12 vs 18-20 us between the end of the device work and the caller)
+      HIP_TRY(hipEventSynchronize(ev[2]));
+      read_outcome(w, sequential, oc);
+   }
    const uint64_t leftovers = sequential ? 0 : (w.h_result[5] & 0xFFFFFFFFu);
    if (leftovers == 0) {
       w.ctrl_clean = true;                      // mm_rank_scatter's last block re-zeroed the control block
@@ -474,11 +608,21 @@ int run_pipeline(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, const mm:
 {
    begin_scan_events(c, !sequential);
    c->scans_recorded++;
-   int rc = enqueue_pipeline(c, c->ws[0], c->stream, c->ev, g, pl, fc, sequential, base_offset, max_candidates, skip_bits);
+   const int slot = (int)((c->scans_recorded - 1) % mmh_ctx::kRing);
+   c->ring_filter_ms[slot] = 0;
+   int rc = enqueue_pipeline(c, c->ws[0], c->stream, c->ev, g, pl, fc, sequential, base_offset, max_candidates, skip_bits, true);
    if (rc != MMH_OK) {
       return rc;
    }
-   return finish_pipeline(c->ws[0], c->stream, c->ev, g, pl, base_offset, max_candidates, sequential, oc);
+   const bool fused = c->ws[0].fused;
+   if (fused) {
+      c->ring_has_filter[slot] = false;            // one launch: no event marks the end of its streaming phase
+   }
+   rc = finish_pipeline(c, c->ws[0], c->stream, c->ev, g, pl, base_offset, max_candidates, sequential, oc);
+   if (fused) {
+      c->ring_filter_ms[slot] = c->ws[0].fused_filter_ms;
+   }
+   return rc;
 }
 
 int grow(uint64_t **buf, uint64_t *cap, uint64_t need)
@@ -1125,7 +1269,7 @@ extern "C" int mmh_scan_collect(mmh_ctx *c, int ticket, uint64_t *out, uint64_t 
    MmWorkspace &w = c->ws[1 + (ticket & 1)];
    if (!rescan) {
       const MmGeom g = scan_geometry(c, &p.plan, p.block_bytes, p.big_endian);
-      int rc = finish_pipeline(w, c->lane_stream[ticket & 1], p.ev, g, p.plan, p.base_offset, p.max_candidates, false, &oc);
+      int rc = finish_pipeline(c, w, c->lane_stream[ticket & 1], p.ev, g, p.plan, p.base_offset, p.max_candidates, false, &oc);
       if (rc != MMH_OK) {
          p.active = false;
          return rc;
@@ -1182,6 +1326,9 @@ void scan_timings(mmh_ctx *c, uint64_t k, float *ms4)
       }
       if (c->ring_has_filter[slot] && hipEventElapsedTime(&ms4[0], e[0], e[1]) != hipSuccess) {
          ms4[0] = 0;
+      }
+      if (!c->ring_has_filter[slot]) {
+         ms4[0] = c->ring_filter_ms[slot];        // fused scan: the kernel's own stamps
       }
    }
    ms4[1] = ms4[3] - ms4[0];                    // everything behind the streaming kernel

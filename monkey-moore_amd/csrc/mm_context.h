@@ -10,14 +10,6 @@
 
 #include "mmoore_hip.h"
 
-// layout of the block a scan publishes (pinned host memory and its device-side copies):
-// MM_RESULT_HEADER_WORDS counters, then the ordered matches.  Header words: [0] candidates (= result
-// slots of the filter + resolver path), [1] matches appended by the sequential engine, [2] windows
-// mapped, [3] hard candidates / overflow flag, [5] left-overs, [6] matches + 1 (0: not ordered on the
-// device), [7] which of words 0 / 1 is the list length.
-constexpr uint64_t MM_RESULT_HEADER_WORDS = 8;
-constexpr uint32_t MM_MAX_RANK_SORT = 16384;      // longest list the device orders (and a gather record holds)
-
 // pinned staging of mmh_rom_load_file (mm_ingest.hip): two pieces per reader thread
 struct MmIngest {
    static constexpr size_t kPiece = 4u << 20;
@@ -54,6 +46,9 @@ struct MmWorkspace {
    // while scan k+1 publishes (the gather overlaps the next scan).
    uint64_t *d_result[2] = {nullptr, nullptr};
    int result_turn = 0;             // d_result[result_turn] belongs to the most recent scan
+   uint64_t seq = 0;                // fused scans: the number the kernel raises in h_result[MM_HDR_FLAG_WORD]
+   bool fused = false;              // the scan under way is one mm_scan_fused launch (and holds the process-wide fused lock)
+   float fused_filter_ms = 0;       // its streaming phase, from the kernel's own wall-clock stamps
    bool ctrl_clean = false;         // the previous scan's last kernel left d_ctrl zeroed
 };
 
@@ -132,6 +127,7 @@ struct mmh_ctx {
    // a slot may instead hold finished numbers: scans of the submit lanes use their own events (a
    // ring slot could be re-recorded by 64 later scans before the lane is collected) and copy
    // their timings in here when they are collected
+   float ring_filter_ms[kRing] = {};   // streaming phase of a fused scan (no event marks it inside the one launch)
    bool ring_is_ms[kRing] = {};
    float ring_ms[kRing][2] = {};    // {streaming kernel, whole scan}
    uint64_t scans_recorded = 0;     // slot of scan k is k % kRing
@@ -142,6 +138,7 @@ struct mmh_ctx {
    MmPending pending[2];
    int next_ticket = 0;
    int engine = 0;
+   bool fused_ok = true;            // cleared for good when a fused scan's grid barrier ever timed out on this context
    uint64_t counters[4] = {0, 0, 0, 0};
    MmIngest ingest;
    MmComm mg;

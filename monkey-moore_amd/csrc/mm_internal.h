@@ -35,6 +35,18 @@ struct MmGeom {
    uint32_t whole;         // 1 = whole-buffer mode (results are element indices)
 };
 
+// layout of the block a scan publishes (pinned host memory and its device-side copies):
+// MM_RESULT_HEADER_WORDS counters, then the ordered matches.  Header words: [0] candidates (= result
+// slots of the filter + resolver path), [1] matches appended by the sequential engine, [2] windows
+// mapped, [3] hard candidates / overflow flag, [5] left-overs, [6] matches + 1 (0: not ordered on the
+// device), [7] which of words 0 / 1 is the list length.
+constexpr uint64_t MM_RESULT_HEADER_WORDS = 8;
+constexpr uint32_t MM_MAX_RANK_SORT = 16384;      // longest list the device orders (and a gather record holds)
+// the pinned block has a few more words behind the slots: the fused scan kernel raises the scan's
+// sequence number in the first of them when everything is published (the host polls it)
+constexpr uint64_t MM_HDR_FLAG_WORD = MM_RESULT_HEADER_WORDS + MM_MAX_RANK_SORT;
+constexpr uint64_t MM_RESULT_BLOCK_WORDS = MM_HDR_FLAG_WORD + 8;
+
 // ---- per-scan control block (device memory, zeroed before every scan), in u64 words --
 //
 // Returning atomics on ONE address serialise at ~20 ns each on MI355X even when they are
@@ -48,12 +60,25 @@ enum {
    MM_CTRL_HARD = 3,         // lo 32: hard candidates, hi 32: "prefix too long" flag
    MM_CTRL_TICKET = 4,       // arrival ticket of mm_rank_scatter's blocks (the last one re-zeroes the block)
    MM_CTRL_NOMATCH = 6,      // keys of the ordered list that are "not a match" slots (counted by mm_rank_scatter's blocks)
+   MM_CTRL_DECISION = 25,    // mm_scan_fused: outcome of its grid barrier (1 everybody arrived, 2 timed out: nothing is resolved)
+   MM_CTRL_T_START = 26,     //   ... wall clock at the kernel's start / when the last workgroup left the streaming phase
+   MM_CTRL_T_BARRIER = 27,
+   MM_CTRL_T_STAMPS = 28,    //   ... two more stamps of workgroup 0 (tuning aid)
    MM_CTRL_TILES = 8,        // MM_STAT_STRIPES striped counters of tiles walked
    MM_STAT_STRIPES = 16,
    MM_CTRL_LISTS = 32,       // MM_CAND_LISTS list counters, MM_LIST_STRIDE words apart
    MM_CAND_LISTS = 64,
    MM_LIST_STRIDE = 16,
-   MM_CTRL_DONE = MM_CTRL_LISTS + MM_CAND_LISTS * MM_LIST_STRIDE   // unsigned int tickets of mm_hard_resolve
+   MM_CTRL_DONE = MM_CTRL_LISTS + MM_CAND_LISTS * MM_LIST_STRIDE,  // unsigned int tickets of mm_hard_resolve (32 of them: 16 words)
+   // mm_scan_fused's arrival counters and release flags, one 128-byte line each.  A returning atomic on
+   // one address costs ~20 ns, so 1024 workgroups arriving at ONE counter would take 20 us: they arrive
+   // in groups of MM_ARRIVE_FAN at a line of their own, the last of a group at the root.
+   MM_ARRIVE_FAN = 32,
+   MM_ARRIVE_LINES = 1 + 64,                                       // root + up to 64 groups (2048 workgroups)
+   MM_CTRL_ARRIVE_BARRIER = MM_CTRL_DONE + 32,                     // (keeps the lines 128-byte aligned: 1088 = 68 * 16)
+   MM_CTRL_ARRIVE_END = MM_CTRL_ARRIVE_BARRIER + MM_ARRIVE_LINES * MM_LIST_STRIDE,
+   MM_CTRL_RELEASE = MM_CTRL_ARRIVE_END + MM_ARRIVE_LINES * MM_LIST_STRIDE,   // MM_CAND_LISTS release flags the waiting workgroups poll
+   MM_CTRL_WORDS = MM_CTRL_RELEASE + MM_CAND_LISTS * MM_LIST_STRIDE
 };
 
 #if defined(__HIPCC__) || defined(__cplusplus)

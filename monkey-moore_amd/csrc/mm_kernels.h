@@ -67,6 +67,12 @@ struct ResolveBuffers {
 // holds a candidate its two windows cannot settle (one bit per domain, zeroed by the caller)
 void launch_resolve(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const ResolveBuffers &rb,
                     uint64_t base_offset, uint32_t max_candidates, uint32_t *flag_bits = nullptr);
+// The whole first phase of a scan in ONE launch (mm_fused.h): streaming filter, grid barrier, every
+// candidate resolved and ranked, results + header published to host_result (pinned) and dev_result,
+// then `seq` raised in host_result[MM_HDR_FLAG_WORD].  false: not possible on this device (no launch).
+bool launch_fused(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc, const ResolveBuffers &rb,
+                  uint64_t base_offset, uint32_t max_candidates, uint64_t *host_result, uint64_t *dev_result, uint32_t max_rank,
+                  uint64_t seq, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 // the scan's second phase (only when mm_resolve left candidates over): mm_resolve2 + mm_hard_resolve
 void launch_leftovers(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const ResolveBuffers &rb, uint64_t base_offset);
 size_t hard_scratch_bytes();
@@ -79,6 +85,8 @@ struct DenseGeom {
    uint64_t ndom;
    uint32_t tpd;
    uint32_t nsup;
+   uint32_t bpd;             // single-pass engine (mm_forward.h): batches per domain
+   size_t status_bytes;      //   ... its ticket + look-back words, at the start of `maps`
    size_t maps_bytes, supmaps_bytes, supentry_bytes, entry_bytes;
 };
 struct DenseBuffers {

@@ -131,6 +131,9 @@ __device__ __forceinline__ bool mm_locate(const MmGeom &g, uint64_t o, uint64_t 
       *b = 0; *p = 0; *j = (int64_t)(o / g.S);
    }
    else {
+      if (o >= g.nbytes) {
+         return false;                          // a SWAR survivor in the padding behind the ROM: block o / B does not exist
+      }
       uint64_t blk = o / g.block_bytes;
       uint64_t r = o - blk * g.block_bytes;
       *b = blk; *p = (uint32_t)(r % g.S); *j = (int64_t)(r / g.S);
@@ -143,6 +146,14 @@ __device__ __forceinline__ uint64_t mm_uniform64_k(uint64_t v)
 {
    return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) |
           ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32);
+}
+
+// A word another workgroup of the SAME launch reads (the fused scan kernel resolves candidates in
+// the launch that found them): stored write-through (sc1), cdna guideline 16 R1.  Candidates are
+// a few thousand stores per scan, so the plain kernels use it as well.
+__device__ __forceinline__ void mm_store_shared(uint64_t *p, uint64_t v)
+{
+   __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // wave-aggregated append (ballot + prefix popcount -> one atomic per wave)
@@ -162,7 +173,7 @@ __device__ __forceinline__ void mm_append(uint64_t *list, unsigned long long *co
    if (want) {
       unsigned long long slot = base + __popcll(mask & ((1ull << lane) - 1));
       if (slot < cap) {
-         list[slot] = value;
+         mm_store_shared(list + slot, value);
       }
    }
 }
@@ -429,7 +440,7 @@ __device__ __forceinline__ void mm_f8_survivors(const A &a, uint64_t chunk0, uin
          const int bit = __ffs((int)bits) - 1;
          bits &= bits - 1;
          if (slot < room) {
-            list[slot] = chunk0 + 4 * (bit & 3) + (bit >> 3) - a.iA;
+            mm_store_shared(list + slot, chunk0 + 4 * (bit & 3) + (bit >> 3) - a.iA);
          }
          slot++;
       }
@@ -690,7 +701,7 @@ __device__ __forceinline__ void mm_f16_survivors(const A &a, uint64_t chunk0, ui
          bits &= bits - 1;
          const int j = bit >> 2, odd = (bit >> 1) & 1, half = bit & 1;
          if (slot < room) {
-            list[slot] = chunk0 + 4 * j + 2 * half - odd - 2 * (uint64_t)a.iA;
+            mm_store_shared(list + slot, chunk0 + 4 * j + 2 * half - odd - 2 * (uint64_t)a.iA);
          }
          slot++;
       }
@@ -846,6 +857,8 @@ __global__ __launch_bounds__(256) void mm_filter_u16(MmFilterArgs a)
 
 #include "mm_tiles.h"
 #include "mm_dense.h"
+#include "mm_forward.h"
+#include "mm_fused.h"
 
 // --------------------------------------------------------------------------
 // sequential engine: one lane per domain, exact by construction
@@ -973,6 +986,9 @@ __global__ __launch_bounds__(256) void mm_rank_scatter(const uint64_t *in, unsig
       }
       if (threadIdx.x == 5) {
          v = ctrl[MM_CTRL_MID];                            // word 2 of the header carries the tile count
+      }
+      if (threadIdx.x == 4) {
+         v = 0;                                            // flags (mm_fused.h MM_HDR_*): a dense list
       }
       if (threadIdx.x == 7) {
          v = (unsigned long long)count_index;              // which header word holds the list length
@@ -1117,6 +1133,16 @@ const Tuning &tuning()
       return k;
    }();
    return t;
+}
+
+// MMOORE_DENSE_V1=1: the round-1 two-pass forward engine (mm_dense.h) instead of mm_forward.h (A/B runs, cross-checks)
+static bool forward_v1()
+{
+   static const bool on = [] {
+      const char *v = getenv("MMOORE_DENSE_V1");
+      return v && *v == '1';
+   }();
+   return on;
 }
 
 // Picks the SWAR conditions of a plan: an anchor position iA (condition 0) and up to three
@@ -1271,24 +1297,71 @@ static void launch_filter_pair(Span span, Edge edge, hipStream_t st, const MmFil
    }
 }
 
-template <int SHAPE>
-static void launch_filter_u8(hipStream_t st, const MmFilterArgs &a, const MmGeom &g, hipEvent_t start, hipEvent_t stop)
+// Calls f(integral_constant<ELEM>, integral_constant<SHAPE>) for the kernel shape a plan's filter
+// choice selects: the contiguous 8-bit shapes 1..4 (compile-time shifts), the run-time-shift
+// 8-bit shapes (one per number of conditions and gap mask), the five 16-bit shapes.
+template <int V> using mm_int = std::integral_constant<int, V>;
+
+template <int NC, class F, int... M2>
+static bool with_shape_u8_masks(uint32_t mask2, std::integer_sequence<int, M2...>, F &f)
 {
-   launch_filter_pair(mm_filter_u8<SHAPE>, mm_filter_u8_edge<SHAPE>, st, a, g, start, stop);
+   return ((mask2 == (uint32_t)M2 ? (f(mm_int<1>(), mm_int<NC | (M2 << 4) | 0x100>()), true) : false) || ...);
 }
 
-template <int SHAPE>
-static void launch_filter_u16(hipStream_t st, const MmFilterArgs &a, const MmGeom &g, hipEvent_t start, hipEvent_t stop)
+template <class F>
+static void with_shape(uint32_t elem_bytes, const FilterChoice &fc, F &&f)
 {
-   launch_filter_pair(mm_filter_u16<SHAPE>, mm_filter_u16_edge<SHAPE>, st, a, g, start, stop);
+   const uint32_t shape = fc.shape;
+   if (elem_bytes == 1) {
+      const uint32_t mask2 = MM_F8_MASK2(shape);
+      if (!MM_F8_RT(shape)) {
+         switch (fc.ncond) {
+         case 4: f(mm_int<1>(), mm_int<4>()); break;
+         case 3: f(mm_int<1>(), mm_int<3>()); break;
+         case 2: f(mm_int<1>(), mm_int<2>()); break;
+         default: f(mm_int<1>(), mm_int<1>()); break;
+         }
+      }
+      else {
+         switch (fc.ncond) {
+         case 4: with_shape_u8_masks<4>(mask2, std::make_integer_sequence<int, 16>(), f); break;
+         case 3: with_shape_u8_masks<3>(mask2, std::make_integer_sequence<int, 8>(), f); break;
+         case 2: with_shape_u8_masks<2>(mask2, std::make_integer_sequence<int, 4>(), f); break;
+         default: with_shape_u8_masks<1>(mask2, std::make_integer_sequence<int, 2>(), f); break;
+         }
+      }
+   }
+   else {
+      switch (shape) {
+      case 1 | 16: f(mm_int<2>(), mm_int<1 | 16>()); break;
+      case 2: f(mm_int<2>(), mm_int<2>()); break;
+      case 2 | 32: f(mm_int<2>(), mm_int<2 | 32>()); break;
+      case 2 | 16 | 64: f(mm_int<2>(), mm_int<2 | 16 | 64>()); break;
+      default:
+         // shape 1; (a gap-2 anchor with an adjacent second condition cannot occur: position iA-1 would be a wildcard)
+         f(mm_int<2>(), mm_int<1>());
+         break;
+      }
+   }
 }
 
-// run-time-shift shapes of NC conditions: one instantiation per gap mask
-template <int NC, int... M2>
-static bool launch_filter_u8_masks(uint32_t mask2, std::integer_sequence<int, M2...>, hipStream_t st, const MmFilterArgs &a,
-                                   const MmGeom &g, hipEvent_t start, hipEvent_t stop)
+// the streaming code's arguments, common to the plain and the fused kernels
+template <class A>
+static void fill_filter_args(A &a, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc, uint64_t *cand,
+                             unsigned long long *ctrl, uint64_t cand_cap, uint32_t groups_per_span)
 {
-   return ((mask2 == (uint32_t)M2 ? (launch_filter_u8<NC | (M2 << 4) | 0x100>(st, a, g, start, stop), true) : false) || ...);
+   a.t = tile_args(g, pl); a.iA = fc.iA; a.ncond = fc.ncond;
+   a.verify = filter_verifies(pl, fc) ? 1u : 0u;
+   for (int k = 0; k < 4; k++) {
+      a.pat[k] = fc.pat[k];
+      a.sh[k] = 32u - 8u * fc.shift[k];
+   }
+   a.cand = cand; a.list_count = ctrl + MM_CTRL_LISTS; a.list_cap = cand_cap / MM_CAND_LISTS;
+   a.dom_count = nullptr; a.skip_bits = nullptr;
+   // whole 4 KiB groups go to the span code, the ragged end to the bounds-checked one
+   a.ngroups = g.nbytes / 4096;
+   a.groups_per_span = groups_per_span;
+   a.edge_first = a.ngroups * 256;
 }
 
 void launch_filter(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc,
@@ -1297,51 +1370,73 @@ void launch_filter(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, con
 {
    g_filter_block_cap = block_cap;
    MmFilterArgs a;
-   a.t = tile_args(g, pl); a.iA = fc.iA; a.ncond = fc.ncond;
-   a.verify = filter_verifies(pl, fc) ? 1u : 0u;
-   for (int k = 0; k < 4; k++) {
-      a.pat[k] = fc.pat[k];
-      a.sh[k] = 32u - 8u * fc.shift[k];
-   }
-   a.cand = cand; a.list_count = ctrl + MM_CTRL_LISTS; a.list_cap = cand_cap / MM_CAND_LISTS;
+   fill_filter_args(a, g, pl, fc, cand, ctrl, cand_cap, block_cap ? tuning().filter_gps_comm : filter_groups_per_span());
    a.dom_count = dom_count; a.skip_bits = skip_bits;
-   // whole 4 KiB groups go to the span kernel, the ragged end to the bounds-checked one
-   a.ngroups = g.nbytes / 4096;
-   a.groups_per_span = block_cap ? tuning().filter_gps_comm : filter_groups_per_span();
-   a.edge_first = a.ngroups * 256;
-   const uint32_t shape = fc.shape;
-   if (pl.elem_bytes == 1) {
-      const uint32_t mask2 = MM_F8_MASK2(shape);
-      if (!MM_F8_RT(shape)) {
-         switch (fc.ncond) {
-         case 4: launch_filter_u8<4>(st, a, g, start, stop); break;
-         case 3: launch_filter_u8<3>(st, a, g, start, stop); break;
-         case 2: launch_filter_u8<2>(st, a, g, start, stop); break;
-         default: launch_filter_u8<1>(st, a, g, start, stop); break;
-         }
+   with_shape(pl.elem_bytes, fc, [&](auto elem, auto shape) {
+      constexpr int SHAPE = decltype(shape)::value;
+      if constexpr (decltype(elem)::value == 1) {
+         launch_filter_pair(mm_filter_u8<SHAPE>, mm_filter_u8_edge<SHAPE>, st, a, g, start, stop);
       }
       else {
-         switch (fc.ncond) {
-         case 4: launch_filter_u8_masks<4>(mask2, std::make_integer_sequence<int, 16>(), st, a, g, start, stop); break;
-         case 3: launch_filter_u8_masks<3>(mask2, std::make_integer_sequence<int, 8>(), st, a, g, start, stop); break;
-         case 2: launch_filter_u8_masks<2>(mask2, std::make_integer_sequence<int, 4>(), st, a, g, start, stop); break;
-         default: launch_filter_u8_masks<1>(mask2, std::make_integer_sequence<int, 2>(), st, a, g, start, stop); break;
-         }
+         launch_filter_pair(mm_filter_u16<SHAPE>, mm_filter_u16_edge<SHAPE>, st, a, g, start, stop);
       }
-   }
-   else {
-      switch (shape) {
-      case 1: launch_filter_u16<1>(st, a, g, start, stop); break;
-      case 1 | 16: launch_filter_u16<1 | 16>(st, a, g, start, stop); break;
-      case 2: launch_filter_u16<2>(st, a, g, start, stop); break;
-      case 2 | 32: launch_filter_u16<2 | 32>(st, a, g, start, stop); break;
-      case 2 | 16 | 64: launch_filter_u16<2 | 16 | 64>(st, a, g, start, stop); break;
-      default:
-         // (gap-2 anchor with an adjacent second condition cannot occur: position iA-1 would be a wildcard)
-         launch_filter_u16<1>(st, a, g, start, stop);
-         break;
+   });
+}
+
+// ---- the fused scan kernel (mm_fused.h) ---------------------------------------------------------
+
+// Workgroups of mm_scan_fused that are resident at once on this device, for sure: the grid barrier
+// needs all of them.  The occupancy API can be one block per CU high at this kernel's SGPR count
+// (MI355X_MICROARCH.md, correctness boundaries), so one is taken off, and never more than 5 per CU
+// (16 waves per CU already stream at the full read bandwidth: 1024 x 8 measured like 2048 x 8;
+// 1280 workgroups = 5120 waves resolve the bench ROM's 4223 candidates in one round).
+static unsigned fused_resident_blocks()
+{
+   static const unsigned blocks = [] {
+      int device = 0, cus = 0, per_cu = 0;
+      if (hipGetDevice(&device) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess ||
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mm_scan_fused<1, 4>, 64 * MM_WAVES, 0) != hipSuccess) {
+         return 0u;
       }
+      per_cu = std::min(5, per_cu - 1);
+      return per_cu > 0 ? (unsigned)(per_cu * cus) : 0u;
+   }();
+   return blocks;
+}
+
+bool launch_fused(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc, const ResolveBuffers &rb,
+                  uint64_t base_offset, uint32_t max_candidates, uint64_t *host_result, uint64_t *dev_result, uint32_t max_rank,
+                  uint64_t seq, hipEvent_t start, hipEvent_t stop)
+{
+   const unsigned resident = fused_resident_blocks();
+   if (resident == 0) {
+      return false;
    }
+   MmFusedArgs a;
+   const uint64_t ngroups = g.nbytes / 4096;
+   // spans of 8 groups for ROMs that take several rounds of the grid; small ROMs are cut finer so
+   // that every resident wave has a span (a 128 KiB ROM: 32 waves of 4 KiB instead of 4 of 32 KiB)
+   uint32_t gps = filter_groups_per_span();
+   while (gps > 1 && ngroups / gps < (uint64_t)resident * MM_WAVES) {
+      gps >>= 1;
+   }
+   fill_filter_args(a, g, pl, fc, rb.cand, rb.ctrl, rb.cand_cap, gps);
+   a.out_cap = rb.out_cap; a.out = rb.out; a.tiles_walked = rb.ctrl + MM_CTRL_TILES;
+   a.base_offset = base_offset; a.max_candidates = max_candidates;
+   a.mid_off = rb.mid_off; a.mid_hi = rb.mid_hi; a.mid_set = rb.mid_set; a.mid_slot = rb.mid_slot;
+   a.mid_count = reinterpret_cast<unsigned int *>(rb.ctrl + MM_CTRL_MID);
+   a.flag_bits = nullptr;
+   a.ctrl = rb.ctrl; a.host_result = host_result; a.dev_result = dev_result; a.max_rank = max_rank;
+   a.ctrl_words = (uint32_t)(ctrl_bytes() / sizeof(unsigned long long));
+   a.seq = seq;
+   a.timeout_ticks = 20000000;                    // 200 ms of the 100 MHz wall clock
+   a.has_edge = a.edge_first * 16 < g.nbytes ? 1u : 0u;
+   const uint64_t spans = (a.ngroups + gps - 1) / gps;
+   const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((spans + MM_WAVES - 1) / MM_WAVES, resident));
+   with_shape(pl.elem_bytes, fc, [&](auto elem, auto shape) {
+      launch_timed(mm_scan_fused<decltype(elem)::value, decltype(shape)::value>, dim3(blocks), dim3(64 * MM_WAVES), st, start, stop, a);
+   });
+   return true;
 }
 
 static MmTileArgs tile_args(const MmGeom &g, const mmh_plan_desc &pl)
@@ -1406,7 +1501,8 @@ void launch_leftovers(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, 
 size_t hard_scratch_bytes() { return (size_t)MM_HARD_CAP * MM_HARD_MAX_TILES * MM_MAXD; }
 size_t hard_cap() { return MM_HARD_CAP; }
 size_t mid_cap() { return MM_MID_CAP; }
-size_t ctrl_bytes() { return MM_CTRL_DONE * sizeof(uint64_t) + MM_HARD_CAP * sizeof(unsigned int); }
+size_t ctrl_bytes() { return MM_CTRL_WORDS * sizeof(uint64_t); }
+static_assert(MM_CTRL_DONE * sizeof(uint64_t) + MM_HARD_CAP * sizeof(unsigned int) <= MM_CTRL_ARRIVE_BARRIER * sizeof(uint64_t), "ctrl layout");
 size_t rank_partials_bytes(uint32_t max_n) { return (size_t)MM_RANK_SLICES * max_n * sizeof(uint32_t); }
 
 DenseGeom dense_geom(const MmGeom &g, uint64_t listed_domains)
@@ -1420,6 +1516,15 @@ DenseGeom dense_geom(const MmGeom &g, uint64_t listed_domains)
    }
    d.tpd = (uint32_t)((most + MM_TILE - 1) / MM_TILE);
    d.nsup = (d.tpd + MM_SUPER - 1) / MM_SUPER;
+   d.bpd = (d.tpd + MM_FWD_BATCH - 1) / MM_FWD_BATCH;
+   if (!forward_v1()) {
+      // single-pass engine: [ticket, pad][one look-back word per batch] then one map per batch, all in `maps`
+      d.status_bytes = (((size_t)d.ndom * d.bpd + 2) * sizeof(unsigned long long) + 255) & ~(size_t)255;
+      d.maps_bytes = d.status_bytes + (size_t)d.ndom * d.bpd * MM_MAXD;
+      d.supmaps_bytes = d.supentry_bytes = d.entry_bytes = 0;
+      return d;
+   }
+   d.status_bytes = 0;
    d.maps_bytes = (size_t)d.ndom * d.tpd * MM_MAXD;
    d.supmaps_bytes = (size_t)d.ndom * d.nsup * MM_MAXD;
    d.supentry_bytes = (size_t)d.ndom * d.nsup;
@@ -1427,9 +1532,51 @@ DenseGeom dense_geom(const MmGeom &g, uint64_t listed_domains)
    return d;
 }
 
+// the single-pass forward engine (mm_forward.h); db.maps holds [ticket + look-back words][batch maps]
+static void launch_forward(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const DenseGeom &dg, const DenseBuffers &db,
+                           uint64_t base_offset, const uint32_t *dom_list)
+{
+   MmForwardArgs a;
+   a.t = tile_args(g, pl);
+   a.ndom = dg.ndom; a.dom_list = dom_list; a.tpd = dg.tpd; a.bpd = dg.bpd;
+   const uint64_t nbatches = dg.ndom * dg.bpd;
+   a.ticket = reinterpret_cast<unsigned long long *>(db.maps);
+   a.status = a.ticket + 2;
+   a.agg = db.maps + dg.status_bytes;
+   a.out = db.out; a.list_count = db.ctrl + MM_CTRL_LISTS; a.list_cap = db.out_cap / MM_CAND_LISTS;
+   a.base_offset = base_offset;
+   // the table-driven jump path: 8-bit elements, first compare against an element 1..4 to the left
+   a.fast = 0; a.i1 = a.g1 = a.has2 = a.i2 = a.g2 = 0;
+   int i1 = (int)pl.L - 1;
+   while (i1 >= 0 && pl.cmp_mask[i1] == 0) {
+      i1--;
+   }
+   if (pl.elem_bytes == 1 && i1 >= 1 && pl.bridge[i1] <= -1 && pl.bridge[i1] >= -4 && i1 + pl.bridge[i1] >= 0 &&
+       !(getenv("MMOORE_FORWARD_SLOW") && *getenv("MMOORE_FORWARD_SLOW") == '1')) {
+      a.fast = 1; a.i1 = (uint32_t)i1; a.g1 = (uint32_t)(-pl.bridge[i1]);
+      int i2 = i1 - 1;
+      while (i2 >= 0 && pl.cmp_mask[i2] == 0) {
+         i2--;
+      }
+      if (i2 >= 1 && pl.bridge[i2] < 0 && i2 + pl.bridge[i2] >= 0) {
+         a.has2 = 1; a.i2 = (uint32_t)i2; a.g2 = (uint32_t)(-pl.bridge[i2]);
+      }
+   }
+   (void)hipMemsetAsync(db.maps, 0, dg.status_bytes, st);
+   int device = 0, cus = 256;
+   (void)hipGetDevice(&device);
+   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+   const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nbatches + MM_WAVES - 1) / MM_WAVES, (uint64_t)cus * 5));
+   hipLaunchKernelGGL(mm_forward, dim3(blocks), dim3(64 * MM_WAVES), 0, st, a);
+}
+
 void launch_dense(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const DenseGeom &dg, const DenseBuffers &db,
                   uint64_t base_offset, const uint32_t *dom_list)
 {
+   if (!forward_v1()) {
+      launch_forward(st, g, pl, dg, db, base_offset, dom_list);
+      return;
+   }
    MmDenseArgs a;
    a.t = tile_args(g, pl);
    a.ndom = dg.ndom; a.tpd = dg.tpd; a.nsup = dg.nsup; a.dom_list = dom_list;

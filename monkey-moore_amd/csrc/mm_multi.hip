@@ -94,7 +94,7 @@ double now_s()
 __global__ void mm_gather_stamp(uint64_t *rec, uint64_t count)
 {
    if (threadIdx.x < MM_RESULT_HEADER_WORDS) {
-      rec[threadIdx.x] = threadIdx.x == 6 ? count + 1 : 0;
+      rec[threadIdx.x] = threadIdx.x == 6 ? count + 1 : (threadIdx.x == 0 ? count : 0);
    }
 }
 
@@ -132,8 +132,37 @@ __global__ __launch_bounds__(256) void mm_gather_pack(const uint64_t *table, uin
    const uint64_t *rec = table + (uint64_t)r * words;
    const unsigned long long n = rec[6] ? rec[6] - 1 : 0;
    uint64_t *dst = merged + kMergedHeader + sh_before;
-   for (unsigned long long i = threadIdx.x; i < n; i += blockDim.x) {
-      dst[i] = rec[MM_RESULT_HEADER_WORDS + i];
+   if ((rec[4] & 1) == 0 || rec[0] == n) {
+      for (unsigned long long i = threadIdx.x; i < n; i += blockDim.x) {
+         dst[i] = rec[MM_RESULT_HEADER_WORDS + i];
+      }
+      return;
+   }
+   // a fused scan's record with holes: one slot per candidate (rec[0] of them), ~0 = not reported.
+   // Ordered compaction, 256 slots at a time.
+   __shared__ unsigned int wave_count[4];
+   unsigned long long kept = 0;                     // block uniform
+   const unsigned long long slots = rec[0];
+   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   for (unsigned long long base = 0; base < slots; base += blockDim.x) {
+      const unsigned long long i = base + threadIdx.x;
+      const uint64_t v = i < slots ? rec[MM_RESULT_HEADER_WORDS + i] : ~0ull;
+      const bool keep = v != ~0ull;
+      const unsigned long long mask = __ballot(keep);
+      if (lane == 0) {
+         wave_count[wave] = (unsigned int)__popcll(mask);
+      }
+      __syncthreads();
+      unsigned int before = 0, all = 0;
+      for (int w = 0; w < 4; w++) {
+         before += w < wave ? wave_count[w] : 0;
+         all += wave_count[w];
+      }
+      if (keep) {
+         dst[kept + before + __popcll(mask & ((1ull << lane) - 1))] = v;
+      }
+      kept += all;
+      __syncthreads();
    }
 }
 

@@ -61,12 +61,18 @@ struct MmPlanLds {
    uint8_t skip8[512];                      // dense bad-character table, 8-bit elements
 };
 
-struct MmWaveLds {
-   uint32_t tile[((MM_TILE + MMH_MAX_KEYWORD + 1) * 2 + 16) / 4];
-   uint8_t jump[MM_TILE];                    // J of every position of the window (| MM_JUMP_MATCH)
-   uint8_t gmap[MM_TILE / 64][MM_MAXD];      // phase map of every group of 64 positions (long windows)
-   uint8_t gentry[MM_TILE / 64];             // mm_dense_emit: the chain's phase on entering each group
+// a wave's working set for windows of up to NPOS positions
+template <int NPOS>
+struct MmWaveLdsT {
+   static constexpr int kPositions = NPOS;
+   uint32_t tile[((NPOS + MMH_MAX_KEYWORD + 1) * 2 + 16) / 4];
+   uint8_t jump[NPOS + 8];                   // J of every position of the window (| MM_JUMP_MATCH); the forward engine
+                                             // stores four at a time and shifts the array by 0..3 bytes for that
+   uint8_t gmap[NPOS / 64][MM_MAXD];         // phase map of every group of 64 positions (long windows)
+   uint8_t gentry[NPOS / 64];                // forward engine: the chain's phase on entering each group
 };
+using MmWaveLds = MmWaveLdsT<MM_TILE>;       // whole tiles: hard resolver, forward engine
+using MmWaveLdsShort = MmWaveLdsT<512>;      // look-back windows of <= 512 positions: mm_resolve, mm_resolve2, the fused scan
 
 // tell the compiler a value is the same in every lane (keeps it in SGPRs / on the scalar unit)
 __device__ __forceinline__ uint32_t mm_uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -117,7 +123,8 @@ __device__ __forceinline__ void mm_plan_to_lds(MmPlanLds &P, const mmh_plan_desc
 // start + lo*S + k, where mis (returned, wave uniform) is the source misalignment.
 // All loads of a lane are issued before the first LDS store (one memory latency
 // per tile instead of one per 256 bytes).
-__device__ __forceinline__ int mm_stage_tile(const MmTileArgs &a, MmWaveLds &W, uint64_t start, int64_t lo, int npos, int lane)
+template <class WL>
+__device__ __forceinline__ int mm_stage_tile(const MmTileArgs &a, WL &W, uint64_t start, int64_t lo, int npos, int lane)
 {
    const int S = (int)a.g.S;
    const uint64_t src0 = start + (uint64_t)lo * S;
@@ -130,7 +137,7 @@ __device__ __forceinline__ int mm_stage_tile(const MmTileArgs &a, MmWaveLds &W, 
    const int mis = (int)(((uintptr_t)(a.g.rom + src0)) & 3);
    const uint32_t *s4 = reinterpret_cast<const uint32_t *>(a.g.rom + src0 - mis);
    const int nw = (nstage + mis + 3) >> 2;
-   constexpr int NU = (int)(sizeof(W.tile) / 4 + 63) / 64;
+   constexpr int NU = (int)(sizeof(W.tile) / 4 + 63) / 64;      // (5 loads per lane for the short windows, 17 for whole tiles)
    uint32_t v[NU];
 #pragma unroll
    for (int u = 0; u < NU; u++) {
@@ -206,6 +213,11 @@ __device__ __forceinline__ bool mm_locate_fast(const MmTileArgs &a, uint64_t o, 
       *b = 0; *p = 0; *j = (int64_t)(o >> sshift);
       return *j < (int64_t)(a.g.nbytes >> sshift) - (int64_t)a.g.L + 1;
    }
+   if (o >= a.g.nbytes) {
+      // a SWAR survivor in the padding behind the ROM (the streaming code looks at whole 16-byte chunks):
+      // block o / B does not exist -- and "bytes remaining" below would wrap around
+      return false;
+   }
    const uint64_t blk = a.block_shift < 64 ? o >> a.block_shift : o / a.g.block_bytes;
    const uint64_t first = a.block_shift < 64 ? blk << a.block_shift : blk * a.g.block_bytes;
    const uint64_t r = o - first;
@@ -239,7 +251,8 @@ __device__ __forceinline__ bool mm_tile_matches(const MmTileArgs &a, const MmPla
 // Steps 1 and 2 of the header: stage positions [lo, lo + npos) of the domain at byte `start`
 // and leave the jump of every position (| MM_JUMP_MATCH where the compare loop matched) in
 // W.jump.  Returns the staged tile's first byte.
-__device__ __forceinline__ const uint8_t *mm_tile_jumps(const MmTileArgs &a, const MmPlanLds &P, MmWaveLds &W, uint64_t start,
+template <class WL>
+__device__ __forceinline__ const uint8_t *mm_tile_jumps(const MmTileArgs &a, const MmPlanLds &P, WL &W, uint64_t start,
                                                         int64_t lo, int npos, int lane)
 {
    const int mis = mm_stage_tile(a, W, start, lo, npos, lane);
@@ -307,8 +320,11 @@ __device__ __forceinline__ const uint8_t *mm_tile_jumps(const MmTileArgs &a, con
 // the chain that enters group g in phase e leaves it.  ngroups * D independent little walks
 // (<= 64 / mean-jump steps each) spread over the lanes; composing the group maps afterwards
 // costs one LDS lookup per group.  Needs W.jump (mm_tile_jumps).
-__device__ __forceinline__ void mm_group_maps(const MmTileArgs &a, MmWaveLds &W, int npos, uint32_t lo_mod, int lane)
+template <class WL>
+__device__ __forceinline__ void mm_group_maps(const MmTileArgs &a, WL &W, int npos, uint32_t lo_mod, int lane,
+                                              const uint8_t *J = nullptr)
 {
+   J = J ? J : W.jump;
    const uint32_t D = a.plan.L - 1;
    const uint32_t ngroups = (uint32_t)(npos + 63) >> 6;
    const uint32_t ntasks = ngroups * D;                        // <= 32 * 31
@@ -321,7 +337,7 @@ __device__ __forceinline__ void mm_group_maps(const MmTileArgs &a, MmWaveLds &W,
       off = off >= D ? off - D : off;
       uint32_t p = first + off;
       while (p < end) {
-         p += W.jump[p] & (MM_JUMP_MATCH - 1);
+         p += J[p] & (MM_JUMP_MATCH - 1);
       }
       uint32_t v = mm_modd(a, lo_mod + end) + (p - end);        // it left the group at p in [end, end + D)
       v = v >= D ? v - D : v;
@@ -335,7 +351,8 @@ __device__ __forceinline__ void mm_group_maps(const MmTileArgs &a, MmWaveLds &W,
 // identity).  *end_matches: does the compare loop match AT position npos (the candidate in
 // front of which the window ends)?  Only meaningful when the domain holds L elements from
 // there, which the caller checked.
-__device__ __forceinline__ uint32_t mm_tile_map(const MmTileArgs &a, const MmPlanLds &P, MmWaveLds &W, uint64_t start, int64_t lo,
+template <class WL>
+__device__ __forceinline__ uint32_t mm_tile_map(const MmTileArgs &a, const MmPlanLds &P, WL &W, uint64_t start, int64_t lo,
                                                 int npos, uint32_t lo_mod, int lane, bool *end_matches = nullptr)
 {
    start = mm_uniform64(start);
@@ -423,14 +440,23 @@ struct MmResolveLds {
    unsigned int walked;                      // windows mapped by this workgroup
 };
 
+// a word another workgroup may have written during this launch (candidate lists, their counters):
+// read past this CU's L1 (sc1) -- cdna guideline 16; costs nothing where the word was written
+// by an earlier launch
+__device__ __forceinline__ unsigned long long mm_load_shared(const unsigned long long *p)
+{
+   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // The filter's MM_CAND_LISTS (= 64 = one per lane) lists get one compact numbering: candidate
 // ci is entry ci - excl[c] of the list c with excl[c] <= ci < excl[c+1].  Wave 0 reads the
 // counters (64 cache lines) once for the workgroup; call before a __syncthreads().
-__device__ __forceinline__ void mm_resolve_prefix(const MmResolveArgs &a, MmResolveLds &R)
+template <class A>
+__device__ __forceinline__ void mm_resolve_prefix(const A &a, MmResolveLds &R)
 {
    if (threadIdx.x < 64) {
       const int lane = threadIdx.x;
-      const unsigned long long my_count = a.list_count[lane * MM_LIST_STRIDE];
+      const unsigned long long my_count = mm_load_shared(&a.list_count[lane * MM_LIST_STRIDE]);
       unsigned long long incl = my_count;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
@@ -446,9 +472,91 @@ __device__ __forceinline__ void mm_resolve_prefix(const MmResolveArgs &a, MmReso
    }
 }
 
-__device__ __forceinline__ void mm_resolve_body(const MmResolveArgs &a, const MmPlanLds &P, MmWaveLds &W, MmResolveLds &R)
+// candidate number ci of the compact numbering (wave uniform)
+template <class A>
+__device__ __forceinline__ uint64_t mm_candidate(const A &a, unsigned long long excl, uint64_t ci)
+{
+   const int list = __popcll(__ballot(excl <= ci)) - 1;
+   const unsigned long long *slot = reinterpret_cast<const unsigned long long *>(a.cand) + (uint64_t)list * a.list_cap +
+                                    (ci - __shfl(excl, list));
+   return mm_uniform64(mm_load_shared(slot));
+}
+
+// One candidate, one wave: is byte offset o reported by the reference?  1 yes (on the chain of its
+// domain and the compare loop matches), 0 no, -1 the two short windows could not tell (*hi, *set:
+// where the pull-back stands, for mm_resolve2; *dom: its domain), -2 not an alignment of any domain.
+template <class A, class WL>
+__device__ __forceinline__ int mm_resolve_candidate(const A &a, const MmPlanLds &P, WL &W, uint64_t o, int lane,
+                                                    unsigned long long *walked, int64_t *hi_out, uint32_t *set_out, uint64_t *dom_out)
 {
    const uint32_t D = a.t.plan.L - 1;
+   const uint32_t full = D >= 32 ? 0xFFFFFFFFu : ((1u << D) - 1u);
+   uint64_t b; uint32_t p; int64_t jc;
+   if (!mm_locate_fast(a.t, o, &b, &p, &jc)) {
+      return -2;                               // SWAR survivor that is not an alignment of any domain (file tail, 16-bit odd boundary)
+   }
+   const uint64_t start = mm_domain_start(a.t.g, b, p);
+   *dom_out = a.t.g.whole ? 0 : b * a.t.g.S + p;
+
+   uint32_t S = 1u << mm_modd64(a.t, (uint64_t)jc);
+   int64_t hi = jc;
+   int verdict = -1;                           // 1 visited, 0 not visited, -1 undecided
+   if (jc == 0) {
+      // first alignment of its domain: always visited, but is it a match?  (no window to
+      // stage in front of it: read the elements directly)
+      bool matched;
+      mm_step(a.t.plan, [&](int64_t k) { return mm_elem(a.t.g, start, k); }, 0, &matched);
+      verdict = matched ? 1 : 0;
+   }
+   // Look-back windows of <= 256, then <= 512 positions, ending on multiples of their size:
+   // a true match pulls every phase onto itself within a few keyword lengths (that is
+   // what the bad-character rule is for), so the first window usually settles it.
+   for (int step = 0; step < MM_FAST_STEPS && hi > 0 && verdict < 0; step++) {
+      const int64_t gran = (int64_t)256 << step;
+      const int64_t lo = (hi - 1) & ~(gran - 1);
+      bool is_match = true;
+      const uint32_t map = mm_tile_map(a.t, P, W, start, lo, (int)(hi - lo), mm_modd64(a.t, (uint64_t)lo), lane,
+                                       step == 0 ? &is_match : nullptr);
+      (*walked)++;
+      if (!is_match) {
+         verdict = 0;                           // survived the SWAR conditions only
+         break;
+      }
+      S = mm_pull_back(S, D, map, lane);
+      hi = lo;
+      if (S == full || S == 0) {
+         verdict = S ? 1 : 0;
+         break;
+      }
+   }
+   if (verdict < 0 && hi == 0) {
+      verdict = (S & 1u) ? 1 : 0;              // domain start: the chain is in phase 0
+   }
+   *hi_out = hi;
+   *set_out = S;
+   return verdict;
+}
+
+// lane 0 of the wave that could not settle candidate ci: hand it to mm_resolve2 (or, in the flag
+// pass, mark its domain)
+template <class A>
+__device__ __forceinline__ void mm_resolve_hand_over(const A &a, uint64_t o, uint64_t ci, int64_t hi, uint32_t set, uint64_t dom)
+{
+   if (a.flag_bits) {
+      atomicOr(&a.flag_bits[dom >> 5], 1u << (dom & 31));
+      return;
+   }
+   unsigned int slot = atomicAdd(a.mid_count, 1u);   // beyond MM_MID_CAP: the host sees the count and switches engines
+   if (slot < MM_MID_CAP) {
+      a.mid_off[slot] = o;
+      a.mid_hi[slot] = (uint64_t)hi;
+      a.mid_set[slot] = set;
+      a.mid_slot[slot] = (uint32_t)ci;
+   }
+}
+
+__device__ __forceinline__ void mm_resolve_body(const MmResolveArgs &a, const MmPlanLds &P, MmWaveLdsShort &W, MmResolveLds &R)
+{
    const int wave = (int)mm_uniform(threadIdx.x >> 6);
    const int lane = threadIdx.x & 63;
    const unsigned long long excl = R.excl[lane];
@@ -460,71 +568,17 @@ __device__ __forceinline__ void mm_resolve_body(const MmResolveArgs &a, const Mm
       return;                                  // dense input: the host runs another engine
    }
    const uint64_t nwaves = (uint64_t)gridDim.x * MM_WAVES;
-   const uint32_t full = D >= 32 ? 0xFFFFFFFFu : ((1u << D) - 1u);
    unsigned long long walked = 0;
 
    for (uint64_t ci = (uint64_t)blockIdx.x * MM_WAVES + wave; ci < ncand; ci += nwaves) {
-      const int list = __popcll(__ballot(excl <= ci)) - 1;
       // wave uniform from here on: the index arithmetic below runs on the scalar unit
-      const uint64_t o = mm_uniform64(a.cand[(uint64_t)list * a.list_cap + (ci - __shfl(excl, list))]);
-      uint64_t b; uint32_t p; int64_t jc;
-      if (!mm_locate_fast(a.t, o, &b, &p, &jc)) {
-         // SWAR survivor that is not an alignment of any domain (file tail, 16-bit odd boundary)
-         if (lane == 0) {
-            a.out[ci] = MM_NO_MATCH;
-         }
-         continue;
-      }
-      const uint64_t start = mm_domain_start(a.t.g, b, p);
-
-      uint32_t A = 1u << mm_modd64(a.t, (uint64_t)jc);
-      int64_t hi = jc;
-      int verdict = -1;                        // 1 visited, 0 not visited, -1 undecided
-      if (jc == 0) {
-         // first alignment of its domain: always visited, but is it a match?  (no window to
-         // stage in front of it: read the elements directly)
-         bool matched;
-         mm_step(a.t.plan, [&](int64_t k) { return mm_elem(a.t.g, start, k); }, 0, &matched);
-         verdict = matched ? 1 : 0;
-      }
-      // Look-back windows of <= 256, then <= 512 positions, ending on multiples of their size:
-      // a true match pulls every phase onto itself within a few keyword lengths (that is
-      // what the bad-character rule is for), so the first window usually settles it.
-      for (int step = 0; step < MM_FAST_STEPS && hi > 0 && verdict < 0; step++) {
-         const int64_t gran = (int64_t)256 << step;
-         const int64_t lo = (hi - 1) & ~(gran - 1);
-         bool is_match = true;
-         const uint32_t map = mm_tile_map(a.t, P, W, start, lo, (int)(hi - lo), mm_modd64(a.t, (uint64_t)lo), lane,
-                                          step == 0 ? &is_match : nullptr);
-         walked++;
-         if (!is_match) {
-            verdict = 0;                        // survived the SWAR conditions only
-            break;
-         }
-         A = mm_pull_back(A, D, map, lane);
-         hi = lo;
-         if (A == full || A == 0) {
-            verdict = A ? 1 : 0;
-            break;
-         }
-      }
-      if (verdict < 0 && hi == 0) {
-         verdict = (A & 1u) ? 1 : 0;           // domain start: the chain is in phase 0
-      }
+      const uint64_t o = mm_candidate(a, excl, ci);
+      int64_t hi = 0; uint32_t set = 0; uint64_t dom = 0;
+      const int verdict = mm_resolve_candidate(a, P, W, o, lane, &walked, &hi, &set, &dom);
       if (lane == 0) {
          a.out[ci] = verdict == 1 ? mm_report_value(a.t.g, o, a.base_offset) : MM_NO_MATCH;
-         if (verdict < 0 && a.flag_bits) {
-            const uint64_t dom = a.t.g.whole ? 0 : b * a.t.g.S + p;
-            atomicOr(&a.flag_bits[dom >> 5], 1u << (dom & 31));
-         }
-         else if (verdict < 0) {
-            unsigned int slot = atomicAdd(a.mid_count, 1u);   // beyond MM_MID_CAP: the host sees the count and switches engines
-            if (slot < MM_MID_CAP) {
-               a.mid_off[slot] = o;
-               a.mid_hi[slot] = (uint64_t)hi;
-               a.mid_set[slot] = A;
-               a.mid_slot[slot] = (uint32_t)ci;
-            }
+         if (verdict == -1) {
+            mm_resolve_hand_over(a, o, ci, hi, set, dom);
          }
       }
    }
@@ -541,7 +595,7 @@ __device__ __forceinline__ void mm_resolve_body(const MmResolveArgs &a, const Mm
 __global__ __launch_bounds__(64 * MM_WAVES) void mm_resolve(MmResolveArgs a)
 {
    __shared__ MmPlanLds P;
-   __shared__ MmWaveLds Wv[MM_WAVES];
+   __shared__ MmWaveLdsShort Wv[MM_WAVES];
    __shared__ MmResolveLds R;
    mm_resolve_prefix(a, R);
    mm_plan_to_lds(P, a.t.plan);                 // ends with a __syncthreads()
@@ -575,7 +629,7 @@ struct MmResolve2Args {
    unsigned int *hard_count;
 };
 
-__device__ __forceinline__ void mm_resolve2_body(const MmResolve2Args &a, const MmPlanLds &P, MmWaveLds &W,
+__device__ __forceinline__ void mm_resolve2_body(const MmResolve2Args &a, const MmPlanLds &P, MmWaveLdsShort &W,
                                                  uint8_t (&maps)[MM_TILE / MM_MID_CHUNK][MM_MAXD])
 {
    const uint32_t D = a.t.plan.L - 1;
@@ -641,7 +695,7 @@ __device__ __forceinline__ void mm_resolve2_body(const MmResolve2Args &a, const 
 __global__ __launch_bounds__(64 * MM_WAVES) void mm_resolve2(MmResolve2Args a)
 {
    __shared__ MmPlanLds P;
-   __shared__ MmWaveLds Wv[MM_WAVES];
+   __shared__ MmWaveLdsShort Wv[MM_WAVES];
    __shared__ uint8_t maps[MM_TILE / MM_MID_CHUNK][MM_MAXD];
    if (*a.mid_count == 0) {
       return;

@@ -23,13 +23,18 @@ sys.path.insert(0, ROOT)
 from _oracle import Ref  # noqa: E402
 from conftest import load_package  # noqa: E402
 
+M16, M256 = 16 << 20, 256 << 20
 CASES = [
-    # name, elem, keyword, wildcard, big_endian, nbytes, block sizes
-    ("C2 shape: 8-bit, 12 symbols", 1, "relativesrch", None, False, 16 << 20, [524288, 8388608]),
-    ("C3 shape: 8-bit, 16 symbols, 3 wildcards", 1, "re*ative*ear*hxy", ord("*"), False, 16 << 20, [524288]),
-    ("C4 shape: 16-bit LE, 8 symbols", 2, "textsrch", None, False, 16 << 20, [524288]),
-    ("C4 shape: 16-bit BE, 8 symbols", 2, "textsrch", None, True, 16 << 20, [524288]),
+    # name, elem, keyword, wildcard, big_endian, nbytes, block sizes (G5: the library default, the GUI default, one block = the file)
+    ("C2 shape: 8-bit, 12 symbols", 1, "relativesrch", None, False, M16, [524288, 8388608, M16]),
+    ("C3 shape: 8-bit, 16 symbols, 3 wildcards", 1, "re*ative*ear*hxy", ord("*"), False, M16, [524288, 8388608, M16]),
+    ("C4 shape: 16-bit LE, 8 symbols", 2, "textsrch", None, False, M16, [524288, 8388608, M16]),
+    ("C4 shape: 16-bit BE, 8 symbols", 2, "textsrch", None, True, M16, [524288, 8388608, M16]),
     ("ragged: 8-bit, odd size, small blocks", 1, "relativesrch", None, False, (3 << 20) + 4099, [65536, 8191]),
+    # G4 at 256 MiB
+    ("C2 shape at 256 MiB", 1, "relativesrch", None, False, M256, [524288, 8388608, M256]),
+    ("C3 shape at 256 MiB", 1, "re*ative*ear*hxy", ord("*"), False, M256, [524288, 8388608]),
+    ("C4 shape at 256 MiB: 16-bit LE", 2, "textsrch", None, False, M256, [524288, 8388608]),
 ]
 
 
@@ -43,9 +48,9 @@ def main():
         entry = dict(name=name, seed=42, nbytes=n, elem_bytes=elem, keyword=kw, wildcard=wc, big_endian=be,
                      sha256=hashlib.sha256(rom.tobytes()).hexdigest(), engine={})
         for b in blocks:
-            offs = ref.engine(elem, rom, kw, wc if wc is not None else ord("*"), None, big_endian=be, threads=4, block_size=b)
+            offs = ref.engine(elem, rom, kw, wc if wc is not None else ord("*"), None, big_endian=be, threads=8, block_size=b)
             entry["engine"][str(b)] = [int(x) for x in offs]
-        if not be:
+        if not be and n <= M16:
             data = rom[: (n // elem) * elem].view(np.uint8 if elem == 1 else "<u2")
             entry["whole_buffer"] = [int(x) for x in ref.search(elem, kw, data, wc or 0)]
         out.append(entry)

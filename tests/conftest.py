@@ -19,6 +19,22 @@ def load_golden(name):
         return json.load(f)
 
 
+def load_tiny():
+    """tests/golden/diff_tiny.json.gz (oracle/gen_tiny_golden.py) -> (search cases, engine cases) in the
+    field names of the other golden files; inputs are decoded to numpy arrays."""
+    import base64
+    import gzip
+    import numpy as np
+    with gzip.open(os.path.join(HERE, "golden", "diff_tiny.json.gz"), "rb") as f:
+        doc = json.loads(f.read().decode())
+    search = [dict(elem_bytes=c["e"], keyword=c["k"], wildcard=c["w"], char_seq=c["s"], values=c["v"],
+                   data=np.frombuffer(base64.b64decode(c["d"]), dtype=np.uint8 if c["e"] == 1 else "<u2"), expect=c["x"])
+              for c in doc["search"]]
+    engine = [dict(elem_bytes=c["e"], keyword=c["k"], wildcard=c["w"], big_endian=c["be"], block_size=c["b"],
+                   file=np.frombuffer(base64.b64decode(c["f"]), dtype=np.uint8), expect=c["x"]) for c in doc["engine"]]
+    return search, engine
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from _oracle import Oracle

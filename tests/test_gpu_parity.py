@@ -68,6 +68,46 @@ def test_reference_vectors_engine(mm, gpu_engine):
         assert got.tolist() == c["expect"], c
 
 
+def test_tiny_reference_vectors(mm, gpu_engine):
+    """all 11 000 tiny vectors of the compiled reference through the C ABI (every 16th
+    also through the sequential and the forward engine)."""
+    from conftest import load_tiny
+    search, engine = load_tiny()
+    assert len(search) + len(engine) >= 10000
+    for i, c in enumerate(search):
+        gpu_engine.upload(c["data"])
+        plan = _mm_plan(mm, c)
+        got = _scan_both(gpu_engine, plan) if i % 16 == 0 else gpu_engine.scan(plan)
+        assert got.tolist() == c["expect"], {k: v for k, v in c.items() if k != "data"}
+    for i, c in enumerate(engine):
+        gpu_engine.upload(c["file"])
+        plan = _mm_plan(mm, c)
+        kw = dict(block_bytes=c["block_size"], big_endian=c["big_endian"])
+        got = _scan_both(gpu_engine, plan, **kw) if i % 16 == 0 else gpu_engine.scan(plan, **kw)
+        assert got.tolist() == c["expect"], {k: v for k, v in c.items() if k != "file"}
+
+
+def test_no_matches_in_the_padding_behind_the_rom(mm, gpu_engine, oracle):
+    """Regression (found by the tiny vectors): the streaming code looks at whole 16-byte chunks, so it
+    sees the bytes behind the ROM; when those continue the pattern (stale bytes of a larger ROM that
+    was resident before, or a borrowed buffer) a survivor there must not be taken for an alignment
+    of a block that does not exist.  Sizes that are exact multiples of the block size are the trap."""
+    for elem, kw, n, block in ((1, "eee", 7 * 76, 7), (1, "ddddddddd", 129 * 7, 129), (2, "uuu", 26 * 36, 26), (1, "nnnn", 4096, 512),
+                               (1, "relativesrch", 65536, 4096)):
+        big = np.full(n + 4096, 0x41, np.uint8)
+        if kw == "relativesrch":
+            vals = np.array([ord(c) for c in kw], np.uint8)
+            for at in range(100, n + 4000, 1000):             # plants inside AND behind the ROM
+                big[at:at + len(kw)] = vals
+        gpu_engine.upload(big)                                 # leaves its bytes in the device buffer ...
+        gpu_engine.upload(big[:n])                             # ... behind the ROM that counts
+        plan = mm.plan_relative(elem, kw)
+        want = oracle.engine(oracle.plan(elem, kw), big[:n], block)
+        got = _scan_both(gpu_engine, plan, block_bytes=block)
+        assert got.tolist() == want.tolist(), (kw, n, block)
+        assert len(got) == 0 or int(got.max()) + len(kw) * elem <= n
+
+
 def test_device_generator_matches_oracle(mm, gpu_engine, oracle):
     n = (1 << 20) + 13
     gpu_engine.alloc(n)

@@ -92,6 +92,24 @@ def test_models_against_reference_vectors(mm):
     assert n_fast > 500
 
 
+def test_models_against_tiny_reference_vectors(mm):
+    """A sample of the 11 000 tiny vectors (tests/golden/diff_tiny.json.gz) through the host plan and the
+    Python model of the device algorithm (every 8th case; the oracle and the GPU take all of them)."""
+    from conftest import load_tiny
+    search, engine = load_tiny()
+    for c in search[::8]:
+        pl = _plan(mm, c)
+        rom = c["data"].view(np.uint8)
+        g = _model.Geom(rom.size, c["elem_bytes"], pl.L)
+        assert _model.chain_seq(pl, rom, g) == c["expect"], c
+        assert _model.fast_path(pl, rom, g, tile=16, seg=2) == c["expect"], c
+    for c in engine[::8]:
+        pl = _plan(mm, c)
+        g = _model.Geom(c["file"].size, c["elem_bytes"], pl.L, c["block_size"], c["big_endian"])
+        assert _model.chain_seq(pl, c["file"], g) == c["expect"], c
+        assert _model.fast_path(pl, c["file"], g, tile=16, seg=4) == c["expect"], c
+
+
 def test_models_against_reference_engine_vectors(mm):
     cases = load_golden("diff_engine.json")
     for idx, c in enumerate(cases):
