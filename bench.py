@@ -1,4 +1,5 @@
 #!/usr/bin/env python3
+# SPDX-License-Identifier: GPL-3.0-or-later
 """bench.py -- GB/s scanned by the MI355X relative-search engine.
 
   python bench.py --gpus N --steps K --warmup W [--config C2|C5]

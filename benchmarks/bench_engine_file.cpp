@@ -1,3 +1,4 @@
+// SPDX-License-Identifier: GPL-3.0-or-later
 // bench_engine_file.cpp -- end-to-end rate of SearchEngine<T>::run on a FILE (the reference's
 // GUI / test entry point, src/core/search_engine.cpp:23-216): file in the page cache (tmpfs)
 // -> parallel readers -> pinned staging -> PCIe -> HBM -> scan -> equivalency maps.  This is

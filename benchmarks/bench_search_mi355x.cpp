@@ -1,3 +1,4 @@
+// SPDX-License-Identifier: GPL-3.0-or-later
 // bench_search_mi355x.cpp -- the reference's benchmark cases (benchmarks/bench_search.cpp:
 // BM_Search/Relative{,/Wildcard/{Front,Middle,Back}}/{8,16}-Bit, 128 KiB .. 16 MiB x4,
 // mt19937(42) data, bytes per second) run through the SAME public API -- MonkeyMoore<T>

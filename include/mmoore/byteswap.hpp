@@ -1,3 +1,4 @@
+// SPDX-License-Identifier: GPL-3.0-or-later
 // byteswap.hpp -- endianness helpers of the mmoore API (MI355X build).
 //
 // Same names and call signatures as the helpers the reference exposes in its header of the

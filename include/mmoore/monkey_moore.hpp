@@ -1,3 +1,4 @@
+// SPDX-License-Identifier: GPL-3.0-or-later
 // monkey_moore.hpp -- MonkeyMoore<Ty>, the relative-search matcher of the mmoore API,
 // backed by the MI355X engine (libmmoore_hip.so, include/mmoore_hip.h).
 //

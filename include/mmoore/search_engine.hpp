@@ -1,3 +1,4 @@
+// SPDX-License-Identifier: GPL-3.0-or-later
 // search_engine.hpp -- SearchEngine<T>, the file-level driver of the mmoore API, backed by
 // the MI355X engine.
 //

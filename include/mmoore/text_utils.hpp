@@ -1,3 +1,4 @@
+// SPDX-License-Identifier: GPL-3.0-or-later
 // text_utils.hpp -- small helpers of the mmoore API (MI355X build).
 //
 // The names and meanings match what the reference's header of the same name offers

@@ -1,3 +1,4 @@
+/* SPDX-License-Identifier: GPL-3.0-or-later */
 /*
  * mmoore_hip.h -- C ABI of the MI355X relative-search engine (libmmoore_hip.so).
  *
@@ -32,7 +33,12 @@
 extern "C" {
 #endif
 
-#define MMH_MAX_KEYWORD 32      /* longest keyword the GPU plan holds */
+/* Longest keyword a plan holds.  The reference has no explicit limit, but its wildcard-path tables
+ * store keyword_len - 1 in a char (src/core/monkey_moore.cpp:250-253, :270-272): from 129 symbols
+ * on that wraps negative and its skip arithmetic changes meaning, so 128 is where parity ends.
+ * Keywords of up to 32 symbols take the streaming filter + per-candidate resolvers; longer ones
+ * always run on the forward engine (csrc/mm_forward.h), whose phase maps are sized for 127 phases. */
+#define MMH_MAX_KEYWORD 128
 
 enum {
    MMH_OK = 0,

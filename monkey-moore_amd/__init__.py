@@ -1,3 +1,4 @@
+# SPDX-License-Identifier: GPL-3.0-or-later
 """monkey-moore_amd -- MI355X-native relative-search engine (host-side Python binding).
 
 Thin ctypes layer over the C ABI of include/mmoore_hip.h (libmmoore_hip.so).
@@ -19,7 +20,7 @@ from . import build, partition, synth  # noqa: F401
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = _build.CAPI_SO
 
-MMH_MAX_KEYWORD = 32
+MMH_MAX_KEYWORD = 128
 MMH_OK, MMH_E_ARG, MMH_E_PLAN, MMH_E_DEVICE, MMH_E_CAPACITY, MMH_E_STATE = 0, -1, -2, -3, -4, -5
 
 EXPORTS = [

@@ -1,3 +1,4 @@
+# SPDX-License-Identifier: GPL-3.0-or-later
 """Builds libmmoore_hip.so (HIP kernels + C ABI) and libmonkey-core.so (the C++17
 facade with the reference's include/mmoore API) in-tree, for gfx950 only.
 

@@ -1,3 +1,4 @@
+// SPDX-License-Identifier: GPL-3.0-or-later
 // mm_capi.hip -- the C ABI of include/mmoore_hip.h: device context, ROM
 // ownership, and the orchestration of one scan on one HIP stream.
 //
@@ -417,20 +418,33 @@ int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev,
    }
    w.ctrl_clean = false;
    w.fused = false;
-   if (allow_fused && !sequential && !skip_bits && c->fused_ok && fused_enabled() && g_fused_lock.try_lock()) {
-      // the whole first phase in one launch; its end is announced in pinned memory (finish_pipeline polls)
-      w.seq++;
-      if (mm::launch_fused(st, g, pl, fc, rb, base_offset, max_candidates, w.h_result, w.d_result[w.result_turn], kMaxRankSort,
-                           w.seq, ev[0], ev[2])) {
-         if (!hip_ok(hipGetLastError(), "launching the fused scan kernel")) {
-            g_fused_lock.unlock();
-            return MMH_E_DEVICE;
+   w.polled = false;
+   if (allow_fused && !sequential && !skip_bits && fused_enabled()) {
+      // the scan's end is announced in pinned memory (finish_pipeline polls): either everything in one
+      // launch (small ROMs), or the streaming kernel + ONE tail kernel
+      if (c->fused_ok && mm::fused_applies(g) && g_fused_lock.try_lock()) {
+         w.seq++;
+         if (mm::launch_fused(st, g, pl, fc, rb, base_offset, max_candidates, w.h_result, w.d_result[w.result_turn], kMaxRankSort,
+                              w.seq, ev[0], ev[2])) {
+            if (!hip_ok(hipGetLastError(), "launching the fused scan kernel")) {
+               g_fused_lock.unlock();
+               return MMH_E_DEVICE;
+            }
+            w.fused = true;
+            w.polled = true;
+            return MMH_OK;
          }
-         w.fused = true;
-         return MMH_OK;
+         g_fused_lock.unlock();
+         c->fused_ok = false;                   // the occupancy query failed: never try again
       }
-      g_fused_lock.unlock();
-      c->fused_ok = false;                      // the occupancy query failed: plain kernels from now on
+      w.seq++;
+      const uint64_t block_cap = (c->mg.comm && c->mg.nranks > 1) ? mm::tuning().filter_blocks_comm : 0;
+      mm::launch_filter(st, g, pl, fc, w.d_cand, w.d_ctrl, w.cand_cap, ev[0], ev[1], nullptr, nullptr, block_cap);
+      mm::launch_tail(st, g, pl, fc, rb, base_offset, max_candidates, w.h_result, w.d_result[w.result_turn], kMaxRankSort, w.seq,
+                      ev[2]);
+      HIP_TRY(hipGetLastError());
+      w.polled = true;
+      return MMH_OK;
    }
    // The scan's three events ride on kernel dispatches (hipExtLaunchKernelGGL) where they can:
    // a hipEventRecord between dependent kernels costs ~6 us of stream time on this stack.
@@ -509,17 +523,21 @@ int wait_fused(MmWorkspace &w, hipEvent_t done)
 int finish_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev, const MmGeom &g, const mmh_plan_desc &pl,
                     uint64_t base_offset, uint32_t max_candidates, bool sequential, Outcome *oc)
 {
-   if (w.fused) {
+   if (w.polled) {
+      w.polled = false;
+      const bool was_fused = w.fused;
       w.fused = false;
       const int rc = wait_fused(w, ev[2]);
-      g_fused_lock.unlock();
+      if (was_fused) {
+         g_fused_lock.unlock();
+      }
       if (rc != MMH_OK) {
          return rc;
       }
       const uint64_t flags = w.h_result[4];
-      w.fused_filter_ms = (float)((double)(flags >> 8) * 1e-5);          // 100 MHz ticks -> ms
+      w.fused_filter_ms = was_fused ? (float)((double)(flags >> 8) * 1e-5) : 0.0f;   // 100 MHz ticks -> ms
       static const bool trace = getenv("MMOORE_FUSED_TRACE") != nullptr;
-      if (trace) {
+      if (trace && was_fused) {
          const uint64_t st = w.h_result[1];
          fprintf(stderr, "fused scan: streaming %.2f us; after the last arrival: wg0 past the barrier %.2f us, wg0 done %.2f us, header %.2f us; %llu candidates\n",
                  (double)(flags >> 8) * 1e-2, (double)(st & 0xFFFFF) * 1e-2, (double)((st >> 20) & 0xFFFFF) * 1e-2,
@@ -682,7 +700,7 @@ int run_dense(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, uint64_t bas
       return MMH_OK;                              // no alignment fits anywhere
    }
    auto round = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
-   const size_t need = round(dg.maps_bytes) + round(dg.supmaps_bytes) + round(dg.supentry_bytes) + round(dg.entry_bytes);
+   const size_t need = round(dg.maps_bytes);
    if (need > c->dense_bytes) {
       if (c->d_dense) {
          HIP_TRY(hipFree(c->d_dense));
@@ -694,9 +712,6 @@ int run_dense(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, uint64_t bas
    }
    mm::DenseBuffers db;
    db.maps = c->d_dense;
-   db.supmaps = db.maps + round(dg.maps_bytes);
-   db.supentry = db.supmaps + round(dg.supmaps_bytes);
-   db.entry = db.supentry + round(dg.supentry_bytes);
    db.out = c->ws[0].d_out; db.out_cap = c->ws[0].out_cap; db.ctrl = c->ws[0].d_ctrl;
 
    HIP_TRY(hipMemsetAsync(c->ws[0].d_ctrl, 0, mm::ctrl_bytes(), st));
@@ -1037,7 +1052,9 @@ int scan_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int b
    // engine 0: filter + per-candidate resolvers; inputs they do not suit (no SWAR key in the
    // pattern, candidate sets too dense, prefixes too long) go to the forward "dense" engine,
    // whose cost is linear in the ROM.  1 / 2 force the sequential / dense engine (tests).
-   enum { FAST, SEQUENTIAL, DENSE } mode = c->engine == 1 ? SEQUENTIAL : (c->engine == 2 || !have_filter) ? DENSE : FAST;
+   // (keywords beyond 32 symbols: the resolvers' phase sets do not hold their D > 31 phases)
+   const bool narrow = plan->L <= MM_RESOLVER_MAX_KEYWORD;
+   enum { FAST, SEQUENTIAL, DENSE } mode = c->engine == 1 ? SEQUENTIAL : (c->engine == 2 || !have_filter || !narrow) ? DENSE : FAST;
    const uint32_t max_candidates = candidate_limit(c->ws[0]);
 
    Outcome oc;
@@ -1225,7 +1242,7 @@ extern "C" int mmh_scan_submit(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t b
    const MmGeom g = scan_geometry(c, plan, block_bytes, big_endian);
    mm::FilterChoice fc;
    const bool have_filter = mm::choose_filter(*plan, &fc);
-   if (c->engine != 0 || !have_filter || g.nbytes == 0) {
+   if (c->engine != 0 || !have_filter || g.nbytes == 0 || plan->L > MM_RESOLVER_MAX_KEYWORD) {
       p.needs_rescan = true;                    // collect runs mmh_scan
    }
    else {

@@ -1,3 +1,4 @@
+// SPDX-License-Identifier: GPL-3.0-or-later
 // mm_context.h -- the device context behind the C ABI's opaque mmh_ctx (private to csrc/)
 #ifndef MM_CONTEXT_H
 #define MM_CONTEXT_H
@@ -48,6 +49,7 @@ struct MmWorkspace {
    int result_turn = 0;             // d_result[result_turn] belongs to the most recent scan
    uint64_t seq = 0;                // fused scans: the number the kernel raises in h_result[MM_HDR_FLAG_WORD]
    bool fused = false;              // the scan under way is one mm_scan_fused launch (and holds the process-wide fused lock)
+   bool polled = false;             // the scan under way announces its end in h_result[MM_HDR_FLAG_WORD] (fused or filter + tail)
    float fused_filter_ms = 0;       // its streaming phase, from the kernel's own wall-clock stamps
    bool ctrl_clean = false;         // the previous scan's last kernel left d_ctrl zeroed
 };

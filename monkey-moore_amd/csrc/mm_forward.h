@@ -1,3 +1,4 @@
+// SPDX-License-Identifier: GPL-3.0-or-later
 // mm_forward.h -- the forward engine, second generation: exact emulation of every chain of the
 // ROM in ONE pass over it.  Included by mm_kernels.hip after mm_tiles.h (device code only).
 //
@@ -19,15 +20,42 @@
 //     published maps (Merrill & Garland's single-pass scan, with function composition in place of
 //     addition).  A batch whose map is constant -- on ordinary data the chains of a 32 KiB batch
 //     have long merged -- publishes its exit phase at once and nobody ever waits for it;
+//   * a tile's phase map comes from EXIT TABLES (mm_fwd_map), 32 steps of one LDS read each
+//     whatever the pattern, instead of walking each of the D phases' chains;
 //   * tiles are only walked for matches when one of their positions passed the whole compare
-//     loop (rare): then the tile is staged again with the now known entry phase.
+//     loop (rare): then the tile is staged again with the now known entry phase;
+//   * keywords of up to MMH_MAX_KEYWORD = 128 symbols (D <= 127): maps are byte arrays handled by
+//     lane e and lane e + 64 (template parameter MAXD); the per-candidate resolvers keep D <= 31,
+//     longer keywords always come here.
 // Batches are handed out through one ticket per workgroup and four batches, so a waiting wave
 // only ever waits for batches that running waves own: no residency assumption, no deadlock.
 #ifndef MM_FORWARD_H
 #define MM_FORWARD_H
 
 constexpr int MM_FWD_BATCH = 16;               // tiles per batch (one wave): 32 Ki positions
+// positions per tile: a tile's positions sit in up to 3 slots further on (MmFwdLds), and 64 lanes own
+// 64 groups of 32 slots -- 2044 + 3 slots still fit them
+constexpr int MM_FWD_TILE = MM_TILE - 4;
 constexpr unsigned long long MM_FWD_AGGREGATE = 1, MM_FWD_INCLUSIVE = 2;
+
+// a wave's working set: one tile of MM_TILE positions of ELEM-byte elements
+template <int ELEM>
+struct MmFwdLds {
+   static constexpr int kPositions = MM_TILE;
+   uint32_t tile_pad[1];                     // tile[-1]: mm_fwd_jumps reads the dword in front of any tile dword unconditionally
+   // Slots: position p of the tile is slot q = p + r (r = 0..3: the jumps of four positions are stored as one
+   // dword, see mm_fwd_jumps); groups of 32 slots are 36 bytes apart (MM_FWD_AT) so that 64 lanes working
+   // on 64 groups in step hit different LDS banks (32 bytes apart: 16 of them on one bank).
+   static constexpr int kPadded = (MM_TILE / 32) * 36 + 4;
+   static_assert(MM_FWD_TILE + 3 <= MM_TILE, "a tile's slots must fit 64 groups of 32");
+   static constexpr int kStaged = (MM_TILE + MMH_MAX_KEYWORD + 1) * ELEM + 16;
+   uint32_t tile[((kStaged > kPadded ? kStaged : kPadded) + 3) / 4];   // staged bytes; later the exit tables / the finds
+   uint8_t jump[kPadded];                    // J of every slot (| MM_JUMP_MATCH)
+   uint8_t gentry[MM_TILE / 32 + 1];         // emit: how far behind its start the chain enters each group of 32 slots
+};
+
+// byte address of slot q in a padded array
+#define MM_FWD_AT(q) ((q) + 4 * ((q) >> 5))
 
 struct MmForwardArgs {
    MmTileArgs t;
@@ -35,7 +63,7 @@ struct MmForwardArgs {
    const uint32_t *dom_list; // nullptr: every domain; else the domains to work on
    uint32_t tpd;             // tiles per domain
    uint32_t bpd;             // batches per domain
-   uint8_t *agg;             // [ndom * bpd][MM_MAXD] published batch maps
+   uint8_t *agg;             // [ndom * bpd][MAXD] published batch maps (MAXD = 32, or 128 for keywords beyond 32 symbols)
    unsigned long long *status;   // [ndom * bpd] look-back words (zeroed before the launch): state | exit phase << 8
    unsigned long long *ticket;   // next batch to hand out (zeroed before the launch)
    uint64_t *out;            // MM_CAND_LISTS output lists of list_cap values
@@ -102,28 +130,28 @@ __device__ __forceinline__ int mm_deep_jump(const MmTileArgs &a, const MmPlanLds
 }
 
 // Stage positions [lo, lo + npos) of the domain at byte `start` and leave the jump of every
-// position in LDS.  Returns the jump array (J[p], p in [0, npos): W.jump shifted by 0..3 bytes so
-// that four positions' jumps are stored as one dword) and, in *tile_out, the staged tile's first
-// byte; *any_match: some position passed the whole compare loop.
-__device__ __forceinline__ const uint8_t *mm_fwd_jumps(const MmForwardArgs &a, const MmPlanLds &P, const MmFwdTables &T, MmWaveLds &W,
-                                                       uint64_t start, int64_t lo, int npos, int lane, bool *any_match,
-                                                       const uint8_t **tile_out)
+// position in W.jump: position p in slot q = p + *shift (padded layout, MM_FWD_AT).  *tile_out: the
+// staged tile's first byte; *any_match: some position passed the whole compare loop.
+template <class WL>
+__device__ __forceinline__ void mm_fwd_jumps(const MmForwardArgs &a, const MmPlanLds &P, const MmFwdTables &T, WL &W, uint64_t start,
+                                             int64_t lo, int npos, int lane, bool *any_match, const uint8_t **tile_out, int *shift)
 {
    if (!a.fast) {
-      const uint8_t *tile = mm_tile_jumps(a.t, P, W, start, lo, npos, lane);
+      const uint8_t *tile = mm_tile_jumps(a.t, P, W, start, lo, npos, lane, true);
       bool m = false;
       for (int q = lane; q < npos; q += 64) {
-         m = m || (W.jump[q] & MM_JUMP_MATCH) != 0;
+         m = m || (W.jump[MM_FWD_AT(q)] & MM_JUMP_MATCH) != 0;
       }
       *any_match = __ballot(m) != 0;
       *tile_out = tile;
-      return W.jump;
+      *shift = 0;
+      return;
    }
    const int mis = mm_stage_tile(a.t, W, start, lo, npos, lane);
    mm_wave_sync();
    const uint8_t *tile = reinterpret_cast<const uint8_t *>(W.tile) + mis;
    // position p compares LDS byte p + base with the byte g1 in front of it; LDS dword b4 + u holds
-   // the compared bytes of positions 4u - r + k, k = 0..3, whose jumps form dword u of J - r
+   // the compared bytes of slots 4u .. 4u + 3 (positions 4u - r + k)
    const int base = mis + (int)a.i1;
    const int r = base & 3, b4 = base >> 2;
    const int ndw = (npos + r + 3) >> 2;
@@ -133,7 +161,7 @@ __device__ __forceinline__ const uint8_t *mm_fwd_jumps(const MmForwardArgs &a, c
    for (int u = lane; u < ndw; u += 64) {
       const int mdw = b4 + u;
       const uint32_t w = W.tile[mdw];
-      const uint32_t wp = mdw > 0 ? W.tile[mdw - 1] : 0u;
+      const uint32_t wp = W.tile[mdw - 1];                     // (mdw = 0: the pad dword in front of the tile; only positions < 0 use it)
       const uint32_t wq = mm_alignbit(w, wp, sh1);            // byte k: the partner of w's byte k
       uint32_t jj = 0;
 #pragma unroll
@@ -141,58 +169,154 @@ __device__ __forceinline__ const uint8_t *mm_fwd_jumps(const MmForwardArgs &a, c
          const int d = (int)((w >> (8 * k)) & 0xFF) - (int)((wq >> (8 * k)) & 0xFF);
          jj |= (uint32_t)T.jump1[d + 255] << (8 * k);
       }
-      // positions outside [0, npos) (in front of the tile in dword 0, behind it in the last one)
+      // Dword 0 may start up to three positions in front of the tile and the last one may end behind
+      // it: their jumps are computed like the others (from whatever bytes are there) and never read.
       const int p0 = 4 * u - r;
-      uint32_t valid = 0xFFFFFFFFu;
-      if (p0 < 0) {
-         valid <<= 8 * (-p0);
-      }
-      if (p0 + 4 > npos) {
-         valid &= p0 >= npos ? 0u : 0xFFFFFFFFu >> (8 * (p0 + 4 - npos));
-      }
-      uint32_t on = jj & valid & 0x80808080u;                 // first compare holds: 1/256 of the positions
+      uint32_t on = jj & 0x80808080u;                         // first compare holds: 1/256 of the positions
       if (__ballot(on != 0) != 0) {
          while (on) {
             const int k = (__ffs((int)on) - 1) >> 3;
             on &= on - 1;
             const int q = p0 + k;
-            int J;
-            if (a.has2) {
-               const int c2 = tile[q + (int)a.i2], p2 = tile[q + (int)a.i2 - (int)a.g2];
-               J = T.jump2[c2 - p2 + 255];
-               if (J & MM_JUMP_MATCH) {
-                  J = mm_deep_jump(a.t, P, tile, q, (int)a.i2 - 1);
+            int J = 1;
+            if (q >= 0 && q < npos) {
+               if (a.has2) {
+                  const int c2 = tile[q + (int)a.i2], p2 = tile[q + (int)a.i2 - (int)a.g2];
+                  J = T.jump2[c2 - p2 + 255];
+                  if (J & MM_JUMP_MATCH) {
+                     J = mm_deep_jump(a.t, P, tile, q, (int)a.i2 - 1);
+                  }
                }
-            }
-            else {
-               J = mm_deep_jump(a.t, P, tile, q, (int)a.i1 - 1);
+               else {
+                  J = mm_deep_jump(a.t, P, tile, q, (int)a.i1 - 1);
+               }
             }
             jj = (jj & ~(0xFFu << (8 * k))) | ((uint32_t)J << (8 * k));
          }
       }
-      m = m || (jj & valid & 0x80808080u) != 0;
-      jump32[u] = jj;
+      m = m || (jj & 0x80808080u) != 0;
+      jump32[u + (u >> 3)] = jj;                               // 8 dwords = one group of 32 slots, groups 9 dwords apart
    }
    *any_match = __ballot(m) != 0;
    *tile_out = tile;
+   *shift = r;
    mm_wave_sync();
-   return W.jump + r;
 }
 
-// phase map of positions [0, npos) (domain positions lo ..., lo_mod = lo mod D) from their jumps J:
-// lane e < D returns the exit phase of entry phase e (group maps in parallel, then composed)
-__device__ __forceinline__ uint32_t mm_fwd_map(const MmTileArgs &a, MmWaveLds &W, const uint8_t *J, int npos, uint32_t lo_mod, int lane)
+// x mod D for x < 2^16, any D <= 127 (mm_modd's 16-bit reciprocal is only exact for small D)
+__device__ __forceinline__ uint32_t mm_fwd_modd(const MmTileArgs &a, uint32_t x)
 {
    const uint32_t D = a.plan.L - 1;
-   mm_group_maps(a, W, npos, lo_mod, lane, J);
-   uint32_t v = (uint32_t)lane;
-   if ((uint32_t)lane < D) {
-      const int ngroups = (npos + 63) >> 6;
-      for (int g = 0; g < ngroups; g++) {
-         v = W.gmap[g][v];
+   if (D == 1) {
+      return 0;
+   }
+   const uint32_t q = __umulhi(x, a.inv_d32);                  // floor(x / D) or one more
+   const int32_t rem = (int32_t)(x - q * D);
+   return (uint32_t)(rem < 0 ? rem + (int32_t)D : rem);
+}
+
+// x / D for x < 2^16, any D <= 127
+__device__ __forceinline__ uint32_t mm_fwd_divd(const MmTileArgs &a, uint32_t x)
+{
+   const uint32_t D = a.plan.L - 1;
+   if (D == 1) {
+      return x;                                                 // (2^32 / 1 + 1 does not fit inv_d32)
+   }
+   const uint32_t q = __umulhi(x, a.inv_d32);                  // floor(x / D) or one more
+   return q * D > x ? q - 1 : q;
+}
+
+// Exit tables of slots [0, nq) from their jumps: the slots are cut into groups of 32, lane g owns
+// group g and fills X[q] = how far behind the group's end the chain that visits q leaves it, from
+// the group's last slot down: X[q] = q + J - end if that is >= 0, else X[q + J].  32 steps of one
+// LDS read each whatever the pattern -- walking every phase's chain forward costs 64 / (mean jump)
+// steps for each of D phases: fine for plain keywords, 4x more for wildcard patterns whose capped
+// skips make the mean jump 1-2.  X overlays the staged bytes (padded like the jumps), which nobody
+// needs once the jumps are known.  The group's 32 jumps are read as 8 dwords up front.
+template <class WL>
+__device__ __forceinline__ uint8_t *mm_fwd_exit_tables(WL &W, int nq, int lane)
+{
+   uint8_t *X = reinterpret_cast<uint8_t *>(W.tile);
+   // (lanes behind the last group, and slots behind nq in the last one, work on whatever is there:
+   // what they write is inside the buffer and never read by a real slot)
+   const int len = nq - 32 * lane < 32 ? nq - 32 * lane : 32;    // <= 0 behind the last group
+   const uint32_t *jw = reinterpret_cast<const uint32_t *>(W.jump) + 9 * lane;
+   uint32_t jd[8];
+#pragma unroll
+   for (int i = 0; i < 8; i++) {
+      jd[i] = jw[i];
+   }
+   uint8_t *Xg = X + 36 * lane;
+#pragma unroll
+   for (int k = 31; k >= 0; --k) {
+      const int t = k + (int)((jd[k >> 2] >> (8 * (k & 3))) & (MM_JUMP_MATCH - 1));
+      const int x = t >= len ? t - len : Xg[t];
+      Xg[k] = (uint8_t)x;
+   }
+   mm_wave_sync();
+   return X;
+}
+
+// the chain that stands `off` slots behind the start of group g: where it stands on entering group g + 1
+// (off >= the group's length: it jumps over the whole group -- only with D > 32 or in a short last group)
+__device__ __forceinline__ uint32_t mm_fwd_through_group(const uint8_t *X, int nq, int g, uint32_t off)
+{
+   const uint32_t len = (uint32_t)(nq - 32 * g < 32 ? nq - 32 * g : 32);
+   return off < len ? X[36 * g + off] : off - len;
+}
+
+// Phase map of positions [0, npos) (domain positions lo ..., lo_mod = lo mod D): v[h] = exit phase of
+// entry phase lane + 64 h (identity for lanes that are no phase).  Threading a phase through the 64
+// groups one after the other would be 64 dependent LDS reads; instead task (s, e) threads entry
+// offset e through the 8 groups of super-group s (all of them at once, SX[s][e]), then phase lane
+// goes through the 8 super-groups: 16 - 24 dependent reads for keywords of up to 17 symbols.
+template <int NH, int MAXD, class WL>
+__device__ __forceinline__ void mm_fwd_map(const MmTileArgs &a, WL &W, uint8_t (&SX)[MM_TILE / 256 + 1][MAXD + 4], int shift, int npos,
+                                           uint32_t lo_mod, int lane, uint32_t (&v)[NH])
+{
+   const uint32_t D = a.plan.L - 1;
+   const int nq = npos + shift;
+   const uint8_t *X = mm_fwd_exit_tables(W, nq, lane);
+   const int ngroups = (nq + 31) >> 5;
+   const int nsuper = (ngroups + 7) >> 3;
+   // SX[s][e]: the chain that stands e slots behind the start of super-group s (8 groups) -> where it stands behind its end.
+   // (Super-group 0 is entered up to `shift` slots later than slot 0: its table has D + 3 entries.)
+   const uint32_t width = D + 3;
+   const uint32_t ntasks = (uint32_t)nsuper * width;
+   for (uint32_t task = (uint32_t)lane; task < ntasks; task += 64) {
+      uint32_t sg = 0, off = task;
+      while (off >= width) {                                     // task / width (nsuper <= 9)
+         off -= width;
+         sg++;
+      }
+      const uint32_t e = off;
+      const int g1 = 8 * (int)sg + 8 < ngroups ? 8 * (int)sg + 8 : ngroups;
+      for (int g = 8 * (int)sg; g < g1; g++) {
+         off = mm_fwd_through_group(X, nq, g, off);
+      }
+      SX[sg][e] = (uint8_t)off;                                  // e < D + 3 <= MAXD + 2
+   }
+   mm_wave_sync();
+   const uint32_t end_mod = mm_fwd_modd(a, lo_mod + (uint32_t)npos);
+#pragma unroll
+   for (int h = 0; h < NH; h++) {
+      const uint32_t e = (uint32_t)lane + 64u * h;
+      v[h] = e;
+      if (e < D) {
+         // entry phase e enters at the first position >= 0 in that phase
+         uint32_t off = e + D - lo_mod;
+         off = (off >= D ? off - D : off) + (uint32_t)shift;
+         for (int sg = 0; sg < nsuper; sg++) {
+            // (a super-group of full groups is 256 slots long: an offset below D + 3 always lands inside
+            // it; the last, possibly short one: the offset may fall behind it)
+            const uint32_t len = (uint32_t)(nq - 256 * sg < 256 ? nq - 256 * sg : 256);
+            off = off < len ? SX[sg][off] : off - len;
+         }
+         uint32_t ph = end_mod + off;                            // the chain left the window `off` positions behind its end
+         v[h] = ph >= D ? ph - D : ph;
       }
    }
-   return v;
+   mm_wave_sync();
 }
 
 __device__ __forceinline__ void mm_fwd_domain(const MmForwardArgs &a, uint64_t dom, uint64_t *start, int64_t *nv)
@@ -207,43 +331,48 @@ __device__ __forceinline__ void mm_fwd_domain(const MmForwardArgs &a, uint64_t d
 }
 
 // the matches on the chain inside one tile, given the phase in which the chain enters it
-__device__ __forceinline__ void mm_fwd_emit(const MmForwardArgs &a, MmWaveLds &W, const uint8_t *J, uint64_t start, int64_t lo, int npos,
+template <class WL>
+__device__ __forceinline__ void mm_fwd_emit(const MmForwardArgs &a, WL &W, int shift, uint64_t start, int64_t lo, int npos,
                                             uint32_t entry, int lane)
 {
    const uint32_t D = a.t.plan.L - 1;
-   uint16_t *found = reinterpret_cast<uint16_t *>(W.tile);      // overwrites the staged bytes: nobody needs them any more
    const uint32_t list = blockIdx.x & (MM_CAND_LISTS - 1);
    const uint32_t lo_mod = mm_modd64(a.t, (uint64_t)lo);
-   const int ngroups = (npos + 63) >> 6;
-   mm_group_maps(a.t, W, npos, lo_mod, lane, J);
+   const int nq = npos + shift;
+   const int ngroups = (nq + 31) >> 5;
+   const uint8_t *X = mm_fwd_exit_tables(W, nq, lane);
    if (lane == 0) {
-      uint32_t ph = entry;
+      uint32_t off = entry + D - lo_mod;                         // first position >= 0 in phase `entry` ...
+      off = (off >= D ? off - D : off) + (uint32_t)shift;        // ... as a slot
       for (int g = 0; g < ngroups; g++) {
-         W.gentry[g] = (uint8_t)ph;
-         ph = W.gmap[g][ph];
+         W.gentry[g] = (uint8_t)(off < 255 ? off : 255);         // (>= 32: the chain jumps over the group)
+         off = mm_fwd_through_group(X, nq, g, off);
       }
    }
    mm_wave_sync();
+   // lane g walks group g and notes the visited slots where the compare loop matched: found[32 g ...], as
+   // offsets inside the group -- over the exit tables, which have served their purpose
+   uint8_t *found = reinterpret_cast<uint8_t *>(W.tile);
+   const uint32_t first = 32u * (uint32_t)lane;
+   uint32_t q = first + W.gentry[lane < ngroups ? lane : 0];
+   mm_wave_sync();
    int nfound = 0;
    if (lane < ngroups) {
-      const uint32_t first = 64u * (uint32_t)lane;
-      const uint32_t end = first + 64 < (uint32_t)npos ? first + 64 : (uint32_t)npos;
-      uint32_t off = (uint32_t)W.gentry[lane] + D - mm_modd(a.t, lo_mod + first);
-      off = off >= D ? off - D : off;
-      uint32_t p = first + off;
-      while (p < end) {
-         const uint32_t j = J[p];
+      const uint32_t end = first + 32 < (uint32_t)nq ? first + 32 : (uint32_t)nq;
+      while (q < end) {
+         const uint32_t j = W.jump[MM_FWD_AT(q)];
          if (j & MM_JUMP_MATCH) {
-            found[first + nfound++] = (uint16_t)p;            // group g's finds live in found[64 g ...]
+            found[first + nfound++] = (uint8_t)(q - first);
          }
-         p += j & (MM_JUMP_MATCH - 1);
+         q += j & (MM_JUMP_MATCH - 1);
       }
    }
+   // one atomic per tile reserves the output range; lanes copy their finds in group order
    int incl = nfound;
 #pragma unroll
    for (int d = 1; d < 64; d <<= 1) {
-      const int v = __shfl_up(incl, d);
-      incl += lane >= d ? v : 0;
+      const int up = __shfl_up(incl, d);
+      incl += lane >= d ? up : 0;
    }
    const int total = __shfl(incl, 63);
    if (total) {
@@ -255,7 +384,7 @@ __device__ __forceinline__ void mm_fwd_emit(const MmForwardArgs &a, MmWaveLds &W
       for (int k = 0; k < nfound; k++) {
          const unsigned long long slot = base + (unsigned long long)k;
          if (slot < a.list_cap) {
-            const uint64_t j = (uint64_t)lo + found[64 * lane + k];
+            const uint64_t j = (uint64_t)lo + first + found[first + k] - (uint32_t)shift;
             a.out[(uint64_t)list * a.list_cap + slot] = a.t.g.whole ? j : start + j * a.t.g.S + a.base_offset;
          }
       }
@@ -275,12 +404,19 @@ __device__ __forceinline__ unsigned long long mm_fwd_wait(const unsigned long lo
    return mm_uniform64(s);
 }
 
+// ELEM: element bytes the tile buffers are sized for (1: 8-bit searches, 6 workgroups per CU instead of 4);
+// MAXD: 32 for keywords of up to 32 symbols, 128 beyond (phase maps handled by lane e and lane e + 64)
+template <int ELEM, int MAXD>
 __global__ __launch_bounds__(64 * MM_WAVES) void mm_forward(MmForwardArgs a)
 {
+   using WL = MmFwdLds<ELEM>;
+   constexpr int NH = (MAXD + 63) / 64;
    __shared__ MmPlanLds P;
    __shared__ MmFwdTables T;
-   __shared__ MmWaveLds Wv[MM_WAVES];
-   __shared__ uint8_t tilemap[MM_WAVES][MM_FWD_BATCH][MM_MAXD];
+   __shared__ WL Wv[MM_WAVES];
+   __shared__ uint8_t tilemap[MM_WAVES][MM_FWD_BATCH][MAXD];
+   __shared__ uint8_t lookback[MM_WAVES][MAXD];
+   __shared__ uint8_t superx[MM_WAVES][MM_TILE / 256 + 1][MAXD + 4];
    __shared__ unsigned long long next_batch;
    mm_plan_to_lds(P, a.t.plan);
    mm_fwd_tables(T, P, a);
@@ -288,7 +424,7 @@ __global__ __launch_bounds__(64 * MM_WAVES) void mm_forward(MmForwardArgs a)
    const uint32_t D = a.t.plan.L - 1;
    const int wave = (int)mm_uniform(threadIdx.x >> 6);
    const int lane = threadIdx.x & 63;
-   MmWaveLds &W = Wv[wave];
+   WL &W = Wv[wave];
    const uint64_t nbatches = a.ndom * a.bpd;
 
    for (;;) {
@@ -313,65 +449,108 @@ __global__ __launch_bounds__(64 * MM_WAVES) void mm_forward(MmForwardArgs a)
       const uint32_t t1 = t0 + MM_FWD_BATCH < a.tpd ? t0 + MM_FWD_BATCH : a.tpd;
 
       // ---- pass 1: the map of every tile of the batch, composed into the batch's map ----------
-      uint32_t bm = (uint32_t)lane;                 // lane e < D: where entry phase e leaves the batch so far
+      uint32_t bm[NH];                              // bm[h]: where entry phase lane + 64 h leaves the batch so far
+#pragma unroll
+      for (int h = 0; h < NH; h++) {
+         bm[h] = (uint32_t)lane + 64u * h;
+      }
       uint32_t flagged = 0;                         // tiles with a position that passed the whole compare loop
       for (uint32_t t = t0; t < t1; t++) {
-         const int64_t lo = (int64_t)t * MM_TILE;
-         uint32_t map = (uint32_t)lane;             // tiles past the domain's end: identity
+         const int64_t lo = (int64_t)t * MM_FWD_TILE;
+         uint32_t map[NH];
+#pragma unroll
+         for (int h = 0; h < NH; h++) {
+            map[h] = (uint32_t)lane + 64u * h;      // tiles past the domain's end: identity
+         }
          if (lo < nv) {
-            const int npos = (int)(nv - lo < MM_TILE ? nv - lo : MM_TILE);
+            const int npos = (int)(nv - lo < MM_FWD_TILE ? nv - lo : MM_FWD_TILE);
             bool any = false;
             const uint8_t *tile;
-            const uint8_t *J = mm_fwd_jumps(a, P, T, W, start, lo, npos, lane, &any, &tile);
-            map = mm_fwd_map(a.t, W, J, npos, mm_modd64(a.t, (uint64_t)lo), lane);
+            int shift;
+            mm_fwd_jumps(a, P, T, W, start, lo, npos, lane, &any, &tile, &shift);
+            mm_fwd_map<NH, MAXD>(a.t, W, superx[wave], shift, npos, mm_modd64(a.t, (uint64_t)lo), lane, map);
             flagged |= any ? 1u << (t - t0) : 0u;
-            mm_wave_sync();
          }
-         if (lane < MM_MAXD) {
-            tilemap[wave][t - t0][lane] = (uint8_t)map;
+#pragma unroll
+         for (int h = 0; h < NH; h++) {
+            if (lane + 64 * h < MAXD) {
+               tilemap[wave][t - t0][lane + 64 * h] = (uint8_t)map[h];
+            }
          }
          mm_wave_sync();
-         if ((uint32_t)lane < D) {
-            bm = tilemap[wave][t - t0][bm];
+#pragma unroll
+         for (int h = 0; h < NH; h++) {
+            if ((uint32_t)lane + 64u * h < D) {
+               bm[h] = tilemap[wave][t - t0][bm[h]];
+            }
          }
       }
       // ---- publish; find the phase in which the chain enters the batch --------------------------
-      const uint32_t bm0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)bm);
-      const bool constant = __ballot((uint32_t)lane < D && bm != bm0) == 0;
+      const uint32_t bm0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)bm[0]);
+      bool differs = false;
+#pragma unroll
+      for (int h = 0; h < NH; h++) {
+         differs = differs || ((uint32_t)lane + 64u * h < D && bm[h] != bm0);
+      }
+      const bool constant = __ballot(differs) == 0;
       uint32_t entry = 0;                           // first batch of a domain: the chain starts at its first position
-      const bool need_entry = b != 0 && (flagged != 0 || !constant);
       if (b == 0 || constant) {
-         const uint32_t exit_phase = bm0;           // (b == 0: the chain enters in phase 0, and lane 0 is the first lane)
+         // (b == 0: the chain enters in phase 0, and lane 0 is the first lane)
          if (lane == 0) {
-            __hip_atomic_store(a.status + item, MM_FWD_INCLUSIVE | ((unsigned long long)exit_phase << 8), __ATOMIC_RELAXED,
+            __hip_atomic_store(a.status + item, MM_FWD_INCLUSIVE | ((unsigned long long)bm0 << 8), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
          }
       }
       else {
-         if (lane < MM_MAXD) {
-            __hip_atomic_store(a.agg + item * MM_MAXD + lane, (uint8_t)bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+         for (int h = 0; h < NH; h++) {
+            if (lane + 64 * h < MAXD) {
+               __hip_atomic_store(a.agg + item * MAXD + lane + 64 * h, (uint8_t)bm[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
          }
          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
          if (lane == 0) {
             __hip_atomic_store(a.status + item, MM_FWD_AGGREGATE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
          }
       }
-      if (need_entry) {
+      if (b != 0 && (flagged != 0 || !constant)) {
          // decoupled look-back: f[e] = the phase at OUR entry when the chain enters batch k+1 in phase e
-         uint32_t f = (uint32_t)lane;
+         // (kept in LDS: composing it with a batch's map is one lookup per phase)
+         uint8_t *f = lookback[wave];
+#pragma unroll
+         for (int h = 0; h < NH; h++) {
+            if (lane + 64 * h < MAXD) {
+               f[lane + 64 * h] = (uint8_t)(lane + 64 * h);
+            }
+         }
+         mm_wave_sync();
          for (uint64_t k = item - 1;; k--) {
-            const unsigned long long s = mm_fwd_wait(a.status, k, lane);
-            if ((s & 3) == MM_FWD_INCLUSIVE) {
-               entry = (uint32_t)__shfl((int)f, (int)((s >> 8) & 0xFF));
+            const unsigned long long st = mm_fwd_wait(a.status, k, lane);
+            if ((st & 3) == MM_FWD_INCLUSIVE) {
+               entry = f[(st >> 8) & 0xFF];
                break;
             }
-            uint32_t mk = (uint32_t)lane;
-            if (lane < MM_MAXD) {
-               mk = __hip_atomic_load(a.agg + k * MM_MAXD + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t fn[NH];
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+               fn[h] = 0;
+               if ((uint32_t)lane + 64u * h < D) {
+                  const uint32_t mk = __hip_atomic_load(a.agg + k * MAXD + lane + 64 * h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  fn[h] = f[mk];
+               }
             }
-            f = (uint32_t)__shfl((int)f, (int)(mk & 63));
-            const uint32_t f0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)f);
-            if (__ballot((uint32_t)lane < D && f != f0) == 0) {
+            mm_wave_sync();
+            const uint32_t f0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)fn[0]);
+            bool varies = false;
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+               if ((uint32_t)lane + 64u * h < D) {
+                  f[lane + 64 * h] = (uint8_t)fn[h];
+                  varies = varies || fn[h] != f0;
+               }
+            }
+            mm_wave_sync();
+            if (__ballot(varies) == 0) {
                entry = f0;                          // every entry phase of batch k ends up here: no need to go further back
                break;
             }
@@ -380,9 +559,12 @@ __global__ __launch_bounds__(64 * MM_WAVES) void mm_forward(MmForwardArgs a)
       }
       if (b != 0 && !constant) {
          // now that the entry is known, tell the batches behind us where the chain leaves this one
-         const uint32_t exit_phase = (uint32_t)__shfl((int)bm, (int)entry);
+         uint32_t ph = entry;
+         for (uint32_t t = t0; t < t1; t++) {
+            ph = tilemap[wave][t - t0][ph];
+         }
          if (lane == 0) {
-            __hip_atomic_store(a.status + item, MM_FWD_INCLUSIVE | ((unsigned long long)exit_phase << 8), __ATOMIC_RELAXED,
+            __hip_atomic_store(a.status + item, MM_FWD_INCLUSIVE | ((unsigned long long)ph << 8), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
          }
       }
@@ -391,12 +573,13 @@ __global__ __launch_bounds__(64 * MM_WAVES) void mm_forward(MmForwardArgs a)
          uint32_t ph = entry;
          for (uint32_t t = t0; t < t1; t++) {
             if ((flagged >> (t - t0)) & 1u) {
-               const int64_t lo = (int64_t)t * MM_TILE;
-               const int npos = (int)(nv - lo < MM_TILE ? nv - lo : MM_TILE);
+               const int64_t lo = (int64_t)t * MM_FWD_TILE;
+               const int npos = (int)(nv - lo < MM_FWD_TILE ? nv - lo : MM_FWD_TILE);
                bool any = false;
                const uint8_t *tile;
-               const uint8_t *J = mm_fwd_jumps(a, P, T, W, start, lo, npos, lane, &any, &tile);
-               mm_fwd_emit(a, W, J, start, lo, npos, ph, lane);
+               int shift;
+               mm_fwd_jumps(a, P, T, W, start, lo, npos, lane, &any, &tile, &shift);
+               mm_fwd_emit(a, W, shift, start, lo, npos, ph, lane);
             }
             ph = tilemap[wave][t - t0][ph];
          }

@@ -1,38 +1,38 @@
-// mm_fused.h -- one launch for a whole scan: streaming filter -> grid barrier -> every candidate
-// resolved AND ranked by one wave -> results published.  Included by mm_kernels.hip after
-// mm_tiles.h (device code only).
+// SPDX-License-Identifier: GPL-3.0-or-later
+// mm_fused.h -- the tail of a scan in one place, and small scans in ONE launch.  Included by
+// mm_kernels.hip after mm_tiles.h (device code only).
 //
-// Why: behind the streaming kernel a scan used to run three more dependent launches (mm_resolve,
-// mm_rank_count, mm_rank_scatter: 32 us on the bench ROM, most of it launch and dependency
-// latency, round 1) and the host then waited on an event (~12 us).  Here the same work is one
-// kernel:
-//   phase A  the streaming code of mm_filter_u8 / mm_filter_u16, unchanged (mm_stream_*); the
-//            ragged end of the ROM goes to the last workgroup (mm_edge_*);
-//   barrier  every workgroup arrives once (one agent-scope atomic each); candidates were stored
-//            write-through and are read past L1 afterwards (cdna guideline 16 R1), so no fence;
-//   phase B  wave w takes candidate w: the reference's compare loop + chain membership through
-//            the two short look-back windows (mm_resolve_candidate, the code of mm_resolve), and
-//            its RANK among all candidates (offsets are unique: rank = number of smaller ones,
-//            counted against the candidate lists staged in LDS) -- the ordering needs no verdicts,
-//            so it needs no second barrier.  The result goes to slot `rank` of the published
-//            block: the reported value, or a hole (~0) for a candidate that is not reported.
-//            Holes are rare (on the bench ROM: none); the host drops them while copying out.
-//   end      the last workgroup to finish writes the header, zeroes the control block for the
-//            next scan and raises a flag word in pinned host memory -- the host polls that word
-//            instead of waiting for a HIP event.
+// Round 1 ran three dependent launches behind the streaming kernel (mm_resolve, mm_rank_count,
+// mm_rank_scatter: 32 us on the bench ROM, most of it launch and dependency latency) and the host
+// then waited on an event (~12 us).  Now:
+//   * mm_scan_tail_phase: wave w takes candidate w -- the reference's compare loop + chain
+//     membership through the two short look-back windows (mm_resolve_candidate, the code of
+//     mm_resolve) AND its rank among all candidates (offsets are unique: rank = number of smaller
+//     ones; the workgroup's threads share out the candidate set and hold it in registers, the loads
+//     are in flight while the resolver runs).  The ordering needs no verdicts, so nothing waits for
+//     anything: the result goes straight to slot `rank` of the published block (pinned host memory
+//     + its device-side copy): the reported value, or a hole (~0) for a candidate that is not
+//     reported.  Holes are rare (bench ROM: none); the host drops them while copying out.  The
+//     last workgroup to finish (two-level arrival counter) writes the header, zeroes the control
+//     block for the next scan and raises the scan's sequence number in pinned host memory -- the
+//     host polls that word instead of waiting for a HIP event.
+//   * mm_scan_tail: that phase as ONE kernel behind mm_filter_* (large ROMs).
+//   * mm_scan_fused: streaming filter, grid barrier and that phase in one launch, for ROMs of a
+//     few MiB, where launch latency is all there is (a 128 KiB scan: 11 us on the device instead
+//     of 20).  On big ROMs it does not pay: a thousand workgroups' arrivals and cache-bypassing
+//     reads of the candidate lists (written in the same launch, cdna guideline 16) cost more than
+//     the launch they save (measured: +35 us on 4 GiB).
 // Candidates the two windows cannot settle are handed to the second phase exactly as mm_resolve
 // does (mid list; the host launches mm_resolve2 / mm_hard_resolve and the rank kernels then).
 //
-// A grid barrier needs every workgroup resident at once: the grid is sized well below the
-// device's capacity (host side, launch_fused), every spin is bounded by a wall-clock timeout, and
-// a timeout makes the kernel give up cleanly (header word 4 bit 1) -- the host then runs the
-// plain kernels on the candidate lists, which are complete by then or rebuilt.  Two fused
+// The fused kernel's grid barrier needs every workgroup resident at once: the grid is small and
+// sized well below the device's capacity (host side, launch_fused), every spin is bounded by a
+// wall-clock timeout, and a timeout makes the kernel give up cleanly (header word 4 bit 1) -- the
+// host then runs the plain kernels on the candidate lists, which are complete by then.  Two fused
 // kernels at once could starve each other of slots, so the host never has more than one in
-// flight per process (a process-wide try-lock; the loser takes the plain path).
+// flight per process (a process-wide try-lock; the loser takes the two-launch path).
 #ifndef MM_FUSED_H
 #define MM_FUSED_H
-
-constexpr int MM_FUSED_RANK_SLICE = 1024;      // candidate keys staged in LDS per ranking pass (8 KiB)
 
 // header word 4 of the published block
 constexpr unsigned long long MM_HDR_SPARSE = 1;     // the list holds one slot per candidate, ~0 = hole
@@ -154,58 +154,258 @@ __device__ __forceinline__ bool mm_grid_barrier(unsigned long long *ctrl, uint32
    return verdict_sh == 1;
 }
 
-// rank of `key` among the candidates = number of candidates with a smaller offset; the workgroup
-// stages the candidate lists slice by slice in LDS (keys[]), each wave counts for its own key.
-// All four waves call this together (block-wide barriers inside); `live` waves get their rank.
-__device__ __forceinline__ uint32_t mm_fused_rank(const MmFusedArgs &a, const MmResolveLds &R, uint64_t *keys, uint64_t ncand,
-                                                  uint64_t key, bool live, int lane)
+// ---- the tail of a scan: every candidate resolved, ranked and published by one wave ------------
+//
+// Shared by the fused kernel (behind its grid barrier: SAME_LAUNCH, the candidate lists were
+// written during this launch and are read past the caches) and by mm_scan_tail, the kernel that
+// follows mm_filter_* on large ROMs (plain cached loads).
+
+constexpr int MM_TAIL_KEYS = 10;               // candidate keys a thread holds in registers per ranking pass (2560 per workgroup)
+
+template <bool SAME_LAUNCH>
+__device__ __forceinline__ unsigned long long mm_tail_load(const unsigned long long *p)
 {
-   uint32_t smaller = 0;
-   for (uint64_t s0 = 0; s0 < ncand; s0 += MM_FUSED_RANK_SLICE) {
-      const uint32_t n = (uint32_t)(ncand - s0 < MM_FUSED_RANK_SLICE ? ncand - s0 : MM_FUSED_RANK_SLICE);
-      __syncthreads();                                     // the previous slice has been consumed
-      for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
-         // compact number s0 + k -> its list and entry (the 64 prefix sums sit in LDS)
-         const uint64_t ci = s0 + k;
-         uint32_t lo = 0, hi = MM_CAND_LISTS - 1;
-         while (lo < hi) {                                  // last list whose first number is <= ci
-            const uint32_t mid = (lo + hi + 1) >> 1;
-            if (R.excl[mid] <= ci) {
-               lo = mid;
-            }
-            else {
-               hi = mid - 1;
-            }
-         }
-         const unsigned long long *slot = reinterpret_cast<const unsigned long long *>(a.cand) + (uint64_t)lo * a.list_cap + (ci - R.excl[lo]);
-         keys[k] = mm_load_shared(slot);
-      }
-      __syncthreads();
-      if (live) {
-         for (uint32_t k = (uint32_t)lane; k < n; k += 64) {
-            smaller += keys[k] < key ? 1u : 0u;
-         }
-      }
-   }
-#pragma unroll
-   for (int d = 32; d >= 1; d >>= 1) {
-      smaller += (uint32_t)__shfl_xor((int)smaller, d);
-   }
-   return smaller;
+   return SAME_LAUNCH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
 }
 
-// (second launch bound: 4 waves per SIMD, i.e. <= 128 VGPRs -- 4 workgroups per CU must fit)
+struct MmTailLds {
+   unsigned long long wkey[MM_WAVES];          // the candidates the workgroup's waves are working on (~0: none)
+   unsigned int smaller[MM_WAVES];             // how many candidates have a smaller offset
+   unsigned int holes, maxcount;
+   int last_block;
+};
+
+// thread t holds entries q, q + 4, q + 8, ... (q = t / 64) of candidate list t % 64, from entry `base` on
+template <bool SAME_LAUNCH>
+__device__ __forceinline__ void mm_tail_keys(const MmFusedArgs &a, unsigned long long count, unsigned long long base,
+                                             unsigned long long (&v)[MM_TAIL_KEYS])
+{
+   const unsigned long long *list = reinterpret_cast<const unsigned long long *>(a.cand) + (uint64_t)(threadIdx.x & 63) * a.list_cap;
+#pragma unroll
+   for (int u = 0; u < MM_TAIL_KEYS; u++) {
+      const unsigned long long j = base + (threadIdx.x >> 6) + 4ull * u;
+      v[u] = j < count ? mm_tail_load<SAME_LAUNCH>(list + j) : ~0ull;      // ~0 is never smaller than a candidate
+   }
+}
+
+template <bool SAME_LAUNCH>
+__device__ __forceinline__ void mm_scan_tail_phase(const MmFusedArgs &a, const MmPlanLds &P, MmWaveLdsShort *Wv, MmResolveLds &R,
+                                                   MmTailLds &T, bool together)
+{
+   const int wave = (int)mm_uniform(threadIdx.x >> 6);
+   const int lane = threadIdx.x & 63;
+   if (threadIdx.x == 0) {
+      T.holes = 0;
+   }
+   // the 64 list counters: one (cache-bypassing, in the fused kernel) load per lane of wave 0
+   if (threadIdx.x < 64) {
+      const unsigned long long my_count = mm_tail_load<SAME_LAUNCH>(a.list_count + lane * MM_LIST_STRIDE);
+      unsigned long long incl = my_count;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+         const unsigned long long up = __shfl_up(incl, d);
+         incl += lane >= d ? up : 0ull;
+      }
+      R.excl[lane] = incl - my_count;
+      const bool overflow = __ballot(my_count > a.list_cap) != 0;
+      unsigned long long most = my_count;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+         const unsigned long long other = __shfl_xor(most, d);
+         most = other > most ? other : most;
+      }
+      if (lane == 63) {
+         R.ncand = overflow ? ~0ull : incl;
+         R.walked = 0;
+         T.maxcount = (unsigned int)(most > 0xFFFFFFFFull ? 0xFFFFFFFFull : most);
+      }
+   }
+   __syncthreads();
+   const unsigned long long excl = R.excl[lane];
+   const unsigned long long ncand = R.ncand;
+   const bool resolvable = together && ncand <= a.out_cap && ncand <= a.max_candidates && ncand <= a.max_rank;
+   unsigned long long walked = 0;
+   if (resolvable) {
+      // this thread's list and how many entries it has
+      const uint32_t c = threadIdx.x & 63;
+      const unsigned long long my_list_count = (c + 1 < MM_CAND_LISTS ? R.excl[c + 1] : ncand) - R.excl[c];
+      const uint64_t nwaves = (uint64_t)gridDim.x * MM_WAVES;
+      const uint64_t rounds = (ncand + nwaves - 1) / nwaves;          // block-uniform trip count: the ranking synchronises the workgroup
+      for (uint64_t rd = 0; rd < rounds; rd++) {
+         const uint64_t first = rd * nwaves + (uint64_t)blockIdx.x * MM_WAVES;
+         if (first >= ncand) {
+            break;                              // (uniform in the workgroup: none of its waves has a candidate)
+         }
+         const uint64_t ci = first + wave;
+         const bool live = ci < ncand;
+         uint64_t o = ~0ull;
+         if (live) {
+            const int list = __popcll(__ballot(excl <= ci)) - 1;
+            const unsigned long long *slot = reinterpret_cast<const unsigned long long *>(a.cand) + (uint64_t)list * a.list_cap +
+                                             (ci - __shfl(excl, list));
+            o = mm_uniform64(mm_tail_load<SAME_LAUNCH>(slot));
+         }
+         if (lane == 0) {
+            T.wkey[wave] = o;
+            T.smaller[wave] = 0;
+         }
+         int verdict = 0;
+         int64_t hi = 0; uint32_t set = 0; uint64_t dom = 0;
+         if (live) {
+            verdict = mm_resolve_candidate(a, P, Wv[wave], o, lane, &walked, &hi, &set, &dom);
+         }
+         // Ranking: offsets are unique, so a candidate's place in the ascending list is the number of
+         // candidates with a smaller offset.  The workgroup's 256 threads share out the candidate set
+         // (thread t: a quarter of list t % 64), hold their share in registers and count for all four
+         // waves' candidates at once.  (Loading the keys before the resolver would hide the one round
+         // trip, but 40 registers held across it cost a workgroup per CU: 55 us instead of 25.)
+         asm volatile("" ::: "memory");         // (keeps the compiler from hoisting the loads above the resolver)
+         unsigned long long keys[MM_TAIL_KEYS];
+         mm_tail_keys<SAME_LAUNCH>(a, my_list_count, 0, keys);
+         __syncthreads();                       // every wave's key is in T.wkey
+         unsigned int cnt[MM_WAVES] = {0, 0, 0, 0};
+         for (unsigned long long base = 0;;) {
+#pragma unroll
+            for (int u = 0; u < MM_TAIL_KEYS; u++) {
+#pragma unroll
+               for (int w = 0; w < MM_WAVES; w++) {
+                  cnt[w] += keys[u] < T.wkey[w] ? 1u : 0u;
+               }
+            }
+            base += 4ull * MM_TAIL_KEYS;
+            if (base >= T.maxcount) {
+               break;
+            }
+            mm_tail_keys<SAME_LAUNCH>(a, my_list_count, base, keys);     // lists longer than a register pass: rare
+         }
+#pragma unroll
+         for (int w = 0; w < MM_WAVES; w++) {
+            unsigned int s = cnt[w];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+               s += (unsigned int)__shfl_xor((int)s, d);
+            }
+            if (lane == 0 && s) {
+               atomicAdd(&T.smaller[w], s);
+            }
+         }
+         __syncthreads();
+         if (live && lane == 0) {
+            const uint32_t rank = T.smaller[wave];
+            const uint64_t value = verdict == 1 ? mm_report_value(a.t.g, o, a.base_offset) : MM_NO_MATCH;
+            a.out[ci] = value;
+            // system-scope store: written through to host memory, complete once this wave's vmcnt drains
+            // (a __threadfence_system() per workgroup instead -- an L2 write-back each -- cost 15 us of a 4 GiB scan's tail)
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.host_result) + MM_RESULT_HEADER_WORDS + rank, (unsigned long long)value,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            a.dev_result[MM_RESULT_HEADER_WORDS + rank] = value;
+            if (verdict != 1) {
+               atomicAdd(&T.holes, 1u);
+            }
+            if (verdict == -1) {
+               mm_resolve_hand_over(a, o, ci, hi, set, dom);
+            }
+         }
+         __syncthreads();                       // T.wkey / T.smaller are rewritten by the next round
+      }
+   }
+   // ---- statistics, header, flag ---------------------------------------------------------------
+   if (blockIdx.x == 0 && threadIdx.x == 0) {
+      __hip_atomic_store(a.ctrl + MM_CTRL_T_STAMPS + 1, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+   }
+   if (lane == 0 && walked) {
+      atomicAdd(&R.walked, (unsigned int)walked);
+   }
+   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's result stores have arrived (host memory: written through)
+   __syncthreads();
+   if (threadIdx.x == 0) {
+      if (R.walked) {
+         atomicAdd(a.tiles_walked + (blockIdx.x % MM_STAT_STRIPES), (unsigned long long)R.walked);
+      }
+      if (T.holes) {
+         atomicAdd(a.ctrl + MM_CTRL_NOMATCH, (unsigned long long)T.holes);
+      }
+      T.last_block = mm_arrive_last(a.ctrl + MM_CTRL_ARRIVE_END, gridDim.x);
+   }
+   __syncthreads();
+   if (!T.last_block) {
+      return;
+   }
+   if (threadIdx.x < 64) {
+      // one round trip for all the words the header is made of: lane k reads word k
+      unsigned long long v = 0;
+      if (lane < 32) {
+         v = __hip_atomic_load(a.ctrl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      unsigned long long tiles = lane >= MM_CTRL_TILES && lane < MM_CTRL_TILES + MM_STAT_STRIPES ? v : 0;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+         tiles += __shfl_xor(tiles, d);
+      }
+      const unsigned long long nomatch = __shfl(v, MM_CTRL_NOMATCH), mid = __shfl(v, MM_CTRL_MID);
+      const unsigned long long t0 = __shfl(v, MM_CTRL_T_START), t1 = __shfl(v, MM_CTRL_T_BARRIER);
+      // tuning aid (header word 1): when workgroup 0 left the barrier and finished its candidates, and now,
+      // in wall-clock ticks after the last arrival at the barrier
+      const unsigned long long s2 = __shfl(v, MM_CTRL_T_STAMPS), s3 = __shfl(v, MM_CTRL_T_STAMPS + 1), s4 = wall_clock64();
+      unsigned long long h = 0;
+      switch (lane) {
+      case 0: h = ncand; break;                            // candidates = slots (~0: a list overflowed)
+      case 1: h = ((s2 - t1) & 0xFFFFF) | (((s3 - t1) & 0xFFFFF) << 20) | (((s4 - t1) & 0xFFFFF) << 40); break;
+      case 2: h = tiles; break;
+      // [4]: flags in the low byte, above them the streaming phase's duration in wall-clock ticks
+      case 4: h = (resolvable ? MM_HDR_SPARSE : 0) | (together ? 0 : MM_HDR_GAVE_UP) | ((t1 > t0 ? t1 - t0 : 0) << 8); break;
+      case 5: h = mid; break;
+      case 6: h = resolvable ? ncand - nomatch + 1 : 0; break;   // matches + 1 (0: not ordered here)
+      default: break;                                      // [3] unused here; [7] = 0: the list length is word 0
+      }
+      if (lane < (int)MM_RESULT_HEADER_WORDS) {
+         a.host_result[lane] = h;
+         a.dev_result[lane] = h;
+      }
+      if (lane == 0) {
+         R.walked = (unsigned int)(mid & 0xFFFFFFFFull);   // (for the decision below)
+      }
+   }
+   __syncthreads();
+   // the control block goes back to zero for the next scan -- unless the second phase follows
+   // (left-overs) or the plain kernels take over (gave up / too many candidates): they need the
+   // candidate counters
+   const bool keep = !resolvable || R.walked != 0;
+   if (keep) {
+      if (threadIdx.x == 0) {
+         a.ctrl[MM_CTRL_NOMATCH] = 0;
+         a.ctrl[MM_CTRL_DECISION] = 0;
+         a.ctrl[MM_CTRL_T_START] = 0;
+         a.ctrl[MM_CTRL_T_BARRIER] = 0;
+         a.ctrl[MM_CTRL_T_STAMPS] = 0;
+         a.ctrl[MM_CTRL_T_STAMPS + 1] = 0;
+         a.ctrl[MM_CTRL_TOTAL] = ncand;                    // what mm_resolve would have left for the later stages
+      }
+      for (uint32_t k = MM_CTRL_ARRIVE_BARRIER + threadIdx.x; k < MM_CTRL_WORDS; k += blockDim.x) {
+         a.ctrl[k] = 0;                                    // arrival counters and release flags
+      }
+   }
+   else {
+      for (uint32_t k = threadIdx.x; k < a.ctrl_words; k += blockDim.x) {
+         a.ctrl[k] = 0;
+      }
+   }
+   __syncthreads();
+   if (threadIdx.x == 0) {
+      __threadfence_system();
+      __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.host_result) + MM_HDR_FLAG_WORD, (unsigned long long)a.seq,
+                         __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+   }
+}
+
+// One launch for a whole (small) scan.  (second launch bound: 4 waves per SIMD, i.e. <= 128 VGPRs)
 template <int ELEM, int SHAPE>
 __global__ __launch_bounds__(64 * MM_WAVES, 4) void mm_scan_fused(MmFusedArgs a)
 {
    __shared__ MmPlanLds P;
    __shared__ MmWaveLdsShort Wv[MM_WAVES];
    __shared__ MmResolveLds R;
-   __shared__ uint64_t keys[MM_FUSED_RANK_SLICE];
-   __shared__ int last_block;
-   __shared__ unsigned int holes, wrote;
-   const int wave = (int)mm_uniform(threadIdx.x >> 6);
-   const int lane = threadIdx.x & 63;
+   __shared__ MmTailLds T;
 
    if (blockIdx.x == 0 && threadIdx.x == 0) {
       __hip_atomic_store(a.ctrl + MM_CTRL_T_START, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -232,140 +432,22 @@ __global__ __launch_bounds__(64 * MM_WAVES, 4) void mm_scan_fused(MmFusedArgs a)
    if (blockIdx.x == 0 && threadIdx.x == 0) {
       __hip_atomic_store(a.ctrl + MM_CTRL_T_STAMPS, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
    }
-
    // ---- phase B: resolve + rank + publish ----------------------------------------------------
-   if (threadIdx.x == 0) {
-      holes = 0;
-      wrote = 0;
-   }
-   mm_resolve_prefix(a, R);
-   __syncthreads();
-   const unsigned long long excl = R.excl[lane];
-   const unsigned long long ncand = R.ncand;
-   const bool resolvable = together && ncand <= a.out_cap && ncand <= a.max_candidates && ncand <= a.max_rank;
-   unsigned long long walked = 0;
-   if (resolvable) {
-      const uint64_t nwaves = (uint64_t)gridDim.x * MM_WAVES;
-      // block-uniform trip count: the ranking synchronises the workgroup
-      const uint64_t rounds = (ncand + nwaves - 1) / nwaves;
-      for (uint64_t rd = 0; rd < rounds; rd++) {
-         const uint64_t first = rd * nwaves + (uint64_t)blockIdx.x * MM_WAVES;
-         if (first >= ncand) {
-            break;                              // (uniform in the workgroup: none of its waves has a candidate)
-         }
-         const uint64_t ci = first + wave;
-         const bool live = ci < ncand;
-         uint64_t o = 0;
-         int verdict = 0;
-         int64_t hi = 0; uint32_t set = 0; uint64_t dom = 0;
-         if (live) {
-            o = mm_candidate(a, excl, ci);
-            verdict = mm_resolve_candidate(a, P, Wv[wave], o, lane, &walked, &hi, &set, &dom);
-         }
-         const uint32_t rank = mm_fused_rank(a, R, keys, ncand, o, live, lane);
-         if (live && lane == 0) {
-            const uint64_t value = verdict == 1 ? mm_report_value(a.t.g, o, a.base_offset) : MM_NO_MATCH;
-            a.out[ci] = value;
-            a.host_result[MM_RESULT_HEADER_WORDS + rank] = value;
-            a.dev_result[MM_RESULT_HEADER_WORDS + rank] = value;
-            wrote = 1;
-            if (verdict != 1) {
-               atomicAdd(&holes, 1u);
-            }
-            if (verdict == -1) {
-               mm_resolve_hand_over(a, o, ci, hi, set, dom);
-            }
-         }
-      }
-   }
-   // ---- end: statistics, header, flag ----------------------------------------------------------
-   if (blockIdx.x == 0 && threadIdx.x == 0) {
-      __hip_atomic_store(a.ctrl + MM_CTRL_T_STAMPS + 1, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-   }
-   if (lane == 0 && walked) {
-      atomicAdd(&R.walked, (unsigned int)walked);
-   }
-   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's result stores have left
-   __syncthreads();
-   if (threadIdx.x == 0) {
-      if (R.walked) {
-         atomicAdd(a.tiles_walked + (blockIdx.x % MM_STAT_STRIPES), (unsigned long long)R.walked);
-      }
-      if (wrote) {
-         __threadfence_system();                           // this workgroup published results: in host memory before its arrival
-      }
-      if (holes) {
-         atomicAdd(a.ctrl + MM_CTRL_NOMATCH, (unsigned long long)holes);
-      }
-      last_block = mm_arrive_last(a.ctrl + MM_CTRL_ARRIVE_END, gridDim.x);
-   }
-   __syncthreads();
-   if (!last_block) {
-      return;
-   }
-   if (threadIdx.x < 64) {
-      // one round trip for all the words the header is made of: lane k reads word k
-      unsigned long long v = 0;
-      if (lane < 32) {
-         v = __hip_atomic_load(a.ctrl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      unsigned long long tiles = lane >= MM_CTRL_TILES && lane < MM_CTRL_TILES + MM_STAT_STRIPES ? v : 0;
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) {
-         tiles += __shfl_xor(tiles, d);
-      }
-      const unsigned long long nomatch = __shfl(v, MM_CTRL_NOMATCH), mid = __shfl(v, MM_CTRL_MID);
-      const unsigned long long t0 = __shfl(v, MM_CTRL_T_START), t1 = __shfl(v, MM_CTRL_T_BARRIER);
-      // tuning aid (header words 1 and 3): when workgroup 0 left the barrier and finished its candidates, and now,
-      // in wall-clock ticks after the last arrival at the barrier
-      const unsigned long long s2 = __shfl(v, MM_CTRL_T_STAMPS), s3 = __shfl(v, MM_CTRL_T_STAMPS + 1), s4 = wall_clock64();
-      unsigned long long h = 0;
-      switch (lane) {
-      case 0: h = ncand; break;                            // candidates = slots (~0: a list overflowed)
-      case 2: h = tiles; break;
-      // [4]: flags in the low byte, above them the streaming phase's duration in wall-clock ticks
-      case 4: h = (resolvable ? MM_HDR_SPARSE : 0) | (together ? 0 : MM_HDR_GAVE_UP) | ((t1 > t0 ? t1 - t0 : 0) << 8); break;
-      case 5: h = mid; break;
-      case 6: h = resolvable ? ncand - nomatch + 1 : 0; break;   // matches + 1 (0: not ordered here)
-      case 1: h = ((s2 - t1) & 0xFFFFF) | (((s3 - t1) & 0xFFFFF) << 20) | (((s4 - t1) & 0xFFFFF) << 40); break;
-      default: break;                                      // [3] unused here; [7] = 0: the list length is word 0
-      }
-      if (lane < (int)MM_RESULT_HEADER_WORDS) {
-         a.host_result[lane] = h;
-         a.dev_result[lane] = h;
-      }
-      if (lane == 0) {
-         R.walked = (unsigned int)(mid & 0xFFFFFFFFull);   // (for the decision below)
-      }
-   }
-   __syncthreads();
-   // the control block goes back to zero for the next scan -- unless the second phase follows
-   // (left-overs) or the plain kernels take over (gave up / too many candidates): they need the
-   // candidate counters
-   const bool keep = !resolvable || R.walked != 0;
-   if (keep) {
-      if (threadIdx.x == 0) {
-         a.ctrl[MM_CTRL_NOMATCH] = 0;
-         a.ctrl[MM_CTRL_DECISION] = 0;
-         a.ctrl[MM_CTRL_T_START] = 0;
-         a.ctrl[MM_CTRL_T_BARRIER] = 0;
-         a.ctrl[MM_CTRL_TOTAL] = ncand;                    // what mm_resolve would have left for the later stages
-      }
-      for (uint32_t k = MM_CTRL_ARRIVE_BARRIER + threadIdx.x; k < MM_CTRL_WORDS; k += blockDim.x) {
-         a.ctrl[k] = 0;                                    // arrival counters and release flags
-      }
-   }
-   else {
-      for (uint32_t k = threadIdx.x; k < a.ctrl_words; k += blockDim.x) {
-         a.ctrl[k] = 0;
-      }
-   }
-   __syncthreads();
-   if (threadIdx.x == 0) {
-      __threadfence_system();
-      __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.host_result) + MM_HDR_FLAG_WORD, (unsigned long long)a.seq,
-                         __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-   }
+   mm_scan_tail_phase<true>(a, P, Wv, R, T, together);
+}
+
+// The tail as a kernel of its own, behind mm_filter_* (large ROMs: the streaming kernel keeps
+// its own, leaner launch and all the wave slots; this one replaces mm_resolve, mm_rank_count and
+// mm_rank_scatter -- one dependent launch instead of three).
+// (5 waves per SIMD: <= 96 VGPRs, so that the 1056 workgroups the bench ROM's candidates need are resident at once)
+__global__ __launch_bounds__(64 * MM_WAVES, 5) void mm_scan_tail(MmFusedArgs a)
+{
+   __shared__ MmPlanLds P;
+   __shared__ MmWaveLdsShort Wv[MM_WAVES];
+   __shared__ MmResolveLds R;
+   __shared__ MmTailLds T;
+   mm_plan_to_lds(P, a.t.plan);
+   mm_scan_tail_phase<false>(a, P, Wv, R, T, true);
 }
 
 #endif

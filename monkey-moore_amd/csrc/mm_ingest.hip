@@ -1,3 +1,4 @@
+// SPDX-License-Identifier: GPL-3.0-or-later
 // mm_ingest.hip -- getting a file into HBM, and match bytes back out of it.
 //
 // The reference's workers each read their own blocks with an ifstream and scan them in

@@ -1,3 +1,4 @@
+// SPDX-License-Identifier: GPL-3.0-or-later
 // mm_internal.h -- declarations shared by the host plan builder, the C ABI and
 // the HIP kernels.  Not installed; the public surface is include/mmoore_hip.h.
 #ifndef MM_INTERNAL_H
@@ -34,6 +35,10 @@ struct MmGeom {
    uint32_t big_endian;    // 16-bit elements stored big endian
    uint32_t whole;         // 1 = whole-buffer mode (results are element indices)
 };
+
+// keywords longer than this never take the streaming filter + per-candidate resolvers (their phase
+// sets are one 32-bit word, their stored phase maps 32 bytes): they run on the forward engine
+constexpr uint32_t MM_RESOLVER_MAX_KEYWORD = 32;
 
 // layout of the block a scan publishes (pinned host memory and its device-side copies):
 // MM_RESULT_HEADER_WORDS counters, then the ordered matches.  Header words: [0] candidates (= result

@@ -1,3 +1,4 @@
+// SPDX-License-Identifier: GPL-3.0-or-later
 // mm_kernels.h -- launch wrappers implemented in mm_kernels.hip
 #ifndef MM_KERNELS_H
 #define MM_KERNELS_H
@@ -16,6 +17,7 @@ struct Tuning {
    uint32_t filter_gps_comm;         // MMOORE_FILTER_GPS_COMM  (7 groups per span with that grid)
    uint32_t filter_groups_per_span;  // MMOORE_FILTER_GPS       (8 groups of 4 KiB)
    unsigned resolve_blocks;          // MMOORE_RESOLVE_BLOCKS   (4096 workgroups)
+   unsigned tail_blocks;             // MMOORE_TAIL_BLOCKS      (2048 workgroups of mm_scan_tail)
    uint32_t max_candidates;          // MMOORE_MAX_CANDIDATES   (262144 per scan)
 };
 const Tuning &tuning();
@@ -73,6 +75,12 @@ void launch_resolve(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, co
 bool launch_fused(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc, const ResolveBuffers &rb,
                   uint64_t base_offset, uint32_t max_candidates, uint64_t *host_result, uint64_t *dev_result, uint32_t max_rank,
                   uint64_t seq, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+// does the single-launch kernel suit this ROM (small enough) and this device?
+bool fused_applies(const MmGeom &g);
+// the same tail as a kernel of its own behind launch_filter (mm_scan_tail): results, header and `seq` as launch_fused
+void launch_tail(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc, const ResolveBuffers &rb,
+                 uint64_t base_offset, uint32_t max_candidates, uint64_t *host_result, uint64_t *dev_result, uint32_t max_rank,
+                 uint64_t seq, hipEvent_t stop = nullptr);
 // the scan's second phase (only when mm_resolve left candidates over): mm_resolve2 + mm_hard_resolve
 void launch_leftovers(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const ResolveBuffers &rb, uint64_t base_offset);
 size_t hard_scratch_bytes();
@@ -83,14 +91,13 @@ size_t rank_partials_bytes(uint32_t max_n);
 // the candidate-free forward engine (mm_dense.h): sizes and buffers
 struct DenseGeom {
    uint64_t ndom;
-   uint32_t tpd;
-   uint32_t nsup;
-   uint32_t bpd;             // single-pass engine (mm_forward.h): batches per domain
-   size_t status_bytes;      //   ... its ticket + look-back words, at the start of `maps`
-   size_t maps_bytes, supmaps_bytes, supentry_bytes, entry_bytes;
+   uint32_t tpd;             // tiles per domain
+   uint32_t bpd;             // batches (of MM_FWD_BATCH tiles) per domain
+   size_t status_bytes;      // ticket + look-back words, at the start of `maps`
+   size_t maps_bytes;        // ... followed by one published map per batch
 };
 struct DenseBuffers {
-   uint8_t *maps, *supmaps, *supentry, *entry;
+   uint8_t *maps;
    uint64_t *out;            // MM_CAND_LISTS lists of out_cap / MM_CAND_LISTS values
    uint64_t out_cap;
    unsigned long long *ctrl; // list counters at MM_CTRL_LISTS

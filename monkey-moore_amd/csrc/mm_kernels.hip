@@ -1,3 +1,4 @@
+// SPDX-License-Identifier: GPL-3.0-or-later
 // mm_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the relative-search engine.
 //
 // Pipeline of one scan (all launches on one stream, one host wait at the end):
@@ -856,7 +857,6 @@ __global__ __launch_bounds__(256) void mm_filter_u16(MmFilterArgs a)
 }
 
 #include "mm_tiles.h"
-#include "mm_dense.h"
 #include "mm_forward.h"
 #include "mm_fused.h"
 
@@ -1129,20 +1129,11 @@ const Tuning &tuning()
       k.filter_gps_comm = (uint32_t)number("MMOORE_FILTER_GPS_COMM", 7);
       k.filter_groups_per_span = (uint32_t)number("MMOORE_FILTER_GPS", 8);
       k.resolve_blocks = (unsigned)number("MMOORE_RESOLVE_BLOCKS", 4096);
+      k.tail_blocks = (unsigned)number("MMOORE_TAIL_BLOCKS", 2048);
       k.max_candidates = (uint32_t)number("MMOORE_MAX_CANDIDATES", 262144);
       return k;
    }();
    return t;
-}
-
-// MMOORE_DENSE_V1=1: the round-1 two-pass forward engine (mm_dense.h) instead of mm_forward.h (A/B runs, cross-checks)
-static bool forward_v1()
-{
-   static const bool on = [] {
-      const char *v = getenv("MMOORE_DENSE_V1");
-      return v && *v == '1';
-   }();
-   return on;
 }
 
 // Picks the SWAR conditions of a plan: an anchor position iA (condition 0) and up to three
@@ -1404,6 +1395,33 @@ static unsigned fused_resident_blocks()
    return blocks;
 }
 
+static void fill_tail_args(MmFusedArgs &a, const ResolveBuffers &rb, uint64_t base_offset, uint32_t max_candidates,
+                           uint64_t *host_result, uint64_t *dev_result, uint32_t max_rank, uint64_t seq)
+{
+   a.out_cap = rb.out_cap; a.out = rb.out; a.tiles_walked = rb.ctrl + MM_CTRL_TILES;
+   a.base_offset = base_offset; a.max_candidates = max_candidates;
+   a.mid_off = rb.mid_off; a.mid_hi = rb.mid_hi; a.mid_set = rb.mid_set; a.mid_slot = rb.mid_slot;
+   a.mid_count = reinterpret_cast<unsigned int *>(rb.ctrl + MM_CTRL_MID);
+   a.flag_bits = nullptr;
+   a.ctrl = rb.ctrl; a.host_result = host_result; a.dev_result = dev_result; a.max_rank = max_rank;
+   a.ctrl_words = (uint32_t)(ctrl_bytes() / sizeof(unsigned long long));
+   a.seq = seq;
+   a.timeout_ticks = 20000000;                    // 200 ms of the 100 MHz wall clock
+}
+
+// ROMs up to this size take the single-launch kernel (tools/fused_probe.py: 128 KiB .. 2 MiB 11 us
+// on the device against 20; 16 MiB with candidates 32 against 27; 4 GiB 782 against 738)
+static uint64_t fused_max_bytes()
+{
+   static const uint64_t v = [] {
+      const char *e = getenv("MMOORE_FUSED_MAX_MIB");
+      return (uint64_t)(e && *e ? atol(e) : 4) << 20;
+   }();
+   return v;
+}
+
+bool fused_applies(const MmGeom &g) { return g.nbytes <= fused_max_bytes() && fused_resident_blocks() != 0; }
+
 bool launch_fused(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc, const ResolveBuffers &rb,
                   uint64_t base_offset, uint32_t max_candidates, uint64_t *host_result, uint64_t *dev_result, uint32_t max_rank,
                   uint64_t seq, hipEvent_t start, hipEvent_t stop)
@@ -1414,22 +1432,13 @@ bool launch_fused(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, cons
    }
    MmFusedArgs a;
    const uint64_t ngroups = g.nbytes / 4096;
-   // spans of 8 groups for ROMs that take several rounds of the grid; small ROMs are cut finer so
-   // that every resident wave has a span (a 128 KiB ROM: 32 waves of 4 KiB instead of 4 of 32 KiB)
+   // small ROMs are cut fine so that every wave has a span (a 128 KiB ROM: 32 waves of 4 KiB instead of 4 of 32 KiB)
    uint32_t gps = filter_groups_per_span();
    while (gps > 1 && ngroups / gps < (uint64_t)resident * MM_WAVES) {
       gps >>= 1;
    }
    fill_filter_args(a, g, pl, fc, rb.cand, rb.ctrl, rb.cand_cap, gps);
-   a.out_cap = rb.out_cap; a.out = rb.out; a.tiles_walked = rb.ctrl + MM_CTRL_TILES;
-   a.base_offset = base_offset; a.max_candidates = max_candidates;
-   a.mid_off = rb.mid_off; a.mid_hi = rb.mid_hi; a.mid_set = rb.mid_set; a.mid_slot = rb.mid_slot;
-   a.mid_count = reinterpret_cast<unsigned int *>(rb.ctrl + MM_CTRL_MID);
-   a.flag_bits = nullptr;
-   a.ctrl = rb.ctrl; a.host_result = host_result; a.dev_result = dev_result; a.max_rank = max_rank;
-   a.ctrl_words = (uint32_t)(ctrl_bytes() / sizeof(unsigned long long));
-   a.seq = seq;
-   a.timeout_ticks = 20000000;                    // 200 ms of the 100 MHz wall clock
+   fill_tail_args(a, rb, base_offset, max_candidates, host_result, dev_result, max_rank, seq);
    a.has_edge = a.edge_first * 16 < g.nbytes ? 1u : 0u;
    const uint64_t spans = (a.ngroups + gps - 1) / gps;
    const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((spans + MM_WAVES - 1) / MM_WAVES, resident));
@@ -1437,6 +1446,20 @@ bool launch_fused(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, cons
       launch_timed(mm_scan_fused<decltype(elem)::value, decltype(shape)::value>, dim3(blocks), dim3(64 * MM_WAVES), st, start, stop, a);
    });
    return true;
+}
+
+// mm_scan_tail behind the streaming kernel: every candidate resolved, ranked and published, header and
+// completion flag written -- one launch in place of mm_resolve + mm_rank_count + mm_rank_scatter
+void launch_tail(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc, const ResolveBuffers &rb,
+                 uint64_t base_offset, uint32_t max_candidates, uint64_t *host_result, uint64_t *dev_result, uint32_t max_rank,
+                 uint64_t seq, hipEvent_t stop)
+{
+   MmFusedArgs a;
+   fill_filter_args(a, g, pl, fc, rb.cand, rb.ctrl, rb.cand_cap, filter_groups_per_span());
+   fill_tail_args(a, rb, base_offset, max_candidates, host_result, dev_result, max_rank, seq);
+   a.has_edge = 0;
+   // one wave per candidate for up to 8 K of them in one round (the count is only known on the device)
+   launch_timed(mm_scan_tail, dim3(tuning().tail_blocks), dim3(64 * MM_WAVES), st, nullptr, stop, a);
 }
 
 static MmTileArgs tile_args(const MmGeom &g, const mmh_plan_desc &pl)
@@ -1514,21 +1537,11 @@ DenseGeom dense_geom(const MmGeom &g, uint64_t listed_domains)
       int64_t nv = mm_domain_nv(g, 0, p);                 // block 0 is the largest kind of block
       most = nv > most ? nv : most;
    }
-   d.tpd = (uint32_t)((most + MM_TILE - 1) / MM_TILE);
-   d.nsup = (d.tpd + MM_SUPER - 1) / MM_SUPER;
+   d.tpd = (uint32_t)((most + MM_FWD_TILE - 1) / MM_FWD_TILE);
    d.bpd = (d.tpd + MM_FWD_BATCH - 1) / MM_FWD_BATCH;
-   if (!forward_v1()) {
-      // single-pass engine: [ticket, pad][one look-back word per batch] then one map per batch, all in `maps`
-      d.status_bytes = (((size_t)d.ndom * d.bpd + 2) * sizeof(unsigned long long) + 255) & ~(size_t)255;
-      d.maps_bytes = d.status_bytes + (size_t)d.ndom * d.bpd * MM_MAXD;
-      d.supmaps_bytes = d.supentry_bytes = d.entry_bytes = 0;
-      return d;
-   }
-   d.status_bytes = 0;
-   d.maps_bytes = (size_t)d.ndom * d.tpd * MM_MAXD;
-   d.supmaps_bytes = (size_t)d.ndom * d.nsup * MM_MAXD;
-   d.supentry_bytes = (size_t)d.ndom * d.nsup;
-   d.entry_bytes = (size_t)d.ndom * d.tpd;
+   // [ticket, pad][one look-back word per batch], then one map per batch
+   d.status_bytes = (((size_t)d.ndom * d.bpd + 2) * sizeof(unsigned long long) + 255) & ~(size_t)255;
+   d.maps_bytes = d.status_bytes + (size_t)d.ndom * d.bpd * (g.L > MM_MAXD ? MMH_MAX_KEYWORD : MM_MAXD);
    return d;
 }
 
@@ -1542,7 +1555,7 @@ static void launch_forward(hipStream_t st, const MmGeom &g, const mmh_plan_desc 
    const uint64_t nbatches = dg.ndom * dg.bpd;
    a.ticket = reinterpret_cast<unsigned long long *>(db.maps);
    a.status = a.ticket + 2;
-   a.agg = db.maps + dg.status_bytes;
+   a.agg = db.maps + dg.status_bytes;                 // [batches][MM_MAXD or MMH_MAX_KEYWORD] (dense_geom sized it)
    a.out = db.out; a.list_count = db.ctrl + MM_CTRL_LISTS; a.list_cap = db.out_cap / MM_CAND_LISTS;
    a.base_offset = base_offset;
    // the table-driven jump path: 8-bit elements, first compare against an element 1..4 to the left
@@ -1566,31 +1579,28 @@ static void launch_forward(hipStream_t st, const MmGeom &g, const mmh_plan_desc 
    int device = 0, cus = 256;
    (void)hipGetDevice(&device);
    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-   const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nbatches + MM_WAVES - 1) / MM_WAVES, (uint64_t)cus * 5));
-   hipLaunchKernelGGL(mm_forward, dim3(blocks), dim3(64 * MM_WAVES), 0, st, a);
+   const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nbatches + MM_WAVES - 1) / MM_WAVES, (uint64_t)cus * 6));
+   const bool wide = pl.L > MM_MAXD;                  // more phases than the narrow maps hold
+   if (pl.elem_bytes == 1) {
+      if (wide) {
+         hipLaunchKernelGGL((mm_forward<1, MMH_MAX_KEYWORD>), dim3(blocks), dim3(64 * MM_WAVES), 0, st, a);
+      }
+      else {
+         hipLaunchKernelGGL((mm_forward<1, MM_MAXD>), dim3(blocks), dim3(64 * MM_WAVES), 0, st, a);
+      }
+   }
+   else if (wide) {
+      hipLaunchKernelGGL((mm_forward<2, MMH_MAX_KEYWORD>), dim3(blocks), dim3(64 * MM_WAVES), 0, st, a);
+   }
+   else {
+      hipLaunchKernelGGL((mm_forward<2, MM_MAXD>), dim3(blocks), dim3(64 * MM_WAVES), 0, st, a);
+   }
 }
 
 void launch_dense(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const DenseGeom &dg, const DenseBuffers &db,
                   uint64_t base_offset, const uint32_t *dom_list)
 {
-   if (!forward_v1()) {
-      launch_forward(st, g, pl, dg, db, base_offset, dom_list);
-      return;
-   }
-   MmDenseArgs a;
-   a.t = tile_args(g, pl);
-   a.ndom = dg.ndom; a.tpd = dg.tpd; a.nsup = dg.nsup; a.dom_list = dom_list;
-   a.maps = db.maps; a.supmaps = db.supmaps; a.supentry = db.supentry; a.entry = db.entry;
-   a.out = db.out; a.list_count = db.ctrl + MM_CTRL_LISTS; a.list_cap = db.out_cap / MM_CAND_LISTS;
-   a.base_offset = base_offset;
-   const uint64_t ntiles = dg.ndom * dg.tpd;
-   const unsigned tile_blocks = (unsigned)std::min<uint64_t>((ntiles + MM_WAVES - 1) / MM_WAVES, 4096);
-   const unsigned sup_blocks = (unsigned)std::min<uint64_t>(dg.ndom * dg.nsup, 16384);
-   hipLaunchKernelGGL(mm_dense_maps, dim3(tile_blocks), dim3(64 * MM_WAVES), 0, st, a);
-   hipLaunchKernelGGL(mm_dense_super<0>, dim3(sup_blocks), dim3(64), 0, st, a);
-   hipLaunchKernelGGL(mm_dense_entries, dim3((unsigned)std::min<uint64_t>(dg.ndom, 16384)), dim3(64), 0, st, a);
-   hipLaunchKernelGGL(mm_dense_super<1>, dim3(sup_blocks), dim3(64), 0, st, a);
-   hipLaunchKernelGGL(mm_dense_emit, dim3(tile_blocks), dim3(64 * MM_WAVES), 0, st, a);
+   launch_forward(st, g, pl, dg, db, base_offset, dom_list);
 }
 
 void launch_chain_seq(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, uint64_t *out,

@@ -1,3 +1,4 @@
+// SPDX-License-Identifier: GPL-3.0-or-later
 // mm_multi.hip -- the multi-GPU half of the C ABI: block-aligned partitions and the RCCL
 // gather of the per-GPU offset lists over xGMI.
 //

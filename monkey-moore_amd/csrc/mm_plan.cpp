@@ -1,3 +1,4 @@
+// SPDX-License-Identifier: GPL-3.0-or-later
 // mm_plan.cpp -- host-side pattern-plan builder (no device code).
 //
 // Turns a keyword (or value-scan vector) into the flattened mmh_plan_desc the

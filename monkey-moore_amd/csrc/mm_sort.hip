@@ -1,3 +1,4 @@
+// SPDX-License-Identifier: GPL-3.0-or-later
 // mm_sort.hip -- ordering of LONG match lists on the device.
 //
 // The reference ends every search with std::sort over its results (search_engine.cpp:193-197).

@@ -1,3 +1,4 @@
+// SPDX-License-Identifier: GPL-3.0-or-later
 // mm_tiles.h -- exact emulation of the reference's skip chain, tile by tile.
 // Included by mm_kernels.hip (device code only).
 //
@@ -42,7 +43,8 @@
 
 constexpr int MM_TILE = 2048;                 // positions per tile
 constexpr int MM_WAVES = 4;                   // waves per workgroup in the tile kernels
-constexpr int MM_MAXD = MMH_MAX_KEYWORD;      // bytes of a stored tile map
+constexpr int MM_MAXD = MM_RESOLVER_MAX_KEYWORD;   // bytes of a stored phase map in the per-candidate machinery: keywords of up to 32
+                                              // symbols (D <= 31, phase sets in one 32-bit word); longer ones go to the forward engine
 constexpr int MM_FAST_STEPS = 2;              // look-back windows of mm_resolve: <= 256, then <= 512 positions
 constexpr int MM_MID_CHUNK = 512;             // mm_resolve2: a workgroup's waves map chunks of this many positions in parallel
 constexpr int MM_MID_CAP = 2048;              // candidates mm_resolve hands to mm_resolve2 per scan
@@ -61,11 +63,12 @@ struct MmPlanLds {
    uint8_t skip8[512];                      // dense bad-character table, 8-bit elements
 };
 
-// a wave's working set for windows of up to NPOS positions
-template <int NPOS>
+// a wave's working set for windows of up to NPOS positions of elements of up to ELEM bytes
+template <int NPOS, int ELEM = 2>
 struct MmWaveLdsT {
    static constexpr int kPositions = NPOS;
-   uint32_t tile[((NPOS + MMH_MAX_KEYWORD + 1) * 2 + 16) / 4];
+   uint32_t tile_pad[1];                     // tile[-1]: the forward engine reads the dword in front of any tile dword unconditionally
+   uint32_t tile[((NPOS + MMH_MAX_KEYWORD + 1) * ELEM + 16 + 3) / 4];
    uint8_t jump[NPOS + 8];                   // J of every position of the window (| MM_JUMP_MATCH); the forward engine
                                              // stores four at a time and shifts the array by 0..3 bytes for that
    uint8_t gmap[NPOS / 64][MM_MAXD];         // phase map of every group of 64 positions (long windows)
@@ -251,9 +254,10 @@ __device__ __forceinline__ bool mm_tile_matches(const MmTileArgs &a, const MmPla
 // Steps 1 and 2 of the header: stage positions [lo, lo + npos) of the domain at byte `start`
 // and leave the jump of every position (| MM_JUMP_MATCH where the compare loop matched) in
 // W.jump.  Returns the staged tile's first byte.
+// padded: position q's jump goes to W.jump[q + 4 (q / 32)] (the forward engine's bank-conflict-free layout)
 template <class WL>
 __device__ __forceinline__ const uint8_t *mm_tile_jumps(const MmTileArgs &a, const MmPlanLds &P, WL &W, uint64_t start,
-                                                        int64_t lo, int npos, int lane)
+                                                        int64_t lo, int npos, int lane, bool padded = false)
 {
    const int mis = mm_stage_tile(a, W, start, lo, npos, lane);
    mm_wave_sync();
@@ -307,7 +311,7 @@ __device__ __forceinline__ const uint8_t *mm_tile_jumps(const MmTileArgs &a, con
       }
       if (live) {
          // (a jump below 1 cannot come out of a plan of mm_plan.cpp; the walk below must never stall)
-         W.jump[q] = (uint8_t)((J & (MM_JUMP_MATCH - 1)) == 0 ? 1 : J);
+         W.jump[padded ? q + 4 * (q >> 5) : q] = (uint8_t)((J & (MM_JUMP_MATCH - 1)) == 0 ? 1 : J);
       }
       c = cn;
       pv = pn;
@@ -440,12 +444,10 @@ struct MmResolveLds {
    unsigned int walked;                      // windows mapped by this workgroup
 };
 
-// a word another workgroup may have written during this launch (candidate lists, their counters):
-// read past this CU's L1 (sc1) -- cdna guideline 16; costs nothing where the word was written
-// by an earlier launch
+// (the plain resolver kernels read the candidate lists of an EARLIER launch: ordinary loads)
 __device__ __forceinline__ unsigned long long mm_load_shared(const unsigned long long *p)
 {
-   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+   return *p;
 }
 
 // The filter's MM_CAND_LISTS (= 64 = one per lane) lists get one compact numbering: candidate

@@ -1,3 +1,4 @@
+// SPDX-License-Identifier: GPL-3.0-or-later
 // matcher_state.hpp -- host-side state shared by the MonkeyMoore<Ty> / SearchEngine<T>
 // facade (not installed; the public headers only forward-declare MatcherState).
 #ifndef MMOORE_AMD_MATCHER_STATE_HPP

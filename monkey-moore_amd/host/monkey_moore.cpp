@@ -1,3 +1,4 @@
+// SPDX-License-Identifier: GPL-3.0-or-later
 // monkey_moore.cpp -- MonkeyMoore<Ty> on the MI355X engine (C++17 facade over the C ABI).
 //
 // Mirrors the behaviour of the reference's src/core/monkey_moore.cpp behind the same

@@ -1,3 +1,4 @@
+// SPDX-License-Identifier: GPL-3.0-or-later
 // search_engine.cpp -- SearchEngine<T>::run on the MI355X engine.
 //
 // Replaces the reference's block dispatcher (src/core/search_engine.cpp:23-216): the file

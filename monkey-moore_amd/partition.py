@@ -1,3 +1,4 @@
+# SPDX-License-Identifier: GPL-3.0-or-later
 """Test double of the multi-GPU plumbing.  The product path is in the C ABI (csrc/mm_multi.hip:
 mmh_partition, mmh_comm_*, mmh_gather_start / _finish, mmh_scan_multi -- RCCL called from the
 library itself, lists sent from HBM).  This module restates the same protocol on top of

@@ -1,3 +1,4 @@
+# SPDX-License-Identifier: GPL-3.0-or-later
 """Synthetic ROMs for tests and bench.py.
 
 A ROM is defined by (seed, nbytes, global base offset) plus a list of edits:

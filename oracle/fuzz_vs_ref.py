@@ -1,4 +1,5 @@
 #!/usr/bin/env python3
+# SPDX-License-Identifier: GPL-3.0-or-later
 """Differential fuzz: oracle/liboracle.so (restatement) vs oracle/_ref/libmmref.so
 (the unmodified reference).  Runs only where the reference was compiled
 (this container).  Usage: python oracle/fuzz_vs_ref.py [trials] [seed]

@@ -1,4 +1,5 @@
 #!/usr/bin/env python3
+# SPDX-License-Identifier: GPL-3.0-or-later
 """Generate the committed golden fixtures under tests/golden/.
 
 Runs ONLY in the build container (needs oracle/_ref/libmmref.so, i.e. the

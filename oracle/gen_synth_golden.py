@@ -1,4 +1,5 @@
 #!/usr/bin/env python3
+# SPDX-License-Identifier: GPL-3.0-or-later
 """Golden vectors for the SYNTHETIC bench ROMs: what the compiled reference
 (oracle/_ref, the unmodified sources of /root/reference) reports on 16 MiB instances of the
 BASELINE configurations, with the SHA-256 of the regenerated buffer.

@@ -1,4 +1,5 @@
 #!/usr/bin/env python3
+# SPDX-License-Identifier: GPL-3.0-or-later
 """>= 10 000 tiny differential vectors (inputs <= 1 KiB) from the compiled reference
 (oracle/_ref, the unmodified sources of /root/reference), across modes (plain, wildcard, mixed
 case, custom sequence, value scan), widths, endianness and block sizes -- weighted towards

@@ -1,3 +1,4 @@
+/* SPDX-License-Identifier: GPL-3.0-or-later */
 /*
  * mm_oracle.c -- CPU restatement of the monkey-moore relative-search hot path.
  *

@@ -1,3 +1,4 @@
+// SPDX-License-Identifier: GPL-3.0-or-later
 // ref_shim.cpp -- extern "C" entry points over the UNMODIFIED reference core.
 //
 // TEST INFRASTRUCTURE ONLY.  This file is ours; it is compiled together with

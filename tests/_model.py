@@ -1,3 +1,4 @@
+# SPDX-License-Identifier: GPL-3.0-or-later
 """Pure-Python model of what the HIP kernels compute from an mmh_plan_desc.
 
 Used by the CPU test-suite to check, without a GPU, (a) the host plan builder

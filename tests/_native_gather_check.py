@@ -1,3 +1,4 @@
+# SPDX-License-Identifier: GPL-3.0-or-later
 """Run by test_gpu_multi.py::test_native_gather_next_to_torch_nccl in a fresh process: bench.py's
 N > 1 set-up with a world of one."""
 import os

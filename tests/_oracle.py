@@ -1,3 +1,4 @@
+# SPDX-License-Identifier: GPL-3.0-or-later
 """ctypes bindings for the test-only checkers under oracle/.
 
 `Oracle`  -> oracle/liboracle.so       (our C restatement, mm_oracle.c)

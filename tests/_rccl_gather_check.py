@@ -1,3 +1,4 @@
+# SPDX-License-Identifier: GPL-3.0-or-later
 """Run by test_gpu_parity.py::test_offset_gather_on_rccl_world_of_one in a fresh process."""
 import os
 import sys

@@ -1,3 +1,4 @@
+// SPDX-License-Identifier: GPL-3.0-or-later
 // facade_tests.cpp -- the reference's Catch2 suites (tests/test_monkey_moore.cpp,
 // tests/test_search_engine.cpp) replayed against the MI355X facade through the SAME public
 // API (MonkeyMoore<T>, SearchEngine<T>).  Catch2 is not installed in the image, so this is a

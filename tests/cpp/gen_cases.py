@@ -1,4 +1,5 @@
 #!/usr/bin/env python3
+# SPDX-License-Identifier: GPL-3.0-or-later
 """Turns tests/golden/kat_*.json (the reference's own known-answer vectors) into a C++
 include for tests/cpp/facade_tests.cpp.  Usage: gen_cases.py <out.inc>"""
 import json

@@ -1,3 +1,4 @@
+// SPDX-License-Identifier: GPL-3.0-or-later
 // partition_tests.cpp -- the multi-GPU partition rule of the C ABI (mmh_partition), host only.
 // Replaces what the reference's compute_search_blocks + dispatcher guarantee together
 // (src/core/search_engine.cpp:66-188, :218-253): every block belongs to exactly one worker and

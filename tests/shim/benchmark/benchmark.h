@@ -1,3 +1,4 @@
+// SPDX-License-Identifier: GPL-3.0-or-later
 // Minimal stand-in for the part of google-benchmark the reference's benchmarks/bench_search.cpp
 // uses: State (range, range-for, iterations, SetBytesProcessed), DoNotOptimize,
 // BENCHMARK_TEMPLATE(...)->Name()->RangeMultiplier()->Range(), BENCHMARK_MAIN.  The library is

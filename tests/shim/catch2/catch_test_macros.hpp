@@ -1,3 +1,4 @@
+// SPDX-License-Identifier: GPL-3.0-or-later
 // Minimal stand-in for the part of Catch2 v3 the reference's tests use: TEST_CASE,
 // nested SECTION, GENERATE, REQUIRE / CHECK / FAIL, REQUIRE_THAT(v, Equals(vec)),
 // REQUIRE_THROWS_AS, INFO / CAPTURE.  Catch2 is not in the image; this lets the reference's own

@@ -1,3 +1,4 @@
+// SPDX-License-Identifier: GPL-3.0-or-later
 // Catch::Matchers::Equals(std::vector) of the Catch2 stand-in (tests/shim/catch2/catch_test_macros.hpp)
 #ifndef MM_SHIM_CATCH_MATCHERS_VECTOR_HPP
 #define MM_SHIM_CATCH_MATCHERS_VECTOR_HPP

@@ -1,3 +1,4 @@
+# SPDX-License-Identifier: GPL-3.0-or-later
 """The C++17 facade (include/mmoore: MonkeyMoore<T>, SearchEngine<T>) over the C ABI.
 
 CPU part: it builds, exports the reference's symbol set and refuses to run without a GPU.

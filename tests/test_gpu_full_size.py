@@ -1,3 +1,4 @@
+# SPDX-License-Identifier: GPL-3.0-or-later
 """BASELINE.json's GPU configurations at their full sizes, bit-exact against the oracle
 (which is run over all host cores on block-aligned slices), plus size-independent
 properties.  Needs a real MI355X and ~10 GiB of host memory."""

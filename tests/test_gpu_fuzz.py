@@ -1,3 +1,4 @@
+# SPDX-License-Identifier: GPL-3.0-or-later
 """Seeded differential fuzz of the HIP path against the oracle at sizes that exercise the span
 kernels, the three resolver levels and the dense fallback: random keywords (wildcards, mixed
 case -> the wildcard loop, custom character sequences, value scans), alphabets from 2 symbols

@@ -1,3 +1,4 @@
+# SPDX-License-Identifier: GPL-3.0-or-later
 """The multi-GPU half of the C ABI (csrc/mm_multi.hip) on the one GPU this suite has: a
 communicator of one.  Everything a real 8-rank run does is exercised except the wire --
 communicator bring-up through librccl, the all-gather sent from the device-side copy of the

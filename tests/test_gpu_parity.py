@@ -1,3 +1,4 @@
+# SPDX-License-Identifier: GPL-3.0-or-later
 """Parity of the HIP path (through the C ABI) with the oracle and the golden
 vectors.  Needs a real MI355X: run with `pytest -m gpu`.  Offsets are compared
 bit-exactly (integer work: no tolerance)."""
@@ -272,7 +273,56 @@ def test_keyword_lengths(mm, gpu_engine, oracle, L):
     assert len(want) >= 20 or L == 2
     assert gpu_engine.scan(plan).tolist() == oracle.search(oplan, rom).tolist()
     with pytest.raises(mm.MMError):
-        mm.plan_relative(1, [97 + (i % 5) for i in range(33)])   # longer than MMH_MAX_KEYWORD: refused, loudly
+        mm.plan_relative(1, [97 + (i % 5) for i in range(129)])   # longer than MMH_MAX_KEYWORD: refused, loudly
+
+
+@pytest.mark.parametrize("L", [33, 64, 127, 128])
+@pytest.mark.parametrize("path", ["simple", "wildcard", "mixed-case"])
+@pytest.mark.parametrize("elem,be", [(1, False), (2, True)])
+def test_long_keywords(mm, gpu_engine, oracle, L, path, elem, be):
+    """Keywords beyond 32 symbols, up to the 128 the reference's char-sized tables allow
+    (monkey_moore.cpp:250-253): D = L - 1 phases no longer fit the resolvers' 32-bit phase sets, so
+    they run on the forward engine (phase maps of 128 bytes, lane e and lane e + 64).  Both reference
+    loops, both element sizes, engine and whole-buffer semantics, against the oracle."""
+    rng = np.random.default_rng(1000 + L + 7 * elem)
+    wildcard = 0
+    if path == "simple":
+        kw = [int(c) for c in rng.integers(97, 123, L)]
+        vals = list(kw)
+    elif path == "wildcard":
+        wildcard = ord("*")
+        kw = [int(c) for c in rng.integers(97, 123, L)]
+        for i in rng.choice(np.arange(1, L - 1), size=max(2, L // 9), replace=False):
+            kw[int(i)] = wildcard
+        vals = [None if c == wildcard else c for c in kw]
+    else:
+        wildcard = ord("*")
+        kw = [int(c) for c in rng.integers(97, 123, L)]
+        for i in rng.choice(np.arange(0, L), size=max(2, L // 7), replace=False):
+            kw[int(i)] -= 32                                  # upper case: the minority case becomes wildcards
+        vals = [None if c < 97 else c for c in kw]
+    n = (2 << 20) + 4099
+    rom = _random_rom_with_plants(rng, n, elem, vals, be, nplants=60)
+    # low-entropy stretches: short jumps, chains that do not merge
+    rom[300000:400000] = rng.integers(0, 3, 100000).astype(np.uint8) + 0x40
+    rom[700000:760000] = 0x41
+    gpu_engine.upload(rom)
+    plan, oplan = mm.plan_relative(elem, kw, wildcard), oracle.plan(elem, kw, wildcard)
+    for block in (524288, 65536 + 2 * elem):
+        want = oracle.engine(oplan, rom, block, be)
+        got = gpu_engine.scan(plan, block_bytes=block, big_endian=be)
+        assert gpu_engine.counters()["path"] == 3
+        assert got.tolist() == want.tolist(), (L, path, elem, block)
+        if block == 524288:
+            # (of the 60 plants the reference itself reports few when wildcards cap its skips: its chain
+            # walks past most of them -- SURVEY fact 1; what matters is that the lists are identical)
+            assert len(want) >= (10 if path == "simple" else 1)
+    gpu_engine.set_engine(1)                                   # and the sequential engine agrees
+    assert gpu_engine.scan(plan, block_bytes=524288, big_endian=be).tolist() == oracle.engine(oplan, rom, 524288, be).tolist()
+    gpu_engine.set_engine(0)
+    if not be:
+        data = rom[: (n // elem) * elem].view(np.uint8 if elem == 1 else "<u2")
+        assert gpu_engine.scan(plan).tolist() == oracle.search(oplan, data).tolist()
 
 
 def test_pattern_without_swar_key_uses_dense_engine(mm, gpu_engine, oracle):

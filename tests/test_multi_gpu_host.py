@@ -1,3 +1,4 @@
+# SPDX-License-Identifier: GPL-3.0-or-later
 """The N > 1 path on CPU: 2 processes, gloo.  Each rank takes its block-aligned partition
 (monkey-moore_amd/partition.py, the code bench.py uses), produces its offsets (with the
 oracle here -- there is no GPU in this suite) and the lists are gathered to rank 0, which

@@ -1,3 +1,4 @@
+# SPDX-License-Identifier: GPL-3.0-or-later
 """CPU tests of the product's host logic and of the device ALGORITHM (via the
 Python model in tests/_model.py), against the golden vectors and the oracle.
 No GPU needed."""
@@ -45,7 +46,7 @@ def test_no_gpu_means_loud_failure(mm):
 
 
 def test_plan_rejects_what_the_reference_rejects(mm):
-    for args in ((1, "a"), (1, "*a", ord("*")), (1, [0x3042, 0x41]), (1, "x" * 33), (1, "***", ord("*"))):
+    for args in ((1, "a"), (1, "*a", ord("*")), (1, [0x3042, 0x41]), (1, "x" * 129), (1, "***", ord("*"))):
         with pytest.raises(mm.MMError) as e:
             mm.plan_relative(*args)
         assert e.value.code == mm.MMH_E_PLAN

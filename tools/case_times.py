@@ -1,3 +1,4 @@
+# SPDX-License-Identifier: GPL-3.0-or-later
 """Dev probe: the reference benchmark's keyword shapes (bench_search cases) on an HBM-resident
 random buffer -- stage timings and which engine path each one takes."""
 import sys, os

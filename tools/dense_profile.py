@@ -1,3 +1,4 @@
+# SPDX-License-Identifier: GPL-3.0-or-later
 """Dev probe: the forward (dense) engine alone, enough launches for rocprofv3 averages.
    python3 tools/dense_profile.py [plain|wild] [scans]"""
 import sys, os, time

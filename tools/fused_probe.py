@@ -1,3 +1,4 @@
+# SPDX-License-Identifier: GPL-3.0-or-later
 """Dev probe: the fused scan kernel against the plain kernels (MMOORE_FUSED=0): per-scan wall time,
 device time, parity of every single scan's list, on the bench ROM and on small ROMs."""
 import sys, os, subprocess, time

@@ -1,3 +1,4 @@
+# SPDX-License-Identifier: GPL-3.0-or-later
 """Dev probe: streaming-kernel time vs launch geometry (MMOORE_FILTER_BLOCKS / MMOORE_FILTER_GPS)."""
 import sys, os, subprocess
 if len(sys.argv) > 1 and sys.argv[1] == "child":

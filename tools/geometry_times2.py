@@ -1,3 +1,4 @@
+# SPDX-License-Identifier: GPL-3.0-or-later
 """Dev probe: streaming-kernel time vs launch geometry with a workgroup slot per CU left free
 (what a multi-rank communicator makes the filter do, MMOORE_FILTER_BLOCKS_COMM)."""
 import sys, os, subprocess

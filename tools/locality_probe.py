@@ -1,3 +1,4 @@
+# SPDX-License-Identifier: GPL-3.0-or-later
 """Dev probe (run under tools/trace_kernels.sh): ~4 K candidates spread over 4 GiB vs packed into 64 MiB."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,3 +1,4 @@
+# SPDX-License-Identifier: GPL-3.0-or-later
 """Dev probe: streaming-kernel time of the C2 keyword with 1..4 SWAR conditions (MMOORE_FILTER_MAXCOND)."""
 import sys, os, subprocess
 if len(sys.argv) > 1:

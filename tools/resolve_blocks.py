@@ -1,3 +1,4 @@
+# SPDX-License-Identifier: GPL-3.0-or-later
 """Dev probe: post-filter time of scans vs the resolver's grid (MMOORE_RESOLVE_BLOCKS)."""
 import sys, os, subprocess
 if len(sys.argv) > 1 and sys.argv[1] == "child":
