@@ -687,7 +687,7 @@ int sort_to_host(mmh_ctx *c, const uint64_t *keys, uint64_t n, std::vector<uint6
    return MMH_OK;
 }
 
-// The candidate-free forward engine (mm_dense.h).  Matches land in MM_CAND_LISTS device
+// The candidate-free forward engine (mm_forward.h).  Matches land in MM_CAND_LISTS device
 // lists; they are fetched and ordered on the host (dense results are long lists anyway).
 int run_dense(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, uint64_t base_offset, std::vector<uint64_t> *found,
               bool *grew, const uint32_t *dom_list = nullptr, uint64_t listed_domains = 0)

@@ -88,7 +88,7 @@ size_t hard_cap();
 size_t mid_cap();
 size_t ctrl_bytes();
 size_t rank_partials_bytes(uint32_t max_n);
-// the candidate-free forward engine (mm_dense.h): sizes and buffers
+// the candidate-free forward engine (mm_forward.h): sizes and buffers
 struct DenseGeom {
    uint64_t ndom;
    uint32_t tpd;             // tiles per domain

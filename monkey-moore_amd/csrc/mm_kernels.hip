@@ -1,7 +1,7 @@
 // SPDX-License-Identifier: GPL-3.0-or-later
 // mm_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the relative-search engine.
 //
-// Pipeline of one scan (all launches on one stream, one host wait at the end):
+// Pipeline of one scan (one stream; the host polls a word in pinned memory for the end):
 //
 //   mm_filter_u8 / mm_filter_u16   HBM-bound streaming pass over the whole ROM.
 //        Coalesced 16 B/lane loads; two stages: the first two SWAR conditions
@@ -10,21 +10,27 @@
 //        re-read; the survivors -- CANDIDATES: positions where the reference's
 //        compare loop may report a match IF its chain visits them -- are
 //        appended wave-aggregated to 64 lists.
-//   mm_resolve  (mm_tiles.h)       one wavefront per candidate.  The reference
-//        is not a complete matcher: it only tests the positions its skip chain
-//        visits.  The resolver verifies the compare loop at the
-//        candidate and decides "is it on the chain of its domain" exactly, by
-//        pulling the set of acceptable chain phases (phase = position mod (L-1))
-//        back through the phase maps of one or two short windows until the set
-//        is empty, full, or the domain start (phase 0) is reached.
-//   mm_rank_count / mm_rank_scatter   order the matches ascending, straight into
-//        pinned host memory together with the scan's counters.
-//   second phase, only when mm_resolve left candidates over (host decides from the
-//   published counters): mm_resolve2 -> mm_hard_resolve (mm_tiles.h) -> ordering again.
+//   mm_scan_tail  (mm_fused.h, mm_tiles.h)   one wavefront per candidate.  The
+//        reference is not a complete matcher: it only tests the positions its
+//        skip chain visits.  The wave verifies the compare loop
+//        at the candidate and decides "is it on the chain of its domain" exactly,
+//        by pulling the set of acceptable chain phases (phase = position mod
+//        (L-1)) back through the phase maps of one or two short windows until
+//        the set is empty, full, or the domain start (phase 0) is reached; it
+//        also counts the candidates with a smaller offset -- its place in the
+//        ascending list -- and writes the verdict there, in pinned host memory
+//        and in HBM (for the multi-GPU gather).  The last workgroup adds the
+//        header and raises the scan's sequence number.
+//   ROMs of up to 4 MiB: mm_scan_fused runs both stages in ONE launch (grid barrier).
+//   Second phase, only when candidates are left over (host decides from the published
+//   counters): mm_resolve2 -> mm_hard_resolve (mm_tiles.h) -> mm_rank_count / mm_rank_scatter.
+//   The two lanes of mmh_scan_submit keep the round-1 chain mm_filter -> mm_resolve ->
+//   mm_rank_count -> mm_rank_scatter.
 //
-// Other engines: mm_dense_* (mm_dense.h), the candidate-free forward engine, for
-// inputs the per-candidate path does not suit; mm_chain_seq, one lane per domain
-// walking the chain literally, as an on-device cross-check.
+// Other engines: mm_forward (mm_forward.h), the candidate-free forward engine, for
+// inputs the per-candidate path does not suit and for keywords beyond 32 symbols;
+// mm_chain_seq, one lane per domain walking the chain literally, as an on-device
+// cross-check.
 //
 // No MFMA anywhere: the path is integer byte comparison (BASELINE.json).
 #include <hip/hip_runtime.h>

@@ -29,7 +29,7 @@ for W in ("plain", "wild"):
             for r in csv.DictReader(open(f)):
                 by[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (k, c), v in sorted(by.items()):
-        if k.startswith("mm_dense") or k.startswith("void mm_dense"):
+        if "mm_dense" in k or "mm_forward" in k:
             v = v[-16:]
             print("%-34s %-22s n=%-3d avg %16.1f" % (k[:34], c, len(v), sum(v) / len(v)))
 PY
