@@ -145,12 +145,25 @@ void begin_scan_events(mmh_ctx *c, bool has_filter)
 
 void release_rom(mmh_ctx *c)
 {
-   if (c->rom && c->rom_alloc) {
-      (void)hipFree(c->rom);
+   if (c->rom_own) {
+      (void)hipFree(c->rom_own);
    }
    c->rom = nullptr;
+   c->rom_own = nullptr;
    c->rom_bytes = 0;
    c->rom_alloc = 0;
+}
+
+// Uploads of up to this many bytes are not copied to HBM at all: they are copied into a pinned host
+// buffer and the kernels read that over PCIe (a 128 KiB hipMemcpy from pageable memory costs ~20 us
+// of a ~45 us MonkeyMoore<T>::search; a CPU memcpy of it 4 us and the scan reads it once).
+uint64_t zero_copy_limit()
+{
+   static const uint64_t v = [] {
+      const char *e = getenv("MMOORE_ZEROCOPY_MAX_KIB");
+      return (uint64_t)(e && *e ? atol(e) : 512) << 10;
+   }();
+   return v;
 }
 
 } // namespace
@@ -229,6 +242,7 @@ extern "C" void mmh_destroy(mmh_ctx *c)
    for (auto &w : c->ws) {
       free_workspace(w);
    }
+   if (c->rom_host) (void)hipHostFree(c->rom_host);
    if (c->d_dense) (void)hipFree(c->d_dense);
    if (c->d_sort_in) (void)hipFree(c->d_sort_in);
    if (c->d_sort_out) (void)hipFree(c->d_sort_out);
@@ -273,13 +287,14 @@ extern "C" int mmh_rom_alloc(mmh_ctx *c, uint64_t nbytes)
    }
    HIP_TRY(hipSetDevice(c->device));
    uint64_t need = ((nbytes + 15) / 16) * 16 + 16;
-   if (!(c->rom && c->rom_alloc >= need)) {
+   if (!(c->rom_own && c->rom_alloc >= need)) {
       release_rom(c);
       void *p = nullptr;
       HIP_TRY(hipMalloc(&p, need));
-      c->rom = static_cast<uint8_t *>(p);
+      c->rom_own = static_cast<uint8_t *>(p);
       c->rom_alloc = need;
    }
+   c->rom = c->rom_own;
    c->rom_bytes = nbytes;
    // the padding behind the ROM is never interpreted, but keep it defined
    HIP_TRY(hipMemsetAsync(c->rom + (nbytes / 16) * 16, 0, need - (nbytes / 16) * 16, c->stream));
@@ -291,6 +306,20 @@ extern "C" int mmh_rom_upload(mmh_ctx *c, const void *host, uint64_t nbytes)
    if (!c || (!host && nbytes)) {
       mmh_set_error("mmh_rom_upload: bad argument");
       return MMH_E_ARG;
+   }
+   if (nbytes && nbytes <= zero_copy_limit()) {
+      HIP_TRY(hipSetDevice(c->device));
+      if (!c->rom_host) {
+         void *p = nullptr;
+         HIP_TRY(hipHostMalloc(&p, zero_copy_limit() + 64, hipHostMallocDefault));
+         c->rom_host = static_cast<uint8_t *>(p);
+      }
+      // (nothing of an earlier scan still reads the buffer: scans are synchronous, lanes are collected before the ROM may change)
+      std::memcpy(c->rom_host, host, nbytes);
+      std::memset(c->rom_host + nbytes, 0, 32 + (16 - nbytes % 16) % 16);     // the padding behind the ROM stays defined
+      c->rom = c->rom_host;
+      c->rom_bytes = nbytes;
+      return MMH_OK;
    }
    int rc = mmh_rom_alloc(c, nbytes);
    if (rc != MMH_OK) {
@@ -316,7 +345,6 @@ extern "C" int mmh_rom_attach(mmh_ctx *c, const void *device_ptr, uint64_t nbyte
    release_rom(c);
    c->rom = const_cast<uint8_t *>(static_cast<const uint8_t *>(device_ptr));
    c->rom_bytes = nbytes;
-   c->rom_alloc = 0;
    return MMH_OK;
 }
 
@@ -327,7 +355,7 @@ extern "C" int mmh_rom_download(mmh_ctx *c, uint64_t first_byte, void *host, uin
       return MMH_E_ARG;
    }
    HIP_TRY(hipSetDevice(c->device));
-   HIP_TRY(hipMemcpyAsync(host, c->rom + first_byte, nbytes, hipMemcpyDeviceToHost, c->stream));
+   HIP_TRY(hipMemcpyAsync(host, c->rom + first_byte, nbytes, hipMemcpyDefault, c->stream));   // (the ROM may be the pinned host buffer)
    HIP_TRY(hipStreamSynchronize(c->stream));
    return MMH_OK;
 }
@@ -355,7 +383,7 @@ extern "C" int mmh_rom_poke(mmh_ctx *c, uint64_t first_byte, const void *host, u
       return MMH_E_ARG;
    }
    HIP_TRY(hipSetDevice(c->device));
-   HIP_TRY(hipMemcpyAsync(c->rom + first_byte, host, nbytes, hipMemcpyHostToDevice, c->stream));
+   HIP_TRY(hipMemcpyAsync(c->rom + first_byte, host, nbytes, hipMemcpyDefault, c->stream));
    HIP_TRY(hipStreamSynchronize(c->stream));
    return MMH_OK;
 }
@@ -402,7 +430,7 @@ bool fused_enabled()
 
 int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev, const MmGeom &g, const mmh_plan_desc &pl,
                      const mm::FilterChoice &fc, bool sequential, uint64_t base_offset, uint32_t max_candidates,
-                     const uint32_t *skip_bits = nullptr, bool allow_fused = false)
+                     const uint32_t *skip_bits = nullptr, bool allow_polled = false, bool allow_single_launch = false)
 {
    mm::ResolveBuffers rb;
    rb.cand = w.d_cand; rb.cand_cap = w.cand_cap; rb.out = w.d_out; rb.out_cap = w.out_cap; rb.ctrl = w.d_ctrl;
@@ -419,10 +447,10 @@ int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev,
    w.ctrl_clean = false;
    w.fused = false;
    w.polled = false;
-   if (allow_fused && !sequential && !skip_bits && fused_enabled()) {
+   if (allow_polled && !sequential && !skip_bits && fused_enabled()) {
       // the scan's end is announced in pinned memory (finish_pipeline polls): either everything in one
       // launch (small ROMs), or the streaming kernel + ONE tail kernel
-      if (c->fused_ok && mm::fused_applies(g) && g_fused_lock.try_lock()) {
+      if (allow_single_launch && c->fused_ok && mm::fused_applies(g) && g_fused_lock.try_lock()) {
          w.seq++;
          if (mm::launch_fused(st, g, pl, fc, rb, base_offset, max_candidates, w.h_result, w.d_result[w.result_turn], kMaxRankSort,
                               w.seq, ev[0], ev[2])) {
@@ -628,7 +656,7 @@ int run_pipeline(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, const mm:
    c->scans_recorded++;
    const int slot = (int)((c->scans_recorded - 1) % mmh_ctx::kRing);
    c->ring_filter_ms[slot] = 0;
-   int rc = enqueue_pipeline(c, c->ws[0], c->stream, c->ev, g, pl, fc, sequential, base_offset, max_candidates, skip_bits, true);
+   int rc = enqueue_pipeline(c, c->ws[0], c->stream, c->ev, g, pl, fc, sequential, base_offset, max_candidates, skip_bits, true, true);
    if (rc != MMH_OK) {
       return rc;
    }
@@ -1258,7 +1286,9 @@ extern "C" int mmh_scan_submit(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t b
          }
       }
       std::copy(c->lane_ev[lane], c->lane_ev[lane] + 3, p.ev);
-      rc = enqueue_pipeline(c, w, c->lane_stream[lane], p.ev, g, *plan, fc, false, base_offset, p.max_candidates);
+      // (filter + tail kernel, the end polled in the lane's own pinned block; never the single-launch kernel:
+      // its grid barrier wants the device to itself)
+      rc = enqueue_pipeline(c, w, c->lane_stream[lane], p.ev, g, *plan, fc, false, base_offset, p.max_candidates, nullptr, true, false);
       if (rc != MMH_OK) {
          return rc;
       }

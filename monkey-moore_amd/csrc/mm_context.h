@@ -106,9 +106,11 @@ struct mmh_ctx {
    hipStream_t own_stream = nullptr;
    hipStream_t stream = nullptr;
 
-   uint8_t *rom = nullptr;
+   uint8_t *rom = nullptr;          // the ROM the scans read: rom_own, rom_host, or a borrowed device pointer
    uint64_t rom_bytes = 0;
-   uint64_t rom_alloc = 0;          // > 0 when the library owns the buffer
+   uint8_t *rom_own = nullptr;      // library-owned device buffer
+   uint64_t rom_alloc = 0;          //   ... and its size
+   uint8_t *rom_host = nullptr;     // pinned host buffer small uploads are scanned from in place (zero copy)
 
    MmWorkspace ws[3];               // [0] mmh_scan; [1], [2] the two lanes of mmh_scan_submit / _collect
    uint8_t *d_dense = nullptr;      // dense engine: tile maps, super-tile maps, entry phases (one allocation)

@@ -45,6 +45,38 @@ __global__ __launch_bounds__(256) void read_wavespan(const uint4 *p, uint64_t nc
    if (acc == 0x12345678) sink[0] = acc;
 }
 
+// pattern A with the filter's amount of VALU work per dword (14 dependent-ish ops), software pipelined:
+// the load of iteration i+1 is issued before iteration i is processed (DEPTH loads in flight per lane)
+__device__ __forceinline__ uint32_t busy14(uint32_t w, uint32_t prev, uint32_t k)
+{
+   uint32_t d = (w | 0x80808080u) - (__builtin_amdgcn_alignbit(w, prev, 24) & 0x7F7F7F7Fu);
+   d ^= ~(w ^ prev) & 0x80808080u;
+   uint32_t z = d ^ k;
+   z |= __builtin_amdgcn_alignbit(d, prev, 24) ^ (k * 3u);
+   return (z - 0x01010101u) & ~z;
+}
+template <int DEPTH>
+__global__ __launch_bounds__(256) void read_gridstride_work(const uint4 *p, uint64_t nchunks, uint32_t *sink, uint32_t k)
+{
+   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+   uint32_t acc = 0;
+   uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   uint4 w[DEPTH];
+#pragma unroll
+   for (int u = 0; u < DEPTH; u++) w[u] = p[(c + stride * u) < nchunks ? c + stride * u : c];
+   for (; c < nchunks; c += stride * DEPTH) {
+#pragma unroll
+      for (int u = 0; u < DEPTH; u++) {
+         const uint4 cur = w[u];
+         const uint64_t nx = c + stride * (u + DEPTH);
+         w[u] = p[nx < nchunks ? nx : c];
+         const uint32_t back = __builtin_amdgcn_update_dpp(k, cur.w, 0x138, 0xf, 0xf, false);
+         acc |= busy14(cur.x, back, k) | busy14(cur.y, cur.x, k) | busy14(cur.z, cur.y, k) | busy14(cur.w, cur.z, k);
+      }
+   }
+   if ((acc & 0x80808080u) == 0x12345678) sink[0] = acc;
+}
+
 // pattern A plus the 4-byte look-back load the v1 filter does
 template <int UNROLL>
 __global__ __launch_bounds__(256) void read_gridstride_back(const uint4 *p, uint64_t nchunks, uint32_t *sink)
@@ -93,7 +125,7 @@ int main(int argc, char **argv)
    CK(hipMalloc(&p, bytes)); CK(hipMalloc(&sink, 64));
    hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, p, nchunks);
    CK(hipDeviceSynchronize());
-   for (int grid : {1024, 2048, 4096, 8192}) {
+   for (int grid : {1024, 1536, 1792, 2048, 3072, 4096}) {
       char nm[128];
       snprintf(nm, sizeof nm, "gridstride u1 grid %d", grid);
       timeit(nm, bytes, [&] { hipLaunchKernelGGL(read_gridstride<1>, dim3(grid), dim3(256), 0, 0, p, nchunks, sink); });
@@ -101,6 +133,12 @@ int main(int argc, char **argv)
       timeit(nm, bytes, [&] { hipLaunchKernelGGL(read_gridstride<4>, dim3(grid), dim3(256), 0, 0, p, nchunks, sink); });
       snprintf(nm, sizeof nm, "gridstride u8 grid %d", grid);
       timeit(nm, bytes, [&] { hipLaunchKernelGGL(read_gridstride<8>, dim3(grid), dim3(256), 0, 0, p, nchunks, sink); });
+      snprintf(nm, sizeof nm, "gridstride u2 grid %d", grid);
+      timeit(nm, bytes, [&] { hipLaunchKernelGGL(read_gridstride<2>, dim3(grid), dim3(256), 0, 0, p, nchunks, sink); });
+      snprintf(nm, sizeof nm, "gridstride + 14 VALU/dword, 1 load ahead, grid %d", grid);
+      timeit(nm, bytes, [&] { hipLaunchKernelGGL(read_gridstride_work<1>, dim3(grid), dim3(256), 0, 0, p, nchunks, sink, 0x01020304u); });
+      snprintf(nm, sizeof nm, "gridstride + 14 VALU/dword, 2 loads ahead, grid %d", grid);
+      timeit(nm, bytes, [&] { hipLaunchKernelGGL(read_gridstride_work<2>, dim3(grid), dim3(256), 0, 0, p, nchunks, sink, 0x01020304u); });
       snprintf(nm, sizeof nm, "gridstride+back u4 grid %d", grid);
       timeit(nm, bytes, [&] { hipLaunchKernelGGL(read_gridstride_back<4>, dim3(grid), dim3(256), 0, 0, p, nchunks, sink); });
       for (uint64_t span_kb : {16, 64, 512}) {
