@@ -439,8 +439,9 @@ __global__ __launch_bounds__(64 * MM_WAVES, 4) void mm_scan_fused(MmFusedArgs a)
 // The tail as a kernel of its own, behind mm_filter_* (large ROMs: the streaming kernel keeps
 // its own, leaner launch and all the wave slots; this one replaces mm_resolve, mm_rank_count and
 // mm_rank_scatter -- one dependent launch instead of three).
-// (5 waves per SIMD: <= 96 VGPRs, so that the 1056 workgroups the bench ROM's candidates need are resident at once)
-__global__ __launch_bounds__(64 * MM_WAVES, 5) void mm_scan_tail(MmFusedArgs a)
+// OCC waves per SIMD: 5 (<= 96 VGPRs) keeps the 1056 workgroups the bench ROM's candidates need resident at once
+template <int OCC>
+__global__ __launch_bounds__(64 * MM_WAVES, OCC) void mm_scan_tail(MmFusedArgs a)
 {
    __shared__ MmPlanLds P;
    __shared__ MmWaveLdsShort Wv[MM_WAVES];

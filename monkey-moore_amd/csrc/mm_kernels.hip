@@ -1465,7 +1465,8 @@ void launch_tail(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const
    fill_tail_args(a, rb, base_offset, max_candidates, host_result, dev_result, max_rank, seq);
    a.has_edge = 0;
    // one wave per candidate for up to 8 K of them in one round (the count is only known on the device)
-   launch_timed(mm_scan_tail, dim3(tuning().tail_blocks), dim3(64 * MM_WAVES), st, nullptr, stop, a);
+   // (5 waves per SIMD measured best: 6 and 8 spill and run 4-15 us longer; 1280 .. 4096 workgroups: no difference)
+   launch_timed(mm_scan_tail<5>, dim3(tuning().tail_blocks), dim3(64 * MM_WAVES), st, nullptr, stop, a);
 }
 
 static MmTileArgs tile_args(const MmGeom &g, const mmh_plan_desc &pl)

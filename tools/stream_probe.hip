@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void read_gridstride_work(const uint4 *p, uint
          acc |= busy14(cur.x, back, k) | busy14(cur.y, cur.x, k) | busy14(cur.z, cur.y, k) | busy14(cur.w, cur.z, k);
       }
    }
-   if ((acc & 0x80808080u) == 0x12345678) sink[0] = acc;
+   if (acc == k * 7u) sink[0] = acc;
 }
 
 // pattern A plus the 4-byte look-back load the v1 filter does
@@ -125,7 +125,7 @@ int main(int argc, char **argv)
    CK(hipMalloc(&p, bytes)); CK(hipMalloc(&sink, 64));
    hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, p, nchunks);
    CK(hipDeviceSynchronize());
-   for (int grid : {1024, 1536, 1792, 2048, 3072, 4096}) {
+   for (int grid : {1536, 1792, 2048}) {
       char nm[128];
       snprintf(nm, sizeof nm, "gridstride u1 grid %d", grid);
       timeit(nm, bytes, [&] { hipLaunchKernelGGL(read_gridstride<1>, dim3(grid), dim3(256), 0, 0, p, nchunks, sink); });
@@ -136,9 +136,9 @@ int main(int argc, char **argv)
       snprintf(nm, sizeof nm, "gridstride u2 grid %d", grid);
       timeit(nm, bytes, [&] { hipLaunchKernelGGL(read_gridstride<2>, dim3(grid), dim3(256), 0, 0, p, nchunks, sink); });
       snprintf(nm, sizeof nm, "gridstride + 14 VALU/dword, 1 load ahead, grid %d", grid);
-      timeit(nm, bytes, [&] { hipLaunchKernelGGL(read_gridstride_work<1>, dim3(grid), dim3(256), 0, 0, p, nchunks, sink, 0x01020304u); });
+      timeit(nm, bytes, [&] { hipLaunchKernelGGL(read_gridstride_work<1>, dim3(grid), dim3(256), 0, 0, p, nchunks, sink, (uint32_t)argc * 0x01020304u); });
       snprintf(nm, sizeof nm, "gridstride + 14 VALU/dword, 2 loads ahead, grid %d", grid);
-      timeit(nm, bytes, [&] { hipLaunchKernelGGL(read_gridstride_work<2>, dim3(grid), dim3(256), 0, 0, p, nchunks, sink, 0x01020304u); });
+      timeit(nm, bytes, [&] { hipLaunchKernelGGL(read_gridstride_work<2>, dim3(grid), dim3(256), 0, 0, p, nchunks, sink, (uint32_t)argc * 0x01020304u); });
       snprintf(nm, sizeof nm, "gridstride+back u4 grid %d", grid);
       timeit(nm, bytes, [&] { hipLaunchKernelGGL(read_gridstride_back<4>, dim3(grid), dim3(256), 0, 0, p, nchunks, sink); });
       for (uint64_t span_kb : {16, 64, 512}) {
