@@ -30,8 +30,9 @@ EXPORTS = [
     "mmh_timing_history", "mmh_filter_shape", "mmh_rom_load_file", "mmh_last_load_stats", "mmh_rom_gather",
     "mmh_scan_submit", "mmh_scan_collect",
     "mmh_partition", "mmh_comm_unique_id", "mmh_comm_init_rank", "mmh_comm_init_all", "mmh_comm_info", "mmh_comm_destroy",
-    "mmh_gather_start", "mmh_gather_finish", "mmh_last_gather_timings", "mmh_scan_multi",
+    "mmh_gather_start", "mmh_gather_finish", "mmh_last_gather_timings", "mmh_scan_multi", "mmh_selftest_gather_pack",
 ]
+MMH_GATHER_RECORD_WORDS = 8 + 16384
 MMH_COMM_ID_BYTES = 128
 
 
@@ -121,6 +122,7 @@ def lib():
         L.mmh_gather_start.argtypes = [C.c_void_p, u64p, C.c_uint64, C.c_int]
         L.mmh_gather_finish.argtypes = [C.c_void_p, u64p, C.c_uint64, u64p]
         L.mmh_last_gather_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.mmh_selftest_gather_pack.argtypes = [C.c_void_p, u64p, C.c_int, u64p, C.c_uint64, u64p, u64p]
         L.mmh_scan_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(PlanDesc), C.c_uint64, C.c_int, u64p, u64p, C.c_uint64, u64p]
         _lib = L
     return _lib
@@ -366,6 +368,16 @@ class Engine:
             if rc != MMH_OK:
                 _check(rc)
             return out[: count.value].copy()
+
+    def selftest_gather_pack(self, records):
+        """records: (nranks, MMH_GATHER_RECORD_WORDS) uint64 -- the table an all-gather would have left; returns
+        (merged list or None when the long-list phase would follow, longest list)."""
+        rec = np.ascontiguousarray(records, dtype=np.uint64)
+        out = np.empty(rec.shape[0] * 16384, np.uint64)
+        n, longest = C.c_uint64(0), C.c_uint64(0)
+        _check(lib().mmh_selftest_gather_pack(self._h, _p(rec, C.c_uint64), rec.shape[0], _p(out, C.c_uint64), out.size,
+                                              C.byref(n), C.byref(longest)))
+        return (out[: n.value].copy() if longest.value <= 16384 else None), int(longest.value)
 
     def gather_timings(self):
         t = (C.c_float * 2)()

@@ -590,6 +590,59 @@ extern "C" int mmh_last_gather_timings(mmh_ctx *c, float *ms2)
 }
 
 // --------------------------------------------------------------------------
+// self-test hook: the packing kernel on records of MANY ranks without a wire
+// --------------------------------------------------------------------------
+//
+// The development box has one GPU, so a real all-gather never delivers more than one record there.
+// This entry feeds mm_gather_pack the table an N-rank all-gather WOULD have left (nranks records of
+// MMH_GATHER_RECORD_WORDS words, host memory) and returns what mmh_gather_finish would deliver.
+
+extern "C" int mmh_selftest_gather_pack(mmh_ctx *c, const uint64_t *records, int nranks, uint64_t *out, uint64_t cap,
+                                        uint64_t *out_count, uint64_t *longest)
+{
+   if (!c || !records || nranks < 1 || nranks > kMaxRanks || !out_count || !longest || (!out && cap)) {
+      mmh_set_error("mmh_selftest_gather_pack: bad argument");
+      return MMH_E_ARG;
+   }
+   static_assert(MMH_GATHER_RECORD_WORDS == kRecordWords, "record width");
+   HIP_TRY(hipSetDevice(c->device));
+   const uint64_t merged_cap = (uint64_t)nranks * MM_MAX_RANK_SORT;
+   uint64_t *d_table = nullptr, *h_merged = nullptr;
+   HIP_TRY(hipMalloc(&d_table, (uint64_t)nranks * kRecordWords * sizeof(uint64_t)));
+   int rc = MMH_OK;
+   if (!hip_ok(hipHostMalloc(&h_merged, (kMergedHeader + merged_cap) * sizeof(uint64_t), hipHostMallocDefault), "hipHostMalloc")) {
+      rc = MMH_E_DEVICE;
+   }
+   if (rc == MMH_OK && !hip_ok(hipMemcpyAsync(d_table, records, (uint64_t)nranks * kRecordWords * sizeof(uint64_t), hipMemcpyHostToDevice,
+                                              c->stream), "hipMemcpyAsync")) {
+      rc = MMH_E_DEVICE;
+   }
+   if (rc == MMH_OK) {
+      hipLaunchKernelGGL(mm_gather_pack, dim3((unsigned)nranks), dim3(256), 0, c->stream, d_table, (uint32_t)nranks, kRecordWords, h_merged,
+                         merged_cap, 1u);
+      if (!hip_ok(hipGetLastError(), "mm_gather_pack") || !hip_ok(hipStreamSynchronize(c->stream), "hipStreamSynchronize")) {
+         rc = MMH_E_DEVICE;
+      }
+   }
+   if (rc == MMH_OK) {
+      *out_count = h_merged[0];
+      *longest = h_merged[1];
+      if (*longest <= MM_MAX_RANK_SORT) {
+         if (*out_count > cap) {
+            mmh_set_error("mmh_selftest_gather_pack: %llu offsets do not fit", (unsigned long long)*out_count);
+            rc = MMH_E_CAPACITY;
+         }
+         else if (*out_count) {
+            std::memcpy(out, h_merged + kMergedHeader, *out_count * sizeof(uint64_t));
+         }
+      }
+   }
+   (void)hipFree(d_table);
+   if (h_merged) (void)hipHostFree(h_merged);
+   return rc;
+}
+
+// --------------------------------------------------------------------------
 // one process, several GPUs
 // --------------------------------------------------------------------------
 

@@ -156,6 +156,49 @@ int main()
       }
       CHECK(monotone, "progress must be monotone");
    }
+   // progress at a realistic size (the reference's own test only has a 128-byte file): 3 MiB + 777 bytes in
+   // 64 KiB blocks -> 49 blocks, 52 callbacks, monotone, ends at 100; and the matches are the planted ones
+   {
+      std::vector<uint8_t> bytes((3u << 20) + 777);
+      uint32_t x = 99;
+      for (auto &b : bytes) {
+         x = x * 1664525u + 1013904223u;
+         b = static_cast<uint8_t>(x >> 24);
+      }
+      const char *kw = "relative";
+      std::vector<uint64_t> planted;
+      for (size_t at = 70000; at + 8 < bytes.size(); at += 250007) {
+         for (int k = 0; k < 8; k++) {
+            bytes[at + k] = static_cast<uint8_t>(kw[k] - 50);
+         }
+         planted.push_back(at);
+      }
+      TempFile tmp(bytes);
+      mmoore::SearchConfig cfg;
+      cfg.file_path = tmp.path;
+      cfg.keyword = {'r', 'e', 'l', 'a', 't', 'i', 'v', 'e'};
+      cfg.preferred_search_block_size = 65536;
+      std::atomic<bool> abort{false};
+      std::vector<int> history;
+      mmoore::SearchEngine<uint8_t> engine(cfg);
+      auto got = engine.run([&](int pct, const mmoore::SearchStep) { history.push_back(pct); }, abort);
+      CHECK(history.size() == 49 + 3, "progress: %zu callbacks, expected 49 blocks + 3", history.size());
+      bool monotone = !history.empty() && history.back() == 100;
+      for (size_t i = 1; i < history.size(); i++) {
+         monotone = monotone && history[i] >= history[i - 1];
+      }
+      CHECK(monotone, "progress must be monotone and end at 100");
+      CHECK(got.size() == planted.size(), "%zu results, %zu planted", got.size(), planted.size());
+      for (size_t i = 0; i < got.size() && i < planted.size(); i++) {
+         CHECK(got[i].offset == planted[i], "result %zu at %llu, planted at %llu", i, (unsigned long long)got[i].offset,
+               (unsigned long long)planted[i]);
+      }
+      // abort raised in the middle of the progress ticks: nothing is returned
+      std::atomic<bool> stop{false};
+      int calls = 0;
+      auto none = engine.run([&](int, const mmoore::SearchStep) { if (++calls == 20) stop = true; }, stop);
+      CHECK(none.empty() && calls == 20, "abort after 20 callbacks: %zu results, %d callbacks", none.size(), calls);
+   }
    // abort (test_search_engine.cpp:399-427)
    {
       std::string text = "match#catch#batch#match#patch#hatch#match";

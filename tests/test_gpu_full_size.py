@@ -113,3 +113,30 @@ def test_c5_64gib_on_one_gpu(mm, gpu_engine, oracle):
     assert len(got) >= 2000 and int(got[-1]) > (63 << 30)
     assert t["total_ms"] < 20.0, t                        # 64 GiB in 11 ms at the 4 GiB rate
     gpu_engine.alloc(1 << 20)                             # give the HBM back to the other tests
+
+
+@pytest.mark.parametrize("kw,wc", [("relativesrch", 0), ("re*ative*ear*hxy", ord("*")), ("a" * 40 + "bcdefghij" + "k" * 15, 0)])
+def test_forward_engine_4gib(mm, gpu_engine, oracle, kw, wc):
+    """The forward engine (mm_forward: single pass, decoupled look-back over 128 Ki batches of this ROM)
+    at C2 / C3 size, and with a 64-symbol keyword (the wide phase maps), against the oracle and
+    against the filter + resolver path."""
+    n = 4 << 30
+    spec = mm.synth.RomSpec(42, n, kw, 1, wc or None, False, BLOCK)
+    gpu_engine.alloc(n)
+    spec.apply_device(gpu_engine)
+    plan = mm.plan_relative(1, kw, wc)
+    gpu_engine.set_engine(2)
+    try:
+        got = gpu_engine.scan(plan, block_bytes=BLOCK)
+        assert gpu_engine.counters()["path"] == 3
+        whole = gpu_engine.scan(plan)                    # one chain over the whole 4 GiB: look-back across 131072 batches
+    finally:
+        gpu_engine.set_engine(0)
+    rom = _download(gpu_engine, n)
+    oplan = oracle.plan(1, kw, wc)
+    want = oracle_engine_parallel(oracle, oplan, rom, BLOCK)
+    assert got.tolist() == want.tolist()
+    assert len(got) >= 4096 or len(kw) > 32
+    if len(kw) <= 32:
+        assert gpu_engine.scan(plan, block_bytes=BLOCK).tolist() == want.tolist()      # the candidate path agrees
+    assert whole.tolist() == oracle.search(oplan, rom).tolist()

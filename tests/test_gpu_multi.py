@@ -123,6 +123,49 @@ def test_two_gathers_in_flight_overlap_the_next_scan(mm, comm_engine, oracle):
     assert eng.gather_finish().tolist() == [0, 1, 2, 3, 4]
 
 
+def test_packing_of_many_ranks_records(mm, comm_engine):
+    """mm_gather_pack on the table an 8- / 3- / 64-rank all-gather would have left (the box has one GPU, so
+    the wire never delivers more than one record here): dense records (the rank kernels'), sparse ones with
+    holes (the tail kernel's), empty ranks, a full record, and the long-list flag."""
+    eng = comm_engine
+    rng = np.random.default_rng(8)
+    W = mm.MMH_GATHER_RECORD_WORDS
+    for nranks in (1, 3, 8, 64):
+        for trial in range(4):
+            rec = rng.integers(0, 1 << 62, (nranks, W), dtype=np.uint64)        # garbage wherever nothing is defined
+            want = []
+            for r in range(nranks):
+                kind = int(rng.integers(0, 5)) if trial else 4
+                n = [0, 1, int(rng.integers(2, 5000)), 16384, int(rng.integers(2, 9000))][kind]
+                base = np.uint64(r) << np.uint64(40)
+                offs = np.sort(rng.choice(1 << 30, size=n, replace=False)).astype(np.uint64) + base
+                rec[r, :8] = 0
+                if kind == 4 and n > 1:
+                    # sparse: more slots than matches, ~0 in the holes
+                    slots = n + int(rng.integers(1, 200))
+                    slots = min(slots, 16384)
+                    hole = np.ones(slots, bool)
+                    hole[np.sort(rng.choice(slots, size=n, replace=False))] = False
+                    body = np.full(slots, np.uint64(0xFFFFFFFFFFFFFFFF))
+                    body[~hole] = offs
+                    rec[r, 8:8 + slots] = body
+                    rec[r, 0], rec[r, 4], rec[r, 6] = slots, 1, n + 1
+                else:
+                    rec[r, 8:8 + n] = offs
+                    rec[r, 0], rec[r, 4], rec[r, 6] = n + int(rng.integers(0, 3)), 0, n + 1   # (dense: word 0 may count dropped slots too)
+                want.append(offs)
+            got, longest = eng.selftest_gather_pack(rec)
+            flat = np.concatenate(want)
+            assert longest == max(len(w) for w in want)
+            assert got.tolist() == flat.tolist(), (nranks, trial)
+            assert (np.diff(got.astype(np.int64)) > 0).all() or got.size < 2
+    # a rank with a list longer than a record: nothing is delivered, the second phase would follow
+    rec = np.zeros((2, W), np.uint64)
+    rec[0, 6], rec[1, 6] = 5 + 1, 20000 + 1
+    got, longest = eng.selftest_gather_pack(rec)
+    assert got is None and longest == 20000
+
+
 def test_native_gather_next_to_torch_nccl():
     # the way bench.py runs at N > 1: torch.distributed ("nccl") owns the rendezvous and the
     # barriers, the library brings up its OWN RCCL communicator from an id that travels through

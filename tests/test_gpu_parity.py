@@ -88,6 +88,23 @@ def test_tiny_reference_vectors(mm, gpu_engine):
         assert got.tolist() == c["expect"], {k: v for k, v in c.items() if k != "file"}
 
 
+def test_zero_copy_upload_boundary(mm, gpu_engine, oracle):
+    """Uploads of up to 512 KiB are scanned in place from pinned host memory (mmh_rom_upload), larger ones
+    from HBM: the same results on both sides of the limit, and the ROM reads back."""
+    rng = np.random.default_rng(12)
+    kw = "monkey"
+    for n in ((512 << 10) - 1, 512 << 10, (512 << 10) + 1, 4099):
+        rom = _random_rom_with_plants(rng, n, 1, [ord(c) for c in kw], False, nplants=30)
+        gpu_engine.upload(rom)
+        assert (gpu_engine.download(0, n) == rom).all()
+        plan, oplan = mm.plan_relative(1, kw), oracle.plan(1, kw)
+        assert _scan_both(gpu_engine, plan, block_bytes=65536).tolist() == oracle.engine(oplan, rom, 65536).tolist()
+        assert gpu_engine.scan(plan).tolist() == oracle.search(oplan, rom).tolist()
+        gpu_engine.poke(100, np.array([1, 2, 3], np.uint8))                   # poke works on either kind of ROM
+        assert gpu_engine.download(100, 3).tolist() == [1, 2, 3]
+        assert gpu_engine.gather([100, n - 2], 3).tolist() == [[1, 2, 3], [int(rom[n - 2]), int(rom[n - 1]), 0]]
+
+
 def test_no_matches_in_the_padding_behind_the_rom(mm, gpu_engine, oracle):
     """Regression (found by the tiny vectors): the streaming code looks at whole 16-byte chunks, so it
     sees the bytes behind the ROM; when those continue the pattern (stale bytes of a larger ROM that
