@@ -146,9 +146,12 @@ def main():
                     help="N > 1: finish every step's offset gather before the next scan starts (no overlap)")
     ap.add_argument("--torch-gather", action="store_true",
                     help="N > 1: gather through torch.distributed (the test double) instead of the library's own RCCL calls")
-    ap.add_argument("--two-in-flight", action="store_true",
-                    help="after the timed region, repeat the K steps through mmh_scan_submit / mmh_scan_collect and "
-                         "report that as the extra 'two_in_flight' object (never the headline value)")
+    ap.add_argument("--depth", type=int, choices=(1, 2), default=2,
+                    help="scans in flight in the timed region: 2 = mmh_scan_submit / mmh_scan_collect, the next scan's streaming "
+                         "kernel runs while the previous scan's tail kernel, result hand-over and gather finish (how the engine "
+                         "drives partitions); 1 = mmh_scan, every step waits for its own result")
+    ap.add_argument("--no-other-depth", action="store_true",
+                    help="skip the extra K steps at the other depth after the timed region (the 'synchronous' / 'two_in_flight' object)")
     args = ap.parse_args()
 
     import torch
@@ -239,8 +242,8 @@ def main():
         gather_host_ms.append((time.perf_counter() - t0) * 1e3)
         return merged
 
-    def step():
-        offs = eng.scan(plan, block_bytes=BLOCK, base_offset=base)
+    def deliver(offs):
+        """what a step hands over: the scan's list at N = 1, else the gathered one (of this or the previous step)"""
         if world == 1:
             return offs
         if args.sync_gather:
@@ -256,6 +259,20 @@ def main():
             merged = gather_finish(in_flight.pop(0))
         return merged if (rank == 0 and merged is not None) else last
 
+    def run_steps(k, depth):
+        """k steps = k scans of the shard + k deliveries, nothing left in flight at the end"""
+        last, tickets = None, []
+        for _ in range(k):
+            if depth == 1:
+                last = deliver(eng.scan(plan, block_bytes=BLOCK, base_offset=base))
+            else:
+                tickets.append(eng.submit(plan, block_bytes=BLOCK, base_offset=base))
+                if len(tickets) == 2:
+                    last = deliver(eng.collect(tickets.pop(0)))
+        while tickets:
+            last = deliver(eng.collect(tickets.pop(0)))
+        return drain(last)
+
     def fence():
         if world > 1:
             dist.barrier()
@@ -270,51 +287,34 @@ def main():
     while time.perf_counter() - t_pre < args.prewarm_s:
         eng.scan(plan, block_bytes=BLOCK, base_offset=base)
         prewarm_scans += 1
-    offs = None
-    for _ in range(args.warmup):
-        offs = step()
-    drain(offs)
+    run_steps(args.warmup, args.depth)
     fence()
     del gather_dev_ms[:], gather_host_ms[:]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        offs = step()
-    offs = drain(offs)                                   # the last gather belongs to the timed region
+    offs = run_steps(args.steps, args.depth)             # the last collect / gather belongs to the timed region
     fence()
     elapsed = time.perf_counter() - t0
     # HIP-event timings of the timed steps: recorded on the scan's stream during the steps,
-    # read back afterwards (the library keeps the event triples of the last 64 scans)
+    # read back afterwards (the library keeps the timings of the last 64 scans)
     filt_ms, tot_ms = eng.timing_history(min(args.steps, 64))
     post_ms = tot_ms - filt_ms
+    gather_dev, gather_host = list(gather_dev_ms), list(gather_host_ms)
 
-    # Extra, NOT part of `value`: the same K steps with two scans in flight (mmh_scan_submit /
-    # mmh_scan_collect): the host's share of a scan and the kernels behind the streaming filter
-    # overlap the next scan's filter.  Every step still delivers its own (gathered) result.
-    def pipelined(k):
-        prev, last = None, None
-        for _ in range(k):
-            t = eng.submit(plan, block_bytes=BLOCK, base_offset=base)
-            if prev is not None:
-                last = eng.collect(prev)
-                if world > 1:
-                    last = mm.partition.gather_offsets(last, rank, world, dev, dist)
-            prev = t
-        last = eng.collect(prev)
-        if world > 1:
-            last = mm.partition.gather_offsets(last, rank, world, dev, dist)
-        return last
-    offs_pipe, elapsed_pipe = None, 0.0
-    if args.two_in_flight:
-        pipelined(max(args.warmup, 4))
+    # Extra, NOT part of `value`: the same K steps at the other depth.
+    other_depth = 3 - args.depth
+    offs_other, elapsed_other = None, 0.0
+    if not args.no_other_depth:
+        run_steps(max(args.warmup, 4), other_depth)
         fence()
         t1 = time.perf_counter()
-        offs_pipe = pipelined(args.steps)
+        offs_other = run_steps(args.steps, other_depth)
         fence()
-        elapsed_pipe = time.perf_counter() - t1
+        elapsed_other = time.perf_counter() - t1
+        filt_other, tot_other = eng.timing_history(min(args.steps, 64))
     if world > 1:
-        tmax = torch.tensor([elapsed, elapsed_pipe], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed, elapsed_other], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed, elapsed_pipe = float(tmax[0].item()), float(tmax[1].item())
+        elapsed, elapsed_other = float(tmax[0].item()), float(tmax[1].item())
 
     if rank == 0:
         ctr = eng.counters()
@@ -348,6 +348,10 @@ def main():
                 "parallelism": "%d partition(s) on block boundaries%s" % (
                     world, "" if world == 1 else ", offset gather: " + gather_backend +
                     (" (synchronous)" if args.sync_gather else ", overlapped with the next scan")),
+                "scans_in_flight": args.depth,
+                "step": ("mmh_scan_submit + mmh_scan_collect of the previous ticket: K scans submitted and K results delivered "
+                         "inside the timed region, two in flight" if args.depth == 2 else
+                         "mmh_scan: every step waits for its own result"),
                 "prewarm_scans": prewarm_scans,
             },
             "roofline": {
@@ -375,19 +379,24 @@ def main():
             # where an N > 1 step's time goes besides the scan: the collective + packing on the device
             # (HIP events on the communication stream) and the host's share of start + finish
             res["gather_ms"] = {
-                "device_collective_and_pack": float(np.mean(gather_dev_ms)) if gather_dev_ms else None,
-                "host_start_plus_finish": float(np.mean(gather_host_ms)) if gather_host_ms else None,
+                "device_collective_and_pack": float(np.mean(gather_dev)) if gather_dev else None,
+                "host_start_plus_finish": float(np.mean(gather_host)) if gather_host else None,
                 "per_step_overhead_vs_device_scan": elapsed / args.steps * 1e3 - float(np.mean(tot_ms)),
             }
             res["overlap"] = not args.sync_gather
             res["gather_backend"] = gather_backend
             if gather_note:
                 res["gather_note"] = gather_note
-        if args.two_in_flight:
-            res["two_in_flight"] = {
-                "value": total * args.steps / elapsed_pipe / 1e9, "unit": "GB/s", "ms_per_step": elapsed_pipe / args.steps * 1e3,
-                "same_offsets": bool(np.array_equal(offs_pipe, offs)),
-                "note": "not the headline value: the same K steps through mmh_scan_submit / mmh_scan_collect, two scans in flight",
+        if not args.no_other_depth:
+            same = bool(np.array_equal(offs_other, offs))
+            assert same, "the two depths delivered different lists"
+            res["two_in_flight" if other_depth == 2 else "synchronous"] = {
+                "value": total * args.steps / elapsed_other / 1e9, "unit": "GB/s", "ms_per_step": elapsed_other / args.steps * 1e3,
+                "kernel_ms": float(np.mean(filt_other)), "scan_device_ms": float(np.mean(tot_other)),
+                "same_offsets": same,
+                "note": "not the headline value: the same K steps " + (
+                    "through mmh_scan_submit / mmh_scan_collect, two scans in flight" if other_depth == 2 else
+                    "through mmh_scan, one scan at a time: the latency of a single 4 GiB scan as a caller sees it"),
             }
         if world == 1 and not args.no_cpu_baseline:
             cb, cpu_offs, ncov = cpu_baseline(eng, shard, KEYWORD, args.cpu_sample_mib << 20, args.cpu_warmups, args.cpu_runs)

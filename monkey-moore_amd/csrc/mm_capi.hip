@@ -466,8 +466,7 @@ int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev,
          c->fused_ok = false;                   // the occupancy query failed: never try again
       }
       w.seq++;
-      const uint64_t block_cap = (c->mg.comm && c->mg.nranks > 1) ? mm::tuning().filter_blocks_comm : 0;
-      mm::launch_filter(st, g, pl, fc, w.d_cand, w.d_ctrl, w.cand_cap, ev[0], ev[1], nullptr, nullptr, block_cap);
+      mm::launch_filter(st, g, pl, fc, w.d_cand, w.d_ctrl, w.cand_cap, ev[0], ev[1], nullptr, nullptr);
       mm::launch_tail(st, g, pl, fc, rb, base_offset, max_candidates, w.h_result, w.d_result[w.result_turn], kMaxRankSort, w.seq,
                       ev[2]);
       HIP_TRY(hipGetLastError());
@@ -477,10 +476,7 @@ int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev,
    // The scan's three events ride on kernel dispatches (hipExtLaunchKernelGGL) where they can:
    // a hipEventRecord between dependent kernels costs ~6 us of stream time on this stack.
    if (!sequential) {
-      // (with ranks to gather from, the streaming kernel leaves a workgroup slot per CU to the RCCL
-      // kernel of the previous scan's gather, which would otherwise wait for this kernel's end)
-      const uint64_t block_cap = (c->mg.comm && c->mg.nranks > 1) ? mm::tuning().filter_blocks_comm : 0;
-      mm::launch_filter(st, g, pl, fc, w.d_cand, w.d_ctrl, w.cand_cap, ev[0], ev[1], nullptr, skip_bits, block_cap);
+      mm::launch_filter(st, g, pl, fc, w.d_cand, w.d_ctrl, w.cand_cap, ev[0], ev[1], nullptr, skip_bits);
       mm::launch_resolve(st, g, pl, rb, base_offset, max_candidates);
    }
    else {
@@ -1191,21 +1187,32 @@ int scan_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int b
 }
 } // namespace
 
+namespace {
+// An outstanding gather may still be sending the device-side result copy the next scan in this workspace is
+// about to overwrite (the scan before the last one there): wait for its collective.
+int wait_for_gather_of(mmh_ctx *c, const MmWorkspace &w)
+{
+   for (auto &s : c->mg.slot) {
+      if (s.busy && !s.from_host && s.src && s.src == w.d_result[w.result_turn ^ 1]) {
+         HIP_TRY(hipSetDevice(c->device));
+         HIP_TRY(hipEventSynchronize(s.end));
+      }
+   }
+   return MMH_OK;
+}
+} // namespace
+
 // mmh_scan proper + what the multi-GPU gather needs to know about its list (mm_multi.hip)
 extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian,
                         uint64_t base_offset, uint64_t *out, uint64_t cap, uint64_t *out_count)
 {
    if (c) {
-      c->mg.last_on_device = false;
+      c->mg.last_src = nullptr;
       c->mg.last_count = 0;
       c->mg.last_list.clear();
-      // an outstanding gather may still be sending the device-side result copy this scan is about
-      // to overwrite (two scans ago): wait for its collective
-      for (auto &s : c->mg.slot) {
-         if (s.busy && !s.from_host && s.src_turn == (c->ws[0].result_turn ^ 1)) {
-            HIP_TRY(hipSetDevice(c->device));
-            HIP_TRY(hipEventSynchronize(s.end));
-         }
+      int rc = wait_for_gather_of(c, c->ws[0]);
+      if (rc != MMH_OK) {
+         return rc;
       }
    }
    std::vector<uint64_t> host_list;
@@ -1213,7 +1220,7 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
    int rc = scan_impl(c, plan, block_bytes, big_endian, base_offset, out, cap, out_count, &host_list, &on_device);
    if (c && (rc == MMH_OK || rc == MMH_E_CAPACITY)) {
       c->mg.last_count = *out_count;
-      c->mg.last_on_device = on_device;
+      c->mg.last_src = on_device ? c->ws[0].d_result[c->ws[0].result_turn] : nullptr;
       if (!on_device && c->mg.comm) {
          c->mg.last_list.swap(host_list);            // only kept when a communicator may ask for it
       }
@@ -1250,6 +1257,10 @@ extern "C" int mmh_scan_submit(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t b
    HIP_TRY(hipSetDevice(c->device));
    MmWorkspace &w = c->ws[1 + lane];
    rc = ensure_workspace(c, w, std::max<uint64_t>(w.out_cap, kInitialCap));
+   if (rc != MMH_OK) {
+      return rc;
+   }
+   rc = wait_for_gather_of(c, w);
    if (rc != MMH_OK) {
       return rc;
    }
@@ -1352,6 +1363,10 @@ extern "C" int mmh_scan_collect(mmh_ctx *c, int ticket, uint64_t *out, uint64_t 
    }
    std::memcpy(out, w.h_result + kHeaderWords, oc.matches * sizeof(uint64_t));
    p.active = false;
+   // (mmh_gather_start(NULL, 0) sends this ticket's list from the lane's device-side copy)
+   c->mg.last_src = w.d_result[w.result_turn];
+   c->mg.last_count = oc.matches;
+   c->mg.last_list.clear();
    return MMH_OK;
 }
 

@@ -63,7 +63,7 @@ struct MmGatherSlot {
    hipEvent_t begin = nullptr, end = nullptr;
    bool busy = false;
    bool from_host = false;          // the local list came from host memory (long lists, forward engine)
-   int src_turn = 0;                // else: which device-side result copy of the scan workspace it sends
+   const uint64_t *src = nullptr;   // else: the device-side result copy (of the scan's workspace) it sends
    uint64_t local_count = 0;        // this rank's list length
    double start_wall_s = 0;         // host time spent in mmh_gather_start
 };
@@ -77,12 +77,13 @@ struct MmComm {
    int turn = 0;                    // slot of the next mmh_gather_start
    int oldest = 0;                  // slot of the next mmh_gather_finish
    uint64_t *d_send = nullptr;      // record built from a host list: [header][offsets]
-   uint64_t *d_long = nullptr;      // second phase (some list longer than a record): padded lists
+   uint64_t *d_long = nullptr;      // second phase (some list longer than a record): [packing header][this rank's list, padded]
    uint64_t long_cap = 0;
    uint64_t *d_long_table = nullptr;
    uint64_t long_table_cap = 0;
    std::vector<uint64_t> last_list; // host copy of the most recent scan's list when it is not device resident
-   bool last_on_device = false;     // the most recent scan's list sits in ws[0].d_result[result_turn]
+   const uint64_t *last_src = nullptr; // the most recent scan's (or collected ticket's) list sits ordered in this device-side
+                                    // result copy of its workspace; null: it only exists on the host (last_list)
    uint64_t last_count = 0;
    float last_device_ms = 0;        // collective + packing of the last finished gather (HIP events)
    double last_wall_ms = 0;         // host time inside mmh_gather_start + mmh_gather_finish of it

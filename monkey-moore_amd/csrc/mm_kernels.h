@@ -11,11 +11,8 @@ namespace mm {
 
 struct Tuning {
    int filter_max_conditions;        // MMOORE_FILTER_MAXCOND   (4)
-   uint64_t filter_blocks;           // MMOORE_FILTER_BLOCKS    (2048 workgroups)
-   uint64_t filter_blocks_comm;      // MMOORE_FILTER_BLOCKS_COMM (1536): with a multi-rank communicator attached, one
-                                     // workgroup slot per CU stays free for the RCCL kernel of the overlapped gather
-   uint32_t filter_gps_comm;         // MMOORE_FILTER_GPS_COMM  (7 groups per span with that grid)
-   uint32_t filter_groups_per_span;  // MMOORE_FILTER_GPS       (8 groups of 4 KiB)
+   uint64_t filter_blocks;           // MMOORE_FILTER_BLOCKS    (1536 workgroups: 6 of the 8 workgroup slots of a CU)
+   uint32_t filter_groups_per_span;  // MMOORE_FILTER_GPS       (7 groups of 4 KiB)
    unsigned resolve_blocks;          // MMOORE_RESOLVE_BLOCKS   (4096 workgroups)
    unsigned tail_blocks;             // MMOORE_TAIL_BLOCKS      (2048 workgroups of mm_scan_tail)
    uint32_t max_candidates;          // MMOORE_MAX_CANDIDATES   (262144 per scan)
@@ -41,8 +38,7 @@ bool filter_verifies(const mmh_plan_desc &pl, const FilterChoice &fc);
 // flagged domains are dropped (both for candidate floods, engine mode)
 void launch_filter(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc,
                    uint64_t *cand, unsigned long long *ctrl, uint64_t cand_cap, hipEvent_t start = nullptr,
-                   hipEvent_t stop = nullptr, unsigned int *dom_count = nullptr, const uint32_t *skip_bits = nullptr,
-                   uint64_t block_cap = 0);
+                   hipEvent_t stop = nullptr, unsigned int *dom_count = nullptr, const uint32_t *skip_bits = nullptr);
 
 // Device buffers of one scan.  ctrl is zeroed before every scan; layout: MM_CTRL_* in
 // mm_internal.h.  cand holds MM_CAND_LISTS candidate lists of cand_cap / MM_CAND_LISTS entries.

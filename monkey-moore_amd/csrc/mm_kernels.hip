@@ -1130,10 +1130,8 @@ const Tuning &tuning()
       };
       Tuning k;
       k.filter_max_conditions = (int)number("MMOORE_FILTER_MAXCOND", 4);
-      k.filter_blocks = (uint64_t)number("MMOORE_FILTER_BLOCKS", 256 * 8);
-      k.filter_blocks_comm = (uint64_t)number("MMOORE_FILTER_BLOCKS_COMM", 256 * 6);
-      k.filter_gps_comm = (uint32_t)number("MMOORE_FILTER_GPS_COMM", 7);
-      k.filter_groups_per_span = (uint32_t)number("MMOORE_FILTER_GPS", 8);
+      k.filter_blocks = (uint64_t)number("MMOORE_FILTER_BLOCKS", 256 * 6);
+      k.filter_groups_per_span = (uint32_t)number("MMOORE_FILTER_GPS", 7);
       k.resolve_blocks = (unsigned)number("MMOORE_RESOLVE_BLOCKS", 4096);
       k.tail_blocks = (unsigned)number("MMOORE_TAIL_BLOCKS", 2048);
       k.max_candidates = (uint32_t)number("MMOORE_MAX_CANDIDATES", 262144);
@@ -1244,12 +1242,16 @@ bool filter_verifies(const mmh_plan_desc &pl, const FilterChoice &fc)
    return !((pl.elem_bytes == 1 && fc.ncond >= 3) || (pl.elem_bytes == 2 && fc.ncond == 2));
 }
 
-// Launch geometry of the span kernels: 8 workgroups (32 waves) per CU fill the chip with the
-// kernels' <= 64 VGPRs; a wave streams spans of 8 groups = 32 KiB.  Measured on 4 GiB (u8):
-// spans of 4 / 8 / 16 / 32 groups -> 0.732 / 0.695 / 0.711 / 0.712 ms; 1024 .. 4096 workgroups
-// are within 0.5 % of each other (round 2, tools/geometry_times2.py: 2048 x 8 -> 0.700 ms,
-// 1536 x 7 -> 0.695, 1536 x 8 -> 0.705, 1024 x 8 -> 0.702), which is why a context with a
-// multi-rank communicator can leave a workgroup slot per CU to the RCCL kernel for free.
+// Launch geometry of the span kernels: 6 workgroups (24 waves) per CU, a wave streams spans of
+// 7 groups = 28 KiB.  The kernels' <= 64 VGPRs would let 8 workgroups per CU stay resident, but
+// the streaming rate does not need them -- measured on 4 GiB (u8): spans of 4 / 8 / 16 / 32 groups
+// -> 0.732 / 0.695 / 0.711 / 0.712 ms; 1024 .. 4096 workgroups are within 0.5 % of each other
+// (round 2, tools/geometry_times2.py + tools/pipeline_geometry.sh: 2048 x 8 -> 0.700 ms,
+// 1536 x 7 -> 0.695, 1536 x 8 -> 0.705, 1280 x 7 -> 0.700, 1024 x 8 -> 0.702) -- and the two
+// free slots per CU are what lets OTHER kernels run beside it: the tail kernel of the previous
+// scan when two scans are in flight (per-scan time 0.717 -> 0.697 ms, below the streaming kernel's
+// own duration: the next one starts while the last waves of this one drain), and the RCCL kernel
+// of an overlapped gather, which would otherwise wait for this kernel's end.
 // The environment knobs are for such experiments only.
 static uint64_t filter_max_blocks() { return tuning().filter_blocks; }
 static uint32_t filter_groups_per_span() { return tuning().filter_groups_per_span; }
@@ -1272,8 +1274,6 @@ static void launch_timed(Kernel kernel, dim3 grid, dim3 block, hipStream_t st, h
 // `start` goes to whichever runs first, `stop` to whichever runs last
 static MmTileArgs tile_args(const MmGeom &g, const mmh_plan_desc &pl);
 
-static thread_local uint64_t g_filter_block_cap = 0;     // launch_filter's block_cap for the launch under way (0 = none)
-
 template <class Span, class Edge>
 static void launch_filter_pair(Span span, Edge edge, hipStream_t st, const MmFilterArgs &a, const MmGeom &g, hipEvent_t start,
                                hipEvent_t stop)
@@ -1283,7 +1283,7 @@ static void launch_filter_pair(Span span, Edge edge, hipStream_t st, const MmFil
    if (have_span) {
       uint64_t spans = (a.ngroups + a.groups_per_span - 1) / a.groups_per_span;
       uint64_t blocks = (spans + 3) / 4;
-      const uint64_t most = g_filter_block_cap ? std::min(g_filter_block_cap, filter_max_blocks()) : filter_max_blocks();
+      const uint64_t most = filter_max_blocks();
       if (blocks > most) {
          blocks = most;
       }
@@ -1363,11 +1363,10 @@ static void fill_filter_args(A &a, const MmGeom &g, const mmh_plan_desc &pl, con
 
 void launch_filter(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc,
                    uint64_t *cand, unsigned long long *ctrl, uint64_t cand_cap, hipEvent_t start, hipEvent_t stop,
-                   unsigned int *dom_count, const uint32_t *skip_bits, uint64_t block_cap)
+                   unsigned int *dom_count, const uint32_t *skip_bits)
 {
-   g_filter_block_cap = block_cap;
    MmFilterArgs a;
-   fill_filter_args(a, g, pl, fc, cand, ctrl, cand_cap, block_cap ? tuning().filter_gps_comm : filter_groups_per_span());
+   fill_filter_args(a, g, pl, fc, cand, ctrl, cand_cap, filter_groups_per_span());
    a.dom_count = dom_count; a.skip_bits = skip_bits;
    with_shape(pl.elem_bytes, fc, [&](auto elem, auto shape) {
       constexpr int SHAPE = decltype(shape)::value;

@@ -260,7 +260,7 @@ void comm_release(mmh_ctx *c)
    m.rank = 0;
    m.nranks = 1;
    m.last_list.clear();
-   m.last_on_device = false;
+   m.last_src = nullptr;
 }
 
 } // namespace
@@ -376,11 +376,11 @@ int gather_prepare(mmh_ctx *c, const uint64_t *offsets, uint64_t n, const uint64
    const double t0 = now_s();
    s.from_host = true;
    if (!offsets && n == 0) {
-      if (m.last_on_device) {
+      if (m.last_src) {
          s.from_host = false;
-         s.src_turn = c->ws[0].result_turn;
+         s.src = m.last_src;
          s.local_count = m.last_count;
-         *send = c->ws[0].d_result[c->ws[0].result_turn];
+         *send = m.last_src;
       }
       else {
          offsets = m.last_list.data();
@@ -440,7 +440,7 @@ int long_prepare(mmh_ctx *c, MmGatherSlot &s, uint64_t longest)
          HIP_TRY(hipFree(m.d_long));
          m.d_long = nullptr;
       }
-      HIP_TRY(hipMalloc(&m.d_long, longest * sizeof(uint64_t)));
+      HIP_TRY(hipMalloc(&m.d_long, (kMergedHeader + longest) * sizeof(uint64_t)));
       m.long_cap = longest;
    }
    const uint64_t need = (uint64_t)m.nranks * longest;
@@ -458,12 +458,15 @@ int long_prepare(mmh_ctx *c, MmGatherSlot &s, uint64_t longest)
             mmh_set_error("mmh_gather_finish: the list handed to mmh_gather_start is gone (a scan ran in between)");
             return MMH_E_STATE;
          }
-         HIP_TRY(hipMemcpyAsync(m.d_long, m.last_list.data(), s.local_count * sizeof(uint64_t), hipMemcpyHostToDevice, m.stream));
+         HIP_TRY(hipMemcpyAsync(m.d_long + kMergedHeader, m.last_list.data(), s.local_count * sizeof(uint64_t), hipMemcpyHostToDevice,
+                                m.stream));
       }
       else {
-         // (its record in the table is intact whatever the scans did since)
-         HIP_TRY(hipMemcpyAsync(m.d_long, s.d_table + (uint64_t)m.rank * kRecordWords + MM_RESULT_HEADER_WORDS,
-                                s.local_count * sizeof(uint64_t), hipMemcpyDeviceToDevice, m.stream));
+         // its record in the table is intact whatever the scans did since; it may have holes (one slot per
+         // candidate): the packing kernel on that one record leaves the list behind a header nobody reads
+         hipLaunchKernelGGL(mm_gather_pack, dim3(1), dim3(256), 0, m.stream, s.d_table + (uint64_t)m.rank * kRecordWords, 1u, kRecordWords,
+                            m.d_long, longest, 1u);
+         HIP_TRY(hipGetLastError());
       }
    }
    return MMH_OK;
@@ -472,7 +475,7 @@ int long_prepare(mmh_ctx *c, MmGatherSlot &s, uint64_t longest)
 int long_collective(mmh_ctx *c, uint64_t longest)
 {
    MmComm &m = c->mg;
-   NCCL_TRY(ncclAllGather(m.d_long, m.d_long_table, longest, ncclUint64, static_cast<ncclComm_t>(m.comm), m.stream));
+   NCCL_TRY(ncclAllGather(m.d_long + kMergedHeader, m.d_long_table, longest, ncclUint64, static_cast<ncclComm_t>(m.comm), m.stream));
    return MMH_OK;
 }
 

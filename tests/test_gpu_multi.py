@@ -123,6 +123,37 @@ def test_two_gathers_in_flight_overlap_the_next_scan(mm, comm_engine, oracle):
     assert eng.gather_finish().tolist() == [0, 1, 2, 3, 4]
 
 
+def test_gather_of_collected_tickets_two_scans_and_two_gathers_in_flight(mm, comm_engine, oracle):
+    """bench.py's default pattern at N > 1: submit scan k, collect scan k-1, start its gather (sent from the lane's
+    own device-side copy), finish gather k-2 -- with keywords whose lists differ, so that a mixed-up copy shows."""
+    eng = comm_engine
+    rom = _rom(mm, eng, (6 << 20) + 12345, "relativesrch")
+    plans = [("relativesrch", 0), ("elativesrch", 0), ("re*ativesrch", ord("*")), ("relativesrc", 0), ("lativesrch", 0),
+             ("srch", 0),                       # candidate flood: collect rescans synchronously
+             ("relativesrch", 0), ("ativesrch", 0), ("rel*tivesrch", ord("*"))] * 2
+    wants = [oracle.engine(oracle.plan(1, kw, wc), rom, BLOCK) for kw, wc in plans[:9]] * 2
+    base = 1 << 33
+    delivered, tickets, gathers = [], [], 0
+    for kw, wc in plans:
+        tickets.append(eng.submit(mm.plan_relative(1, kw, wc), block_bytes=BLOCK, base_offset=base))
+        if len(tickets) == 2:
+            local = eng.collect(tickets.pop(0))
+            eng.gather_start(None)
+            gathers += 1
+            if gathers == 2:
+                delivered.append(eng.gather_finish())
+                gathers -= 1
+            assert local.tolist() == (wants[len(delivered) + gathers - 1] + np.uint64(base)).tolist()
+    eng.collect(tickets.pop(0))
+    eng.gather_start(None)
+    delivered.append(eng.gather_finish())
+    delivered.append(eng.gather_finish())
+    assert len(delivered) == len(plans)
+    for got, want in zip(delivered, wants):
+        assert got.tolist() == (want + np.uint64(base)).tolist()
+    assert len({tuple(w.tolist()) for w in wants}) > 3
+
+
 def test_packing_of_many_ranks_records(mm, comm_engine):
     """mm_gather_pack on the table an 8- / 3- / 64-rank all-gather would have left (the box has one GPU, so
     the wire never delivers more than one record here): dense records (the rank kernels'), sparse ones with
