@@ -150,6 +150,8 @@ def main():
                     help="scans in flight in the timed region: 2 = mmh_scan_submit / mmh_scan_collect, the next scan's streaming "
                          "kernel runs while the previous scan's tail kernel, result hand-over and gather finish (how the engine "
                          "drives partitions); 1 = mmh_scan, every step waits for its own result")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="N = 1 only (tests): take the N > 1 path anyway -- process group, communicator and gather of ONE rank")
     ap.add_argument("--no-other-depth", action="store_true",
                     help="skip the extra K steps at the other depth after the timed region (the 'synchronous' / 'two_in_flight' object)")
     args = ap.parse_args()
@@ -164,8 +166,10 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_gather
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from __graft_entry__ import load_package
@@ -173,7 +177,7 @@ def main():
     if not os.path.exists(mm.LIB_PATH):
         if local_rank == 0:                                  # one builder per node, the others wait
             mm.build.build_all()
-        if world > 1:
+        if multi:
             dist.barrier()
 
     gib = args.gib_per_gpu if args.gib_per_gpu is not None else CONFIGS[args.config]
@@ -201,7 +205,7 @@ def main():
     # flight; --sync-gather turns the overlap off).  Every step still delivers one merged list.
     gather_backend, gather_note = None, None
     gatherer = None
-    if world > 1:
+    if multi:
         if not args.torch_gather:
             try:
                 box = [mm.comm_unique_id() if rank == 0 else None]
@@ -218,8 +222,8 @@ def main():
         if int(ok.item()) == 0:
             gather_backend = None
             gatherer = mm.partition.OffsetGather(rank, world, dev, dist)
-    native = world > 1 and gather_backend is not None
-    if world > 1 and not native:
+    native = multi and gather_backend is not None
+    if multi and not native:
         gather_backend = "torch.distributed all_gather (test double)"
     in_flight = []
     gather_dev_ms, gather_host_ms = [], []
@@ -244,7 +248,7 @@ def main():
 
     def deliver(offs):
         """what a step hands over: the scan's list at N = 1, else the gathered one (of this or the previous step)"""
-        if world == 1:
+        if not multi:
             return offs
         if args.sync_gather:
             merged = gather_finish(gather_start(offs))
@@ -274,7 +278,7 @@ def main():
         return drain(last)
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -311,7 +315,21 @@ def main():
         fence()
         elapsed_other = time.perf_counter() - t1
         filt_other, tot_other = eng.timing_history(min(args.steps, 64))
-    if world > 1:
+    # N > 1, after the timed region: the library's gather against the torch.distributed double on one more
+    # scan of every rank -- the first place the native collective meets a real second rank
+    gather_check = None
+    if native:
+        local = eng.scan(plan, block_bytes=BLOCK, base_offset=base)
+        eng.gather_start(None, want_list=(rank == 0))
+        mine = eng.gather_finish(want_list=(rank == 0))
+        theirs = mm.partition.gather_offsets(local, rank, world, dev, dist)
+        if rank == 0:
+            same = np.array_equal(np.asarray(mine, dtype=np.uint64), np.asarray(theirs, dtype=np.uint64))
+            gather_check = ("%d offsets of %d ranks identical to the torch.distributed gather" % (len(mine), world) if same
+                            else "MISMATCH: library %d offsets, torch.distributed gather %d" % (len(mine), len(theirs)))
+            if not same:
+                sys.stderr.write("bench.py: NATIVE GATHER " + gather_check + "\n")
+    if multi:
         tmax = torch.tensor([elapsed, elapsed_other], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed, elapsed_other = float(tmax[0].item()), float(tmax[1].item())
@@ -346,7 +364,7 @@ def main():
                 "matches": int(len(offs)),
                 "candidates_rank0": ctr["candidates"],
                 "parallelism": "%d partition(s) on block boundaries%s" % (
-                    world, "" if world == 1 else ", offset gather: " + gather_backend +
+                    world, "" if not multi else ", offset gather: " + gather_backend +
                     (" (synchronous)" if args.sync_gather else ", overlapped with the next scan")),
                 "scans_in_flight": args.depth,
                 "step": ("mmh_scan_submit + mmh_scan_collect of the previous ticket: K scans submitted and K results delivered "
@@ -375,7 +393,7 @@ def main():
                           "device_total": float(np.mean(tot_ms)), "host_wall_per_step": elapsed / args.steps * 1e3},
             "counters_rank0": ctr,
         }
-        if world > 1:
+        if multi:
             # where an N > 1 step's time goes besides the scan: the collective + packing on the device
             # (HIP events on the communication stream) and the host's share of start + finish
             res["gather_ms"] = {
@@ -385,6 +403,8 @@ def main():
             }
             res["overlap"] = not args.sync_gather
             res["gather_backend"] = gather_backend
+            if gather_check:
+                res["gather_check"] = gather_check
             if gather_note:
                 res["gather_note"] = gather_note
         if not args.no_other_depth:
@@ -398,7 +418,7 @@ def main():
                     "through mmh_scan_submit / mmh_scan_collect, two scans in flight" if other_depth == 2 else
                     "through mmh_scan, one scan at a time: the latency of a single 4 GiB scan as a caller sees it"),
             }
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             cb, cpu_offs, ncov = cpu_baseline(eng, shard, KEYWORD, args.cpu_sample_mib << 20, args.cpu_warmups, args.cpu_runs)
             res["cpu_baseline"] = cb
             # parity of the timed configuration: the whole ROM when the CPU run covered it, else
@@ -413,7 +433,7 @@ def main():
                 res["config"]["parity_vs_cpu"] = "first %d MiB: %d offsets identical" % (lim >> 20, len(g)) if g == c else "MISMATCH"
             assert g == c, "GPU offsets differ from the reference CPU engine"
         print(json.dumps(res))
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()

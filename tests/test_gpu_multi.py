@@ -7,6 +7,7 @@ overlap with two gathers in flight, mmh_scan_multi, and SearchEngine<T>::run's m
 path.  Needs a real MI355X: run with `pytest -m gpu`."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -218,3 +219,31 @@ def test_search_engine_run_multi_device_path(mm):
     print(r.stdout[-3000:])
     assert r.returncode == 0, r.stdout[-3000:]
     assert " 0 failures" in r.stdout
+
+
+@pytest.mark.parametrize("extra", [[], ["--depth", "1"], ["--sync-gather"], ["--torch-gather"]])
+def test_bench_multi_rank_path_with_one_rank(extra):
+    """bench.py's N > 1 code path (process group, unique id, communicator, overlapped gather of collected
+    tickets, the native-vs-torch gather check) with the one rank the box has."""
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-gather", "--gib-per-gpu", "0.25", "--steps", "6", "--warmup", "2",
+           "--prewarm-s", "0.02", "--no-cpu-baseline"] + extra
+    env = dict(os.environ, MASTER_PORT=str(29600 + os.getpid() % 300))
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, r.stdout[-2000:]
+    res = json.loads(line[0])
+    assert res["n_gpus"] == 1 and res["steps"] == 6 and res["value"] > 0
+    assert res["config"]["matches"] == 256 + 3 + 3 or res["config"]["matches"] > 200       # 1 plant / MiB + straddlers
+    assert res["config"]["scans_in_flight"] == (1 if "--depth" in extra else 2)
+    assert res["overlap"] == ("--sync-gather" not in extra)
+    assert "gather_note" not in res
+    if "--torch-gather" in extra:
+        assert "test double" in res["gather_backend"] and "gather_check" not in res
+    else:
+        assert "librccl" in res["gather_backend"]
+        assert "identical" in res["gather_check"]
+        assert res["gather_ms"]["device_collective_and_pack"] > 0
+    other = res["two_in_flight" if "--depth" in extra else "synchronous"]
+    assert other["same_offsets"] is True
