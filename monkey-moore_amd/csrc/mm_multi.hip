@@ -32,6 +32,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -479,6 +480,52 @@ int long_collective(mmh_ctx *c, uint64_t longest)
    return MMH_OK;
 }
 
+// A collective only ends when every rank has joined it: a peer that died or never called
+// mmh_gather_start would leave hipEventSynchronize waiting for good.  Poll instead, watch the
+// communicator's asynchronous error state, and give up loudly after MMOORE_GATHER_TIMEOUT_S
+// (default 120 s).  After a time-out the communicator is unusable: destroy the context.
+double gather_timeout_s()
+{
+   static const double limit = [] {
+      const char *e = getenv("MMOORE_GATHER_TIMEOUT_S");
+      const double v = e && *e ? atof(e) : 0;
+      return v > 0 ? v : 120.0;
+   }();
+   return limit;
+}
+
+int wait_collective(MmComm &m, hipEvent_t done)
+{
+   const double t0 = now_s();
+   for (uint64_t spins = 1;; spins++) {
+      const hipError_t e = hipEventQuery(done);
+      if (e == hipSuccess) {
+         return MMH_OK;
+      }
+      if (e != hipErrorNotReady) {
+         (void)hip_ok(e, "hipEventQuery (gather)");
+         return MMH_E_DEVICE;
+      }
+      if (spins % 512 == 0) {
+         ncclResult_t async = ncclSuccess;
+         if (ncclCommGetAsyncError(static_cast<ncclComm_t>(m.comm), &async) == ncclSuccess && async != ncclSuccess &&
+             async != ncclInProgress) {
+            mmh_set_error("mmh_gather_finish: the communicator reports %s", ncclGetErrorString(async));
+            return MMH_E_DEVICE;
+         }
+         const double waited = now_s() - t0;
+         if (waited > gather_timeout_s()) {
+            mmh_set_error("mmh_gather_finish: the collective of rank %d / %d did not end within %.0f s -- a peer rank is missing "
+                          "or stuck (MMOORE_GATHER_TIMEOUT_S)", m.rank, m.nranks, gather_timeout_s());
+            return MMH_E_DEVICE;
+         }
+         if (waited > 0.002) {
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+         }
+      }
+   }
+}
+
 // wait for the first phase of the oldest gather; *longest > MM_MAX_RANK_SORT: second phase needed
 int gather_wait(mmh_ctx *c, uint64_t *total, uint64_t *longest)
 {
@@ -489,7 +536,10 @@ int gather_wait(mmh_ctx *c, uint64_t *total, uint64_t *longest)
       return MMH_E_STATE;
    }
    HIP_TRY(hipSetDevice(c->device));
-   HIP_TRY(hipEventSynchronize(s.end));
+   const int rc = wait_collective(m, s.end);
+   if (rc != MMH_OK) {
+      return rc;
+   }
    *total = s.h_merged[0];
    *longest = s.h_merged[1];
    return MMH_OK;
@@ -519,7 +569,11 @@ int gather_deliver(mmh_ctx *c, uint64_t *out, uint64_t cap, uint64_t *out_count,
             at += n;
          }
       }
-      HIP_TRY(hipStreamSynchronize(m.stream));
+      HIP_TRY(hipEventRecord(s.end, m.stream));      // (the gather's device time then covers both phases)
+      const int rc = wait_collective(m, s.end);
+      if (rc != MMH_OK) {
+         return rc;
+      }
    }
    else if (out && total) {
       std::memcpy(out, s.h_merged + kMergedHeader, total * sizeof(uint64_t));
