@@ -65,3 +65,16 @@ def test_reference_unit_tests_on_the_facade_under_sanitizers():
                           [os.path.join(ROOT, "tests", "shim", "catch_main.cpp")] + FACADE + ["-o", exe])
     assert " 0 failures" in _run(exe)
     assert " 0 failures" in _run(exe, MMOORE_DOUBLE_DEVICES="2", MMOORE_HIP_MULTI="1")
+
+
+def test_facade_under_thread_sanitizer():
+    """concurrent search() calls on one MonkeyMoore, run()'s loader threads and serialized callbacks"""
+    os.makedirs(BUILD, exist_ok=True)
+    subprocess.check_call(["python3", os.path.join(CPP, "gen_cases.py"), os.path.join(BUILD, "cases.inc")])
+    exe = os.path.join(BUILD, "facade_tests_tsan")
+    tsan = [a if not a.startswith("-fsanitize=") else "-fsanitize=thread" for a in SAN if a != "-fno-sanitize-recover=all"]
+    subprocess.check_call(tsan + ["-I" + BUILD, os.path.join(CPP, "facade_tests.cpp")] + FACADE + ["-o", exe])
+    for env in ({}, {"MMOORE_DOUBLE_DEVICES": "3", "MMOORE_HIP_MULTI": "1"}):
+        r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0 and "ThreadSanitizer" not in r.stdout, r.stdout[-4000:]
+        assert " 0 failures" in r.stdout
