@@ -1237,6 +1237,30 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
 // Anything the lanes do not run themselves -- forced engines, patterns without a SWAR key,
 // candidate floods, lists beyond the rank kernels -- is rescanned synchronously by collect.
 
+namespace {
+// fills in the timings a collected lane scan still owes (see mmh_ctx::lane_timing_owed); its events have
+// completed or are about to
+void settle_lane_timing(mmh_ctx *c, int lane)
+{
+   const int64_t k = c->lane_timing_owed[lane];
+   if (k < 0) {
+      return;
+   }
+   c->lane_timing_owed[lane] = -1;
+   if (c->scans_recorded - (uint64_t)k > mmh_ctx::kRing) {
+      return;                                  // its ring slot belongs to a later scan by now
+   }
+   hipEvent_t *e = c->lane_ev[lane];
+   float filter_ms = 0, total_ms = 0;
+   if (hipEventSynchronize(e[2]) == hipSuccess && hipEventElapsedTime(&filter_ms, e[0], e[1]) == hipSuccess &&
+       hipEventElapsedTime(&total_ms, e[0], e[2]) == hipSuccess) {
+      const int slot = (int)((uint64_t)k % mmh_ctx::kRing);
+      c->ring_ms[slot][0] = filter_ms;
+      c->ring_ms[slot][1] = total_ms;
+   }
+}
+} // namespace
+
 extern "C" int mmh_scan_submit(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian,
                                uint64_t base_offset, int *ticket)
 {
@@ -1288,9 +1312,20 @@ extern "C" int mmh_scan_submit(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t b
       // the ROM may still be in the making on the context's stream (upload, synth, poke)
       HIP_TRY(hipEventRecord(c->lane_fence, c->stream));
       HIP_TRY(hipStreamWaitEvent(c->lane_stream[lane], c->lane_fence, 0));
-      // (Making this lane's filter wait for the other lane's "filter done" event was tried, with
-      // filter grids of 1024 .. 2048 workgroups: 766-913 us per scan instead of 697 -- the
-      // hardware interleaves the two queues better on its own.)
+      // How the two lanes share the device (rocprofv3 kernel trace, tools/lane_trace.sh): a lane's tail kernel
+      // (96 VGPRs) does not fit beside the other lane's streaming kernel (6 waves x 72 VGPRs per SIMD), so it
+      // is dispatched but only gets going while that kernel drains -- at the same time as this lane's next
+      // streaming kernel, which starts ~0.12 ms before the other one ends.  The ends of the streaming kernels
+      // (waves finishing at different times, bandwidth going unused) are thus filled with the next scan's
+      // start and the previous scan's tail: 0.70 ms per scan, the duration of ONE streaming kernel run alone.
+      // Tried and dropped: this lane's filter waiting for the other lane's "filter done" event (766-913 us
+      // per scan); the streaming kernels of both lanes on one stream and the tail kernels on the lanes'
+      // (strictly consecutive filters, tail beside the next filter from its start: the tail takes 390 us
+      // instead of 29 under the memory load and the filter 786 instead of 697 -- 0.80 ms per scan); a tail
+      // kernel of 80 VGPRs, which does fit beside six streaming waves (0.712-0.732 ms with 256 .. 2048
+      // workgroups of it against 0.702-0.706: a tail that runs beside a streaming kernel costs more than
+      // one that waits for its drain).
+      settle_lane_timing(c, lane);             // (before the lane's events are recorded again)
       for (auto &e : c->lane_ev[lane]) {
          if (!e) {
             HIP_TRY(hipEventCreate(&e));
@@ -1333,14 +1368,29 @@ extern "C" int mmh_scan_collect(mmh_ctx *c, int ticket, uint64_t *out, uint64_t 
          return rc;
       }
       rescan = oc.candidates > w.out_cap || oc.candidates > p.max_candidates || oc.hard_overflow || !oc.sorted_on_device;
-      // the lane's timings enter the history now that its events have completed
+      static const bool lane_trace = getenv("MMOORE_LANE_TRACE") != nullptr;     // development: where the lanes' kernels lie in time
+      if (lane_trace) {
+         static hipEvent_t base = nullptr;
+         if (!base && hipEventCreate(&base) == hipSuccess) {
+            (void)hipEventRecord(base, c->lane_stream[ticket & 1]);
+            (void)hipEventSynchronize(base);
+         }
+         float t0 = 0, t1 = 0, own = 0;
+         (void)hipEventElapsedTime(&t0, base, p.ev[0]);
+         (void)hipEventElapsedTime(&t1, base, p.ev[1]);
+         (void)hipEventElapsedTime(&own, p.ev[0], p.ev[1]);
+         fprintf(stderr, "lane %d ticket %d: streaming kernel dispatched %.1f us, ended %.1f us after the first collect; ran %.1f us\n",
+                 ticket & 1, ticket, t0 * 1e3, t1 * 1e3, own * 1e3);
+      }
+      // the lane's timings enter the history: now when its last event has completed, else a little later
+      const int lane = ticket & 1;
       const int slot = (int)(c->scans_recorded % mmh_ctx::kRing);
-      float filter_ms = 0, total_ms = 0;
-      if (hipEventElapsedTime(&filter_ms, p.ev[0], p.ev[1]) == hipSuccess && hipEventElapsedTime(&total_ms, p.ev[0], p.ev[2]) == hipSuccess) {
-         c->ring_is_ms[slot] = true;
-         c->ring_ms[slot][0] = filter_ms;
-         c->ring_ms[slot][1] = total_ms;
-         c->scans_recorded++;
+      c->ring_is_ms[slot] = true;
+      c->ring_ms[slot][0] = c->ring_ms[slot][1] = 0;
+      c->lane_timing_owed[lane] = (int64_t)c->scans_recorded;
+      c->scans_recorded++;
+      if (hipEventQuery(p.ev[2]) == hipSuccess) {
+         settle_lane_timing(c, lane);
       }
    }
    if (rescan) {
@@ -1407,6 +1457,8 @@ extern "C" int mmh_last_timings(mmh_ctx *c, float *ms4)
       std::memset(ms4, 0, 4 * sizeof(float));
       return MMH_OK;
    }
+   settle_lane_timing(c, 0);
+   settle_lane_timing(c, 1);
    scan_timings(c, c->scans_recorded - 1, ms4);
    return MMH_OK;
 }
@@ -1417,6 +1469,8 @@ extern "C" int mmh_timing_history(mmh_ctx *c, float *filter_ms, float *total_ms,
       mmh_set_error("mmh_timing_history: bad argument");
       return MMH_E_ARG;
    }
+   settle_lane_timing(c, 0);
+   settle_lane_timing(c, 1);
    const uint64_t have = std::min<uint64_t>(c->scans_recorded, mmh_ctx::kRing);
    const int n = (int)std::min<uint64_t>(have, (uint64_t)cap);
    for (int i = 0; i < n; i++) {

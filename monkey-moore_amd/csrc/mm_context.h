@@ -140,6 +140,10 @@ struct mmh_ctx {
    hipStream_t lane_stream[2] = {nullptr, nullptr};   // streams of the submit lanes
    hipEvent_t lane_fence = nullptr;                     // orders a lane behind earlier work on `stream`
    hipEvent_t lane_ev[2][3] = {};                       // event triples of the two lanes
+   // A lane's scan is over for the host when its flag shows in pinned memory -- a few microseconds before its
+   // last event completes: the timings of such a scan are filled in later (before the lane's events are
+   // recorded again, or when timings are asked for).  -1: nothing owed; else the scan's number (ring slot = % kRing).
+   int64_t lane_timing_owed[2] = {-1, -1};
    MmPending pending[2];
    int next_ticket = 0;
    int engine = 0;

@@ -16,6 +16,59 @@ stats = glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursi
 if stats:
     shutil.copy(stats[0], os.path.join(dst, tag + "_kernel_stats.csv"))
 shutil.copy(os.path.join(out, "bench_n1.json"), os.path.join(dst, tag + "_bench_n1.json"))
+stats1 = glob.glob(os.path.join(out, "stats_depth1", "**", "*kernel_stats.csv"), recursive=True)
+if stats1:
+    shutil.copy(stats1[0], os.path.join(dst, tag + "_kernel_stats_depth1.csv"))
+
+
+def by_phase():
+    """The default run's kernel trace cut into bench.py's phases (launch order): the pre-warm scans and the
+    synchronous leg run one scan at a time, the warm-up + timed steps two in flight.  Kept next to the trace
+    itself so that the figures can be recomputed."""
+    import gzip
+    traces = glob.glob(os.path.join(out, "stats", "**", "*kernel_trace.csv"), recursive=True)
+    line = [l for l in open(os.path.join(out, "bench_under_rocprof.json")).read().splitlines() if l.startswith("{")]
+    if not traces or not line:
+        return
+    b = json.loads(line[-1])
+    rows = []
+    for f in traces:
+        rows += [r for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith(("void mm_filter", "void mm_scan_tail"))]
+    if not rows:
+        return
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    with gzip.open(os.path.join(dst, tag + "_kernel_trace_default_run.csv.gz"), "wt") as g:
+        w = csv.writer(g)
+        w.writerow(["Kernel_Name", "Stream_Id", "Start_Timestamp", "End_Timestamp"])
+        for r in rows:
+            w.writerow([r["Kernel_Name"].split("(")[0], r["Stream_Id"], r["Start_Timestamp"], r["End_Timestamp"]])
+    filt = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if "mm_filter" in r["Kernel_Name"]]
+    tail = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if "mm_scan_tail" in r["Kernel_Name"]]
+    K, W, pre = b["steps"], b["warmup"], b["config"]["prewarm_scans"]
+    d2 = b["config"]["scans_in_flight"] == 2
+    phases = [("prewarm, one scan at a time", pre), ("warm-up, %d in flight" % (2 if d2 else 1), W),
+              ("TIMED steps, %d in flight" % (2 if d2 else 1), K),
+              ("warm-up of the other leg", max(W, 4)), ("other leg, %d in flight" % (1 if d2 else 2), K)]
+    res, at = {"launches_of_the_streaming_kernel": len(filt), "phases": []}, 0
+    for name, n in phases:
+        f, t = filt[at:at + n], tail[at:at + n]
+        at += n
+        if len(f) < 2:
+            continue
+        res["phases"].append({
+            "phase": name, "launches": len(f),
+            "streaming_kernel_avg_us": sum(e - s for s, e in f) / len(f) / 1e3,
+            "streaming_kernel_start_to_start_avg_us": (f[-1][0] - f[0][0]) / (len(f) - 1) / 1e3,
+            "tail_kernel_avg_us (dispatch to end: with two in flight it waits for registers beside the other lane's streaming kernel)":
+                sum(e - s for s, e in t) / max(len(t), 1) / 1e3,
+        })
+    res["bench_line_of_this_run"] = {"ms_per_step": b["ms_per_step"], "roofline_kernel_ms": b["roofline"]["kernel_ms"],
+                                     "timed_region": b["roofline"].get("timed_region")}
+    json.dump(res, open(os.path.join(dst, tag + "_kernel_trace_by_phase.json"), "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+by_phase()
 
 
 def counter_avgs(dirname, counter):
@@ -44,8 +97,8 @@ lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 summary = {
     # bench.py reports `roofline.traffic` from this file only while the library it runs is THIS build
     "library_sha16": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16],
-    "command_fetch": "rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-depth --prewarm-s 0.05",
-    "command_write": "rocprofv3 --pmc WRITE_SIZE --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-depth --prewarm-s 0.05",
+    "command_fetch": "rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 3 --warmup 1 --depth 1 --no-cpu-baseline --no-other-depth --prewarm-s 0.05",
+    "command_write": "rocprofv3 --pmc WRITE_SIZE --output-format csv -- python3 bench.py --steps 3 --warmup 1 --depth 1 --no-cpu-baseline --no-other-depth --prewarm-s 0.05",
     "note": "separate --pmc passes; counters are in KiB; per MI355X_MICROARCH.md gfx950 FETCH_SIZE reports half of the bytes of a "
             "wide coalesced (16 B/lane) streaming read, so the read side is doubled; WRITE_SIZE is exact "
             "(calibration: mm_synth_fill writes the whole ROM and reports exactly its size)",
