@@ -146,14 +146,18 @@ def main():
                     help="N > 1: finish every step's offset gather before the next scan starts (no overlap)")
     ap.add_argument("--torch-gather", action="store_true",
                     help="N > 1: gather through torch.distributed (the test double) instead of the library's own RCCL calls")
-    ap.add_argument("--depth", type=int, choices=(1, 2), default=2,
-                    help="scans in flight in the timed region: 2 = mmh_scan_submit / mmh_scan_collect, the next scan's streaming "
-                         "kernel runs while the previous scan's tail kernel, result hand-over and gather finish (how the engine "
-                         "drives partitions); 1 = mmh_scan, every step waits for its own result")
+    ap.add_argument("--depth", type=int, choices=(1, 2, 3), default=3,
+                    help="tickets outstanding in the timed region: 2 or 3 = mmh_scan_submit / mmh_scan_collect, the next scan's "
+                         "streaming kernel runs while the previous scan's tail kernel, result hand-over and gather finish (two "
+                         "scans are at work on the device either way; with 3 the host has the next one enqueued ahead and may be "
+                         "late); 1 = mmh_scan, every step waits for its own result")
+    ap.add_argument("--host-delay-us", type=float, default=0.0,
+                    help="development probe: the host idles this long after every step's result (a host that is late); "
+                         "never used for a reported figure")
     ap.add_argument("--force-gather", action="store_true",
                     help="N = 1 only (tests): take the N > 1 path anyway -- process group, communicator and gather of ONE rank")
     ap.add_argument("--no-other-depth", action="store_true",
-                    help="skip the extra K steps at the other depth after the timed region (the 'synchronous' / 'two_in_flight' object)")
+                    help="skip the extra K steps at the other depth after the timed region (the 'synchronous' / 'in_flight' object)")
     args = ap.parse_args()
 
     import torch
@@ -263,15 +267,22 @@ def main():
             merged = gather_finish(in_flight.pop(0))
         return merged if (rank == 0 and merged is not None) else last
 
+    def late_host():
+        if args.host_delay_us > 0:
+            t_end = time.perf_counter() + args.host_delay_us * 1e-6
+            while time.perf_counter() < t_end:
+                pass
+
     def run_steps(k, depth):
         """k steps = k scans of the shard + k deliveries, nothing left in flight at the end"""
         last, tickets = None, []
         for _ in range(k):
+            late_host()
             if depth == 1:
                 last = deliver(eng.scan(plan, block_bytes=BLOCK, base_offset=base))
             else:
                 tickets.append(eng.submit(plan, block_bytes=BLOCK, base_offset=base))
-                if len(tickets) == 2:
+                if len(tickets) == depth:
                     last = deliver(eng.collect(tickets.pop(0)))
         while tickets:
             last = deliver(eng.collect(tickets.pop(0)))
@@ -305,7 +316,7 @@ def main():
     gather_dev, gather_host = list(gather_dev_ms), list(gather_host_ms)
 
     # Extra, NOT part of `value`: the same K steps at the other depth.
-    other_depth = 3 - args.depth
+    other_depth = 1 if args.depth > 1 else 3
     offs_other, elapsed_other = None, 0.0
     if not args.no_other_depth:
         run_steps(max(args.warmup, 4), other_depth)
@@ -347,7 +358,7 @@ def main():
             alone_filt, alone_tot, alone_src = filt_other, tot_other, (
                 "the K synchronous steps behind the timed region (mmh_scan, one scan at a time: launches that overlap nothing)")
         else:
-            alone_filt, alone_tot, alone_src = filt_ms, tot_ms, "the K timed steps, two scans in flight: launches OVERLAP (--no-other-depth)"
+            alone_filt, alone_tot, alone_src = filt_ms, tot_ms, "the K timed steps, scans in flight: launches OVERLAP (--no-other-depth)"
         filt = float(np.mean(alone_filt))
         assert filt > 0, "the library reported no streaming-phase timing"
         assert float(np.mean(filt_ms)) > 0
@@ -379,10 +390,11 @@ def main():
                     world, "" if not multi else ", offset gather: " + gather_backend +
                     (" (synchronous)" if args.sync_gather else ", overlapped with the next scan")),
                 "scans_in_flight": args.depth,
-                "step": ("mmh_scan_submit + mmh_scan_collect of the previous ticket: K scans submitted and K results delivered "
-                         "inside the timed region, two in flight" if args.depth == 2 else
-                         "mmh_scan: every step waits for its own result"),
+                "step": ("mmh_scan_submit + mmh_scan_collect of an earlier ticket: K scans submitted and K results delivered "
+                         "inside the timed region, %d tickets outstanding (two scans at work on the device)" % args.depth
+                         if args.depth > 1 else "mmh_scan: every step waits for its own result"),
                 "prewarm_scans": prewarm_scans,
+                **({"host_delay_us": args.host_delay_us} if args.host_delay_us > 0 else {}),
             },
             "roofline": {
                 "bound": "hbm",
@@ -406,8 +418,8 @@ def main():
                     "kernel_ms": float(np.mean(filt_ms)),
                     "kernel_period_ms": elapsed / args.steps * 1e3,
                     "bytes_per_period_GBps": shard / (elapsed / args.steps) / 1e9,
-                    "note": ("launch durations in the timed region; with two scans in flight consecutive streaming kernels overlap, "
-                             "so kernel_ms here exceeds the period at which launches complete" if args.depth == 2 else
+                    "note": ("launch durations in the timed region; with scans in flight consecutive streaming kernels overlap, "
+                             "so kernel_ms here exceeds the period at which launches complete" if args.depth > 1 else
                              "one scan at a time: the same launches as kernel_ms above"),
                 },
             },
@@ -432,12 +444,12 @@ def main():
         if not args.no_other_depth:
             same = bool(np.array_equal(offs_other, offs))
             assert same, "the two depths delivered different lists"
-            res["two_in_flight" if other_depth == 2 else "synchronous"] = {
+            res["in_flight" if other_depth > 1 else "synchronous"] = {
                 "value": total * args.steps / elapsed_other / 1e9, "unit": "GB/s", "ms_per_step": elapsed_other / args.steps * 1e3,
                 "kernel_ms": float(np.mean(filt_other)), "scan_device_ms": float(np.mean(tot_other)),
                 "same_offsets": same,
                 "note": "not the headline value: the same K steps " + (
-                    "through mmh_scan_submit / mmh_scan_collect, two scans in flight" if other_depth == 2 else
+                    "through mmh_scan_submit / mmh_scan_collect, %d tickets outstanding" % other_depth if other_depth > 1 else
                     "through mmh_scan, one scan at a time: the latency of a single 4 GiB scan as a caller sees it"),
             }
         if not multi and not args.no_cpu_baseline:

@@ -137,13 +137,16 @@ int mmh_rom_fill(mmh_ctx *ctx, uint64_t first_byte, uint64_t nbytes, int value, 
 int mmh_scan(mmh_ctx *ctx, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian,
              uint64_t base_offset, uint64_t *out, uint64_t cap, uint64_t *out_count);
 
-/* Two scans in flight, for back-to-back scans (many keywords, many ROM partitions):
- * mmh_scan_submit enqueues a scan with the arguments of mmh_scan on one of two internal lanes
+/* Scans in flight, for back-to-back scans (many keywords, many ROM partitions):
+ * mmh_scan_submit enqueues a scan with the arguments of mmh_scan on one of three internal lanes
  * (own stream, workspace and result block) and returns a ticket; mmh_scan_collect waits for
- * that scan and delivers its offsets exactly as mmh_scan would.  At most two tickets may be
- * outstanding; the ROM must not change while one is.  The host's share of a scan and the
- * small kernels behind the streaming filter then overlap the next scan's streaming kernel.
- * MMH_E_CAPACITY from collect leaves the ticket outstanding: collect again with more room. */
+ * that scan and delivers its offsets exactly as mmh_scan would.  At most MMH_MAX_IN_FLIGHT
+ * tickets may be outstanding (a further submit fails with MMH_E_STATE); collect them in the
+ * order they were submitted; the ROM must not change while one is outstanding.  The host's share
+ * of a scan and the kernel behind the streaming filter then overlap the next scan's streaming
+ * kernel: two outstanding tickets already do that, the third keeps the device fed when the host
+ * is late.  MMH_E_CAPACITY from collect leaves the ticket outstanding: collect again with more room. */
+#define MMH_MAX_IN_FLIGHT 3
 int mmh_scan_submit(mmh_ctx *ctx, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian,
                     uint64_t base_offset, int *ticket);
 int mmh_scan_collect(mmh_ctx *ctx, int ticket, uint64_t *out, uint64_t cap, uint64_t *out_count);

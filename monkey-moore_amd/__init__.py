@@ -33,6 +33,7 @@ EXPORTS = [
     "mmh_gather_start", "mmh_gather_finish", "mmh_last_gather_timings", "mmh_scan_multi", "mmh_selftest_gather_pack",
 ]
 MMH_GATHER_RECORD_WORDS = 8 + 16384
+MMH_MAX_IN_FLIGHT = 3
 MMH_COMM_ID_BYTES = 128
 
 
@@ -311,7 +312,7 @@ class Engine:
             return out[: self._count.value].copy()
 
     def submit(self, plan, block_bytes=0, big_endian=False, base_offset=0):
-        """Enqueue a scan (at most two outstanding); returns the ticket for collect()."""
+        """Enqueue a scan (at most MMH_MAX_IN_FLIGHT = 3 outstanding); returns the ticket for collect()."""
         t = C.c_int(0)
         _check(lib().mmh_scan_submit(self._h, C.byref(plan), block_bytes, int(big_endian), base_offset, C.byref(t)))
         return t.value

@@ -1228,12 +1228,13 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
    return rc;
 }
 
-// ---- two scans in flight ------------------------------------------------------------------
+// ---- scans in flight ----------------------------------------------------------------------
 //
-// mmh_scan_submit enqueues the filter + resolver pipeline of a scan on one of two lanes (own
+// mmh_scan_submit enqueues the streaming kernel + tail kernel of a scan on one of three lanes (own
 // stream, own workspace, own pinned result block) and returns; mmh_scan_collect waits for it.
-// With two lanes the host's share of a scan (launches, the wait, copying the offsets out) and
-// the small kernels behind the streaming filter overlap the NEXT scan's streaming kernel.
+// The host's share of a scan (launches, the wait, copying the offsets out) and the tail kernel
+// then overlap the NEXT scan's streaming kernel; two scans are at work on the device at a time,
+// the third lane holds the one the host has enqueued ahead (see mmh_scan_submit).
 // Anything the lanes do not run themselves -- forced engines, patterns without a SWAR key,
 // candidate floods, lists beyond the rank kernels -- is rescanned synchronously by collect.
 
@@ -1272,10 +1273,10 @@ extern "C" int mmh_scan_submit(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t b
    if (rc != MMH_OK) {
       return rc;
    }
-   const int lane = c->next_ticket & 1;
+   const int lane = c->next_ticket % mmh_ctx::kLanes;
    MmPending &p = c->pending[lane];
    if (p.active) {
-      mmh_set_error("mmh_scan_submit: two scans are already outstanding, collect ticket %d first", p.ticket);
+      mmh_set_error("mmh_scan_submit: %d scans are already outstanding, collect ticket %d first", mmh_ctx::kLanes, p.ticket);
       return MMH_E_STATE;
    }
    HIP_TRY(hipSetDevice(c->device));
@@ -1312,19 +1313,27 @@ extern "C" int mmh_scan_submit(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t b
       // the ROM may still be in the making on the context's stream (upload, synth, poke)
       HIP_TRY(hipEventRecord(c->lane_fence, c->stream));
       HIP_TRY(hipStreamWaitEvent(c->lane_stream[lane], c->lane_fence, 0));
-      // How the two lanes share the device (rocprofv3 kernel trace, tools/lane_trace.sh): a lane's tail kernel
-      // (96 VGPRs) does not fit beside the other lane's streaming kernel (6 waves x 72 VGPRs per SIMD), so it
-      // is dispatched but only gets going while that kernel drains -- at the same time as this lane's next
-      // streaming kernel, which starts ~0.12 ms before the other one ends.  The ends of the streaming kernels
-      // (waves finishing at different times, bandwidth going unused) are thus filled with the next scan's
-      // start and the previous scan's tail: 0.70 ms per scan, the duration of ONE streaming kernel run alone.
-      // Tried and dropped: this lane's filter waiting for the other lane's "filter done" event (766-913 us
-      // per scan); the streaming kernels of both lanes on one stream and the tail kernels on the lanes'
-      // (strictly consecutive filters, tail beside the next filter from its start: the tail takes 390 us
-      // instead of 29 under the memory load and the filter 786 instead of 697 -- 0.80 ms per scan); a tail
-      // kernel of 80 VGPRs, which does fit beside six streaming waves (0.712-0.732 ms with 256 .. 2048
-      // workgroups of it against 0.702-0.706: a tail that runs beside a streaming kernel costs more than
-      // one that waits for its drain).
+      // How scans in flight share the device (rocprofv3 kernel trace, tools/lane_trace.sh).  Scan t starts
+      // behind scan t-2 (the wait below) and runs beside scan t-1: the tail kernel of t-2 (96 VGPRs) does not
+      // fit beside the streaming kernel of t-1 (6 waves x 72 VGPRs per SIMD), so it is dispatched but only
+      // gets going while that kernel drains -- and then the streaming kernel of t starts, ~0.12 ms before
+      // that of t-1 ends.  The ends of the streaming kernels (waves finishing one by one, bandwidth going
+      // unused) are thus filled with the next scan's start and the previous scan's tail: 0.70 ms per scan,
+      // the duration of ONE streaming kernel run alone.  Three lanes, although only two scans are ever at
+      // work on the device: the third is the one the host has ALREADY enqueued -- with two, scan t could
+      // only be submitted once t-2 had been collected, ~0.12 ms before its kernel was due, and a host that
+      // was late (a busy box: 0.80 ms per scan measured) left the device waiting.
+      // Tried and dropped: a scan's filter waiting for the previous scan's "filter done" event (766-913 us
+      // per scan); all streaming kernels on one stream and the tail kernels on the lanes' (strictly
+      // consecutive filters, tail beside the next filter from its start: the tail takes 390 us instead of 29
+      // under the memory load and the filter 786 instead of 697 -- 0.80 ms per scan); a tail kernel of 80
+      // VGPRs, which does fit beside six streaming waves (0.712-0.732 ms with 256 .. 2048 workgroups of it
+      // against 0.702-0.706: a tail that runs beside a streaming kernel costs more than one that waits for
+      // its drain).
+      const int before = (c->next_ticket + mmh_ctx::kLanes - 2) % mmh_ctx::kLanes;       // lane of scan t-2
+      if (c->next_ticket >= 2 && c->lane_ev_recorded[before]) {
+         HIP_TRY(hipStreamWaitEvent(c->lane_stream[lane], c->lane_ev[before][2], 0));
+      }
       settle_lane_timing(c, lane);             // (before the lane's events are recorded again)
       for (auto &e : c->lane_ev[lane]) {
          if (!e) {
@@ -1334,10 +1343,12 @@ extern "C" int mmh_scan_submit(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t b
       std::copy(c->lane_ev[lane], c->lane_ev[lane] + 3, p.ev);
       // (filter + tail kernel, the end polled in the lane's own pinned block; never the single-launch kernel:
       // its grid barrier wants the device to itself)
+      c->lane_ev_recorded[lane] = false;
       rc = enqueue_pipeline(c, w, c->lane_stream[lane], p.ev, g, *plan, fc, false, base_offset, p.max_candidates, nullptr, true, false);
       if (rc != MMH_OK) {
          return rc;
       }
+      c->lane_ev_recorded[lane] = true;
    }
    p.active = true;
    *ticket = c->next_ticket++;
@@ -1351,7 +1362,8 @@ extern "C" int mmh_scan_collect(mmh_ctx *c, int ticket, uint64_t *out, uint64_t 
       return MMH_E_ARG;
    }
    *out_count = 0;
-   MmPending &p = c->pending[ticket & 1];
+   const int lane = ((ticket % mmh_ctx::kLanes) + mmh_ctx::kLanes) % mmh_ctx::kLanes;
+   MmPending &p = c->pending[lane];
    if (!p.active || p.ticket != ticket) {
       mmh_set_error("mmh_scan_collect: ticket %d is not outstanding", ticket);
       return MMH_E_STATE;
@@ -1359,10 +1371,10 @@ extern "C" int mmh_scan_collect(mmh_ctx *c, int ticket, uint64_t *out, uint64_t 
    HIP_TRY(hipSetDevice(c->device));
    bool rescan = p.needs_rescan;
    Outcome oc;
-   MmWorkspace &w = c->ws[1 + (ticket & 1)];
+   MmWorkspace &w = c->ws[1 + lane];
    if (!rescan) {
       const MmGeom g = scan_geometry(c, &p.plan, p.block_bytes, p.big_endian);
-      int rc = finish_pipeline(c, w, c->lane_stream[ticket & 1], p.ev, g, p.plan, p.base_offset, p.max_candidates, false, &oc);
+      int rc = finish_pipeline(c, w, c->lane_stream[lane], p.ev, g, p.plan, p.base_offset, p.max_candidates, false, &oc);
       if (rc != MMH_OK) {
          p.active = false;
          return rc;
@@ -1372,7 +1384,7 @@ extern "C" int mmh_scan_collect(mmh_ctx *c, int ticket, uint64_t *out, uint64_t 
       if (lane_trace) {
          static hipEvent_t base = nullptr;
          if (!base && hipEventCreate(&base) == hipSuccess) {
-            (void)hipEventRecord(base, c->lane_stream[ticket & 1]);
+            (void)hipEventRecord(base, c->lane_stream[lane]);
             (void)hipEventSynchronize(base);
          }
          float t0 = 0, t1 = 0, own = 0;
@@ -1380,10 +1392,9 @@ extern "C" int mmh_scan_collect(mmh_ctx *c, int ticket, uint64_t *out, uint64_t 
          (void)hipEventElapsedTime(&t1, base, p.ev[1]);
          (void)hipEventElapsedTime(&own, p.ev[0], p.ev[1]);
          fprintf(stderr, "lane %d ticket %d: streaming kernel dispatched %.1f us, ended %.1f us after the first collect; ran %.1f us\n",
-                 ticket & 1, ticket, t0 * 1e3, t1 * 1e3, own * 1e3);
+                 lane, ticket, t0 * 1e3, t1 * 1e3, own * 1e3);
       }
       // the lane's timings enter the history: now when its last event has completed, else a little later
-      const int lane = ticket & 1;
       const int slot = (int)(c->scans_recorded % mmh_ctx::kRing);
       c->ring_is_ms[slot] = true;
       c->ring_ms[slot][0] = c->ring_ms[slot][1] = 0;
@@ -1457,8 +1468,9 @@ extern "C" int mmh_last_timings(mmh_ctx *c, float *ms4)
       std::memset(ms4, 0, 4 * sizeof(float));
       return MMH_OK;
    }
-   settle_lane_timing(c, 0);
-   settle_lane_timing(c, 1);
+   for (int lane = 0; lane < mmh_ctx::kLanes; lane++) {
+      settle_lane_timing(c, lane);
+   }
    scan_timings(c, c->scans_recorded - 1, ms4);
    return MMH_OK;
 }
@@ -1469,8 +1481,9 @@ extern "C" int mmh_timing_history(mmh_ctx *c, float *filter_ms, float *total_ms,
       mmh_set_error("mmh_timing_history: bad argument");
       return MMH_E_ARG;
    }
-   settle_lane_timing(c, 0);
-   settle_lane_timing(c, 1);
+   for (int lane = 0; lane < mmh_ctx::kLanes; lane++) {
+      settle_lane_timing(c, lane);
+   }
    const uint64_t have = std::min<uint64_t>(c->scans_recorded, mmh_ctx::kRing);
    const int n = (int)std::min<uint64_t>(have, (uint64_t)cap);
    for (int i = 0; i < n; i++) {

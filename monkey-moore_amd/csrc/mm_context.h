@@ -113,7 +113,8 @@ struct mmh_ctx {
    uint64_t rom_alloc = 0;          //   ... and its size
    uint8_t *rom_host = nullptr;     // pinned host buffer small uploads are scanned from in place (zero copy)
 
-   MmWorkspace ws[3];               // [0] mmh_scan; [1], [2] the two lanes of mmh_scan_submit / _collect
+   static constexpr int kLanes = 3; // scans mmh_scan_submit keeps in flight
+   MmWorkspace ws[1 + kLanes];      // [0] mmh_scan; [1 ...] the lanes of mmh_scan_submit / _collect
    uint8_t *d_dense = nullptr;      // dense engine: tile maps, super-tile maps, entry phases (one allocation)
    size_t dense_bytes = 0;
    uint64_t *d_sort_in = nullptr;   // long lists: contiguous keys (dense engine), ordered keys, rocPRIM scratch
@@ -137,14 +138,15 @@ struct mmh_ctx {
    float ring_ms[kRing][2] = {};    // {streaming kernel, whole scan}
    uint64_t scans_recorded = 0;     // slot of scan k is k % kRing
    hipEvent_t *ev = nullptr;        // the current scan's triple
-   hipStream_t lane_stream[2] = {nullptr, nullptr};   // streams of the submit lanes
+   hipStream_t lane_stream[kLanes] = {};                // streams of the submit lanes
    hipEvent_t lane_fence = nullptr;                     // orders a lane behind earlier work on `stream`
-   hipEvent_t lane_ev[2][3] = {};                       // event triples of the two lanes
+   hipEvent_t lane_ev[kLanes][3] = {};                  // event triples of the lanes
+   bool lane_ev_recorded[kLanes] = {};                  // the lane's triple belongs to a scan whose kernels were enqueued
    // A lane's scan is over for the host when its flag shows in pinned memory -- a few microseconds before its
    // last event completes: the timings of such a scan are filled in later (before the lane's events are
    // recorded again, or when timings are asked for).  -1: nothing owed; else the scan's number (ring slot = % kRing).
-   int64_t lane_timing_owed[2] = {-1, -1};
-   MmPending pending[2];
+   int64_t lane_timing_owed[kLanes] = {-1, -1, -1};
+   MmPending pending[kLanes];
    int next_ticket = 0;
    int engine = 0;
    bool fused_ok = true;            // cleared for good when a fused scan's grid barrier ever timed out on this context

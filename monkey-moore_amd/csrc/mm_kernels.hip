@@ -24,8 +24,8 @@
 //   ROMs of up to 4 MiB: mm_scan_fused runs both stages in ONE launch (grid barrier).
 //   Second phase, only when candidates are left over (host decides from the published
 //   counters): mm_resolve2 -> mm_hard_resolve (mm_tiles.h) -> mm_rank_count / mm_rank_scatter.
-//   The two lanes of mmh_scan_submit keep the round-1 chain mm_filter -> mm_resolve ->
-//   mm_rank_count -> mm_rank_scatter.
+//   The lanes of mmh_scan_submit run the same two kernels; MMOORE_FUSED=0 brings back the round-1
+//   chain mm_filter -> mm_resolve -> mm_rank_count -> mm_rank_scatter everywhere.
 //
 // Other engines: mm_forward (mm_forward.h), the candidate-free forward engine, for
 // inputs the per-candidate path does not suit and for keywords beyond 32 symbols;

@@ -221,7 +221,7 @@ def test_search_engine_run_multi_device_path(mm):
     assert " 0 failures" in r.stdout
 
 
-@pytest.mark.parametrize("extra", [[], ["--depth", "1"], ["--sync-gather"], ["--torch-gather"]])
+@pytest.mark.parametrize("extra", [[], ["--depth", "1"], ["--depth", "2"], ["--sync-gather"], ["--torch-gather"]])
 def test_bench_multi_rank_path_with_one_rank(extra):
     """bench.py's N > 1 code path (process group, unique id, communicator, overlapped gather of collected
     tickets, the native-vs-torch gather check) with the one rank the box has."""
@@ -236,7 +236,8 @@ def test_bench_multi_rank_path_with_one_rank(extra):
     res = json.loads(line[0])
     assert res["n_gpus"] == 1 and res["steps"] == 6 and res["value"] > 0
     assert res["config"]["matches"] == 256 + 3 + 3 or res["config"]["matches"] > 200       # 1 plant / MiB + straddlers
-    assert res["config"]["scans_in_flight"] == (1 if "--depth" in extra else 2)
+    depth = int(extra[1]) if "--depth" in extra else 3
+    assert res["config"]["scans_in_flight"] == depth
     assert res["overlap"] == ("--sync-gather" not in extra)
     assert "gather_note" not in res
     if "--torch-gather" in extra:
@@ -245,5 +246,5 @@ def test_bench_multi_rank_path_with_one_rank(extra):
         assert "librccl" in res["gather_backend"]
         assert "identical" in res["gather_check"]
         assert res["gather_ms"]["device_collective_and_pack"] > 0
-    other = res["two_in_flight" if "--depth" in extra else "synchronous"]
+    other = res["in_flight" if depth == 1 else "synchronous"]
     assert other["same_offsets"] is True

@@ -475,8 +475,9 @@ def test_rom_from_file_and_gather(mm, gpu_engine, oracle, tmp_path):
         gpu_engine.load_file(str(path), data.size - 10, 100)  # runs off the end of the file: short read
 
 
-def test_two_scans_in_flight(mm, gpu_engine, oracle):
-    # mmh_scan_submit / mmh_scan_collect: same offsets as mmh_scan, two tickets outstanding at a
+@pytest.mark.parametrize("depth", [2, 3])
+def test_scans_in_flight(mm, gpu_engine, oracle, depth):
+    # mmh_scan_submit / mmh_scan_collect: same offsets as mmh_scan, `depth` tickets outstanding at a
     # time, different plans interleaved on the same ROM; the paths the lanes do not run themselves
     # (no SWAR key -> dense engine, long match lists) come back through the synchronous rescan
     rng = np.random.default_rng(31)
@@ -492,18 +493,18 @@ def test_two_scans_in_flight(mm, gpu_engine, oracle):
     want = [gpu_engine.scan(p, block_bytes=524288, cap=1 << 16).tolist() for p in plans]
     assert want[0] == oracle.engine(oracle.plan(1, kws[0][0]), rom, 524288).tolist()
     assert len(want[3]) > 16384 and all(len(w) > 20 for w in want), [len(w) for w in want]
-    order = [0, 1, 2, 3, 3, 0, 2, 1, 0, 0, 1]
+    order = [0, 1, 2, 3, 3, 0, 2, 1, 0, 0, 1, 0, 0, 0, 1, 1, 2]
     tickets, got = [], []
     for k in order:
         tickets.append((k, gpu_engine.submit(plans[k], block_bytes=524288)))
-        if len(tickets) == 2:
+        if len(tickets) == depth:
             i, t = tickets.pop(0)
             got.append((i, gpu_engine.collect(t, cap=1000).tolist()))      # cap too small now and then: retried
-    extra = gpu_engine.submit(plans[0], block_bytes=524288)
+    while len(tickets) < mm.MMH_MAX_IN_FLIGHT:
+        tickets.append((0, gpu_engine.submit(plans[0], block_bytes=524288)))
+        order = order + [0]
     with pytest.raises(mm.MMError):
-        gpu_engine.submit(plans[0], block_bytes=524288)                    # a third outstanding scan is refused
-    tickets.append((0, extra))
-    order = order + [0]
+        gpu_engine.submit(plans[0], block_bytes=524288)                    # one more outstanding scan is refused
     while tickets:
         i, t = tickets.pop(0)
         got.append((i, gpu_engine.collect(t).tolist()))

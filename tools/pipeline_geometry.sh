@@ -7,7 +7,7 @@ IFS=';' read -ra CFGS <<< "${GRIDS:-2048 8 2048;1536 7 2048;1280 7 2048;1280 8 2
 for cfg in "${CFGS[@]}"; do
 set -- $cfg
 echo "== blocks $1 gps $2 tail $3"
-MMOORE_FILTER_BLOCKS=$1 MMOORE_FILTER_GPS=$2 MMOORE_TAIL_BLOCKS=$3 timeout 200 python bench.py --no-cpu-baseline --steps 400 2>&1 | python -c "
+MMOORE_FILTER_BLOCKS=$1 MMOORE_FILTER_GPS=$2 MMOORE_TAIL_BLOCKS=$3 timeout 200 python bench.py --no-cpu-baseline --steps 400 --depth ${DEPTH:-3} 2>&1 | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):

@@ -45,10 +45,10 @@ def by_phase():
     filt = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if "mm_filter" in r["Kernel_Name"]]
     tail = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if "mm_scan_tail" in r["Kernel_Name"]]
     K, W, pre = b["steps"], b["warmup"], b["config"]["prewarm_scans"]
-    d2 = b["config"]["scans_in_flight"] == 2
-    phases = [("prewarm, one scan at a time", pre), ("warm-up, %d in flight" % (2 if d2 else 1), W),
-              ("TIMED steps, %d in flight" % (2 if d2 else 1), K),
-              ("warm-up of the other leg", max(W, 4)), ("other leg, %d in flight" % (1 if d2 else 2), K)]
+    depth = b["config"]["scans_in_flight"]
+    phases = [("prewarm, one scan at a time", pre), ("warm-up, %d ticket(s) outstanding" % depth, W),
+              ("TIMED steps, %d ticket(s) outstanding" % depth, K),
+              ("warm-up of the other leg", max(W, 4)), ("other leg, %d ticket(s) outstanding" % (1 if depth > 1 else 3), K)]
     res, at = {"launches_of_the_streaming_kernel": len(filt), "phases": []}, 0
     for name, n in phases:
         f, t = filt[at:at + n], tail[at:at + n]
