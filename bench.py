@@ -160,6 +160,8 @@ def main():
                     help="skip the extra K steps at the other depth after the timed region (the 'synchronous' / 'in_flight' object)")
     args = ap.parse_args()
 
+    # (the pool's host driver only supports dmabuf IPC: RCCL across processes needs this; exported on the boxes already)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 

@@ -1314,15 +1314,16 @@ extern "C" int mmh_scan_submit(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t b
       HIP_TRY(hipEventRecord(c->lane_fence, c->stream));
       HIP_TRY(hipStreamWaitEvent(c->lane_stream[lane], c->lane_fence, 0));
       // How scans in flight share the device (rocprofv3 kernel trace, tools/lane_trace.sh).  Scan t starts
-      // behind scan t-2 (the wait below) and runs beside scan t-1: the tail kernel of t-2 (96 VGPRs) does not
-      // fit beside the streaming kernel of t-1 (6 waves x 72 VGPRs per SIMD), so it is dispatched but only
-      // gets going while that kernel drains -- and then the streaming kernel of t starts, ~0.12 ms before
-      // that of t-1 ends.  The ends of the streaming kernels (waves finishing one by one, bandwidth going
-      // unused) are thus filled with the next scan's start and the previous scan's tail: 0.70 ms per scan,
-      // the duration of ONE streaming kernel run alone.  Three lanes, although only two scans are ever at
-      // work on the device: the third is the one the host has ALREADY enqueued -- with two, scan t could
-      // only be submitted once t-2 had been collected, ~0.12 ms before its kernel was due, and a host that
-      // was late (a busy box: 0.80 ms per scan measured) left the device waiting.
+      // behind scan t-2 (the wait below) and runs beside scan t-1.  The tail kernel of t-2 (96 VGPRs) finds
+      // registers only here and there beside the streaming kernel of t-1 (6 waves x 72 VGPRs per SIMD leave
+      // 80) and takes ~0.54 ms from dispatch to end instead of 0.03; the streaming kernel of t, which waits
+      // for it, then starts ~0.12 ms before that of t-1 ends (a seventh streaming wave per SIMD does fit) and
+      // takes over as its waves finish.  Net: 0.70 ms per scan, the duration of ONE streaming kernel run
+      // alone -- tail kernel, result hand-over and the gaps between kernels cost nothing.  Three lanes,
+      // although only two scans are ever at work on the device: the third is the one the host has ALREADY
+      // enqueued -- with two, scan t could only be submitted once t-2 had been collected, ~0.12 ms before
+      // its kernel was due, and a host that was late (a busy box: 0.80 ms per scan measured) left the device
+      // waiting.
       // Tried and dropped: a scan's filter waiting for the previous scan's "filter done" event (766-913 us
       // per scan); all streaming kernels on one stream and the tail kernels on the lanes' (strictly
       // consecutive filters, tail beside the next filter from its start: the tail takes 390 us instead of 29
@@ -1330,6 +1331,10 @@ extern "C" int mmh_scan_submit(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t b
       // VGPRs, which does fit beside six streaming waves (0.712-0.732 ms with 256 .. 2048 workgroups of it
       // against 0.702-0.706: a tail that runs beside a streaming kernel costs more than one that waits for
       // its drain).
+      // (From an empty pipeline the first two scans start together and the stagger builds up over some tens of
+      // scans: 0.76 ms per scan over 20, 0.73 over 50, 0.70 over 200.  Holding scan t back until the streaming
+      // kernel of t-1 signals that its first workgroups have finished -- a gate wave polling a word -- was tried:
+      // 0.727 ms in the steady state, that kernel's waves all finish within ~20 us of each other.)
       const int before = (c->next_ticket + mmh_ctx::kLanes - 2) % mmh_ctx::kLanes;       // lane of scan t-2
       if (c->next_ticket >= 2 && c->lane_ev_recorded[before]) {
          HIP_TRY(hipStreamWaitEvent(c->lane_stream[lane], c->lane_ev[before][2], 0));
