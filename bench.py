@@ -109,23 +109,22 @@ def cpu_baseline(eng, shard_bytes, plan_kw, want_bytes, warmups, runs):
                                      "(benchmarks/bench_search.cpp shape), 3 warm-ups, 10 runs"), offs, n
 
 
-def pmc_traffic(lib_path, shard):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes -- only when they were
-    taken with THIS build of the library (the summary carries the library's hash), else null."""
+def pmc_traffic(mm, shard):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes -- only when they were taken
+    with THIS device code (the summary carries the hash of the library's sources), else null."""
     for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
         with open(path) as f:
             pmc = json.load(f)
-        with open(lib_path, "rb") as f:
-            digest = hashlib.sha256(f.read()).hexdigest()[:16]
-        if pmc.get("library_sha16") != digest:
-            return None, "profiles/%s was taken with another build of libmmoore_hip.so (%s, this one is %s): not reported" % (
-                name, pmc.get("library_sha16"), digest)
+        digest = mm.build.device_source_sha16()
+        if pmc.get("device_source_sha16") != digest:
+            return None, "profiles/%s was taken with other device sources (%s, these are %s): not reported" % (
+                name, pmc.get("device_source_sha16"), digest)
         return (pmc["hbm_traffic_bytes_per_launch"] * shard / pmc["algorithmic_bytes_per_launch"],
                 "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled per the gfx950 rule; "
-                "same library build: sha256 %s)" % (name, digest))
+                "same device sources: sha256 %s)" % (name, digest))
     return None, None
 
 
@@ -365,7 +364,7 @@ def main():
         assert filt > 0, "the library reported no streaming-phase timing"
         assert float(np.mean(filt_ms)) > 0
         achieved = shard / (filt * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(mm.LIB_PATH, shard)
+        traffic, traffic_src = pmc_traffic(mm, shard)
         res = {
             "metric": "GB/s scanned (%g GiB synthetic ROM per GPU, 12-char 8-bit relative pattern)" % gib,
             "value": total * args.steps / elapsed / 1e9,

@@ -74,6 +74,22 @@ def build_core(force=False):
     return CORE_SO
 
 
+def device_source_sha16():
+    """SHA-256 (first 16 hex digits) over the sources libmmoore_hip.so is built from -- csrc/ and the C-ABI header --
+    in file-name order.  profiles/rNN_pmc_summary.json carries it: bench.py reports the PMC traffic figure only
+    while the device code is the code the counters were taken with (the binary's own hash differs from build
+    directory to build directory)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip", ".cpp")))
+    files.append(os.path.join(ROOT, "include", "mmoore_hip.h"))
+    for path in files:
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def build_all(force=False):
     build_capi(force)
     build_core(force)

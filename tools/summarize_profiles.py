@@ -93,9 +93,13 @@ bench = json.loads(open(os.path.join(out, "bench_n1.json")).read().strip().split
 kernel = "void " + bench["roofline"]["kernel"]
 alg = bench["roofline"]["algorithmic_bytes"]
 import hashlib
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from __graft_entry__ import load_package
+device_source_sha16 = load_package().build.device_source_sha16
 lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "monkey-moore_amd", "lib", "libmmoore_hip.so")
 summary = {
-    # bench.py reports `roofline.traffic` from this file only while the library it runs is THIS build
+    # bench.py reports `roofline.traffic` from this file only while the library's sources are THESE
+    "device_source_sha16": device_source_sha16(),
     "library_sha16": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16],
     "command_fetch": "rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 3 --warmup 1 --depth 1 --no-cpu-baseline --no-other-depth --prewarm-s 0.05",
     "command_write": "rocprofv3 --pmc WRITE_SIZE --output-format csv -- python3 bench.py --steps 3 --warmup 1 --depth 1 --no-cpu-baseline --no-other-depth --prewarm-s 0.05",
