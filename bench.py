@@ -161,6 +161,9 @@ def main():
 
     # (the pool's host driver only supports dmabuf IPC: RCCL across processes needs this; exported on the boxes already)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # HIP streams beyond the 4th share hardware queues by default and then serialize: at N > 1 the process has
+    # torch's stream(s), torch's NCCL stream, the library's two lane streams and its gather stream
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
 
@@ -434,7 +437,8 @@ def main():
             res["gather_ms"] = {
                 "device_collective_and_pack": float(np.mean(gather_dev)) if gather_dev else None,
                 "host_start_plus_finish": float(np.mean(gather_host)) if gather_host else None,
-                "per_step_overhead_vs_device_scan": elapsed / args.steps * 1e3 - float(np.mean(tot_ms)),
+                # what a step costs beyond the streaming kernel run alone: an overlapped gather should leave it near 0
+                "per_step_beyond_streaming_kernel": elapsed / args.steps * 1e3 - filt,
             }
             res["overlap"] = not args.sync_gather
             res["gather_backend"] = gather_backend

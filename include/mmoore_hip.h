@@ -145,7 +145,10 @@ int mmh_scan(mmh_ctx *ctx, const mmh_plan_desc *plan, uint64_t block_bytes, int 
  * order they were submitted; the ROM must not change while one is outstanding.  The host's share
  * of a scan and the kernel behind the streaming filter then overlap the next scan's streaming
  * kernel: two outstanding tickets already do that, the third keeps the device fed when the host
- * is late.  MMH_E_CAPACITY from collect leaves the ticket outstanding: collect again with more room. */
+ * is late.  MMH_E_CAPACITY from collect leaves the ticket outstanding: collect again with more room.
+ * The lanes use two HIP streams of their own; in a process with more than four streams in all, raise the HIP
+ * runtime's GPU_MAX_HW_QUEUES (default 4) before HIP initialises, or streams share hardware queues and the
+ * scans in flight no longer overlap. */
 #define MMH_MAX_IN_FLIGHT 3
 int mmh_scan_submit(mmh_ctx *ctx, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian,
                     uint64_t base_offset, int *ticket);

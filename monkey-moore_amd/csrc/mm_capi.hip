@@ -1289,9 +1289,11 @@ extern "C" int mmh_scan_submit(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t b
    if (rc != MMH_OK) {
       return rc;
    }
-   if (!c->lane_stream[lane]) {
-      HIP_TRY(hipStreamCreateWithFlags(&c->lane_stream[lane], hipStreamNonBlocking));
+   const int sidx = c->next_ticket % mmh_ctx::kLaneStreams;
+   if (!c->lane_stream[sidx]) {
+      HIP_TRY(hipStreamCreateWithFlags(&c->lane_stream[sidx], hipStreamNonBlocking));
    }
+   const hipStream_t lane_st = c->lane_stream[sidx];
    if (!c->lane_fence) {
       HIP_TRY(hipEventCreateWithFlags(&c->lane_fence, hipEventDisableTiming));
    }
@@ -1312,18 +1314,18 @@ extern "C" int mmh_scan_submit(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t b
    else {
       // the ROM may still be in the making on the context's stream (upload, synth, poke)
       HIP_TRY(hipEventRecord(c->lane_fence, c->stream));
-      HIP_TRY(hipStreamWaitEvent(c->lane_stream[lane], c->lane_fence, 0));
+      HIP_TRY(hipStreamWaitEvent(lane_st, c->lane_fence, 0));
       // How scans in flight share the device (rocprofv3 kernel trace, tools/lane_trace.sh).  Scan t starts
-      // behind scan t-2 (the wait below) and runs beside scan t-1.  The tail kernel of t-2 (96 VGPRs) finds
+      // behind scan t-2 (same stream) and runs beside scan t-1.  The tail kernel of t-2 (96 VGPRs) finds
       // registers only here and there beside the streaming kernel of t-1 (6 waves x 72 VGPRs per SIMD leave
       // 80) and takes ~0.54 ms from dispatch to end instead of 0.03; the streaming kernel of t, which waits
       // for it, then starts ~0.12 ms before that of t-1 ends (a seventh streaming wave per SIMD does fit) and
       // takes over as its waves finish.  Net: 0.70 ms per scan, the duration of ONE streaming kernel run
-      // alone -- tail kernel, result hand-over and the gaps between kernels cost nothing.  Three lanes,
-      // although only two scans are ever at work on the device: the third is the one the host has ALREADY
-      // enqueued -- with two, scan t could only be submitted once t-2 had been collected, ~0.12 ms before
-      // its kernel was due, and a host that was late (a busy box: 0.80 ms per scan measured) left the device
-      // waiting.
+      // alone -- tail kernel, result hand-over and the gaps between kernels cost nothing.  Three lanes
+      // (workspaces, result blocks) on the two streams, although only two scans are ever at work on the
+      // device: the third is the one the host has ALREADY enqueued -- with two, scan t could only be
+      // submitted once t-2 had been collected, ~0.12 ms before its kernel was due, and a host that was late
+      // (a busy box: 0.80 ms per scan measured) left the device waiting.
       // Tried and dropped: a scan's filter waiting for the previous scan's "filter done" event (766-913 us
       // per scan); all streaming kernels on one stream and the tail kernels on the lanes' (strictly
       // consecutive filters, tail beside the next filter from its start: the tail takes 390 us instead of 29
@@ -1333,12 +1335,10 @@ extern "C" int mmh_scan_submit(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t b
       // its drain).
       // (From an empty pipeline the first two scans start together and the stagger builds up over some tens of
       // scans: 0.76 ms per scan over 20, 0.73 over 50, 0.70 over 200.  Holding scan t back until the streaming
-      // kernel of t-1 signals that its first workgroups have finished -- a gate wave polling a word -- was tried:
-      // 0.727 ms in the steady state, that kernel's waves all finish within ~20 us of each other.)
-      const int before = (c->next_ticket + mmh_ctx::kLanes - 2) % mmh_ctx::kLanes;       // lane of scan t-2
-      if (c->next_ticket >= 2 && c->lane_ev_recorded[before]) {
-         HIP_TRY(hipStreamWaitEvent(c->lane_stream[lane], c->lane_ev[before][2], 0));
-      }
+      // kernel of t-1 is 60 .. 95 % through its rounds, or until its first workgroups have finished -- it counts
+      // in a word, a gate wave in front of scan t's kernel polls it -- was tried: 0.725-0.76 ms per scan in the
+      // steady state at every threshold against 0.698 without.)
+      // (scan t-2 was enqueued on this very stream: stream order is that wait)
       settle_lane_timing(c, lane);             // (before the lane's events are recorded again)
       for (auto &e : c->lane_ev[lane]) {
          if (!e) {
@@ -1348,12 +1348,10 @@ extern "C" int mmh_scan_submit(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t b
       std::copy(c->lane_ev[lane], c->lane_ev[lane] + 3, p.ev);
       // (filter + tail kernel, the end polled in the lane's own pinned block; never the single-launch kernel:
       // its grid barrier wants the device to itself)
-      c->lane_ev_recorded[lane] = false;
-      rc = enqueue_pipeline(c, w, c->lane_stream[lane], p.ev, g, *plan, fc, false, base_offset, p.max_candidates, nullptr, true, false);
+      rc = enqueue_pipeline(c, w, lane_st, p.ev, g, *plan, fc, false, base_offset, p.max_candidates, nullptr, true, false);
       if (rc != MMH_OK) {
          return rc;
       }
-      c->lane_ev_recorded[lane] = true;
    }
    p.active = true;
    *ticket = c->next_ticket++;
@@ -1379,7 +1377,10 @@ extern "C" int mmh_scan_collect(mmh_ctx *c, int ticket, uint64_t *out, uint64_t 
    MmWorkspace &w = c->ws[1 + lane];
    if (!rescan) {
       const MmGeom g = scan_geometry(c, &p.plan, p.block_bytes, p.big_endian);
-      int rc = finish_pipeline(c, w, c->lane_stream[lane], p.ev, g, p.plan, p.base_offset, p.max_candidates, false, &oc);
+      // (a second phase, if any, goes behind whatever later scans have been enqueued on the ticket's stream: it
+      // works on this ticket's own workspace)
+      const hipStream_t lane_st = c->lane_stream[ticket % mmh_ctx::kLaneStreams];
+      int rc = finish_pipeline(c, w, lane_st, p.ev, g, p.plan, p.base_offset, p.max_candidates, false, &oc);
       if (rc != MMH_OK) {
          p.active = false;
          return rc;
@@ -1389,7 +1390,7 @@ extern "C" int mmh_scan_collect(mmh_ctx *c, int ticket, uint64_t *out, uint64_t 
       if (lane_trace) {
          static hipEvent_t base = nullptr;
          if (!base && hipEventCreate(&base) == hipSuccess) {
-            (void)hipEventRecord(base, c->lane_stream[lane]);
+            (void)hipEventRecord(base, lane_st);
             (void)hipEventSynchronize(base);
          }
          float t0 = 0, t1 = 0, own = 0;
@@ -1448,8 +1449,14 @@ void scan_timings(mmh_ctx *c, uint64_t k, float *ms4)
       ms4[3] = c->ring_ms[slot][1];
    }
    else {
-      // (an event that has not completed or was never recorded leaves its figure at 0)
-      if (hipEventElapsedTime(&ms4[3], e[0], e[2]) != hipSuccess) {
+      // (a scan's end shows in pinned memory a few microseconds before its last event completes: wait for it;
+      // an event that was never recorded leaves its figure at 0)
+      hipError_t err = hipEventElapsedTime(&ms4[3], e[0], e[2]);
+      if (err == hipErrorNotReady && hipEventSynchronize(e[2]) == hipSuccess) {
+         err = hipEventElapsedTime(&ms4[3], e[0], e[2]);
+      }
+      if (err != hipSuccess) {
+         (void)hipGetLastError();
          ms4[3] = 0;
       }
       if (c->ring_has_filter[slot] && hipEventElapsedTime(&ms4[0], e[0], e[1]) != hipSuccess) {

@@ -138,13 +138,14 @@ struct mmh_ctx {
    float ring_ms[kRing][2] = {};    // {streaming kernel, whole scan}
    uint64_t scans_recorded = 0;     // slot of scan k is k % kRing
    hipEvent_t *ev = nullptr;        // the current scan's triple
-   hipStream_t lane_stream[kLanes] = {};                // streams of the submit lanes
+   // The lanes' kernels go to TWO streams, scan t to stream t % 2: scan t then runs behind scan t-2 by stream
+   // order, and the context stays within the 4 hardware queues a process gets by default (GPU_MAX_HW_QUEUES):
+   // its own stream, these two and the gather's.  Streams that share a hardware queue serialize -- a third lane
+   // stream cost 0.706 -> 0.728 ms per scan as soon as a fifth stream existed in the process.
+   static constexpr int kLaneStreams = 2;
+   hipStream_t lane_stream[kLaneStreams] = {};
    hipEvent_t lane_fence = nullptr;                     // orders a lane behind earlier work on `stream`
    hipEvent_t lane_ev[kLanes][3] = {};                  // event triples of the lanes
-   bool lane_ev_recorded[kLanes] = {};                  // the lane's triple belongs to a scan whose kernels were enqueued
-   // A lane's scan is over for the host when its flag shows in pinned memory -- a few microseconds before its
-   // last event completes: the timings of such a scan are filled in later (before the lane's events are
-   // recorded again, or when timings are asked for).  -1: nothing owed; else the scan's number (ring slot = % kRing).
    int64_t lane_timing_owed[kLanes] = {-1, -1, -1};
    MmPending pending[kLanes];
    int next_ticket = 0;
