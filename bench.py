@@ -118,13 +118,17 @@ def pmc_traffic(mm, shard):
             continue
         with open(path) as f:
             pmc = json.load(f)
-        digest = mm.build.device_source_sha16()
-        if pmc.get("device_source_sha16") != digest:
-            return None, "profiles/%s was taken with other device sources (%s, these are %s): not reported" % (
-                name, pmc.get("device_source_sha16"), digest)
+        src = mm.build.device_source_sha16()
+        with open(mm.LIB_PATH, "rb") as f:
+            lib = hashlib.sha256(f.read()).hexdigest()[:16]
+        # the same device code: the same sources (a rebuild elsewhere gives another binary), or the very binary
+        # (a comment edit gives other sources)
+        if pmc.get("device_source_sha16") != src and pmc.get("library_sha16") != lib:
+            return None, "profiles/%s was taken with other device code (sources %s / library %s, here %s / %s): not reported" % (
+                name, pmc.get("device_source_sha16"), pmc.get("library_sha16"), src, lib)
         return (pmc["hbm_traffic_bytes_per_launch"] * shard / pmc["algorithmic_bytes_per_launch"],
                 "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled per the gfx950 rule; "
-                "same device sources: sha256 %s)" % (name, digest))
+                "same device code: sources sha256 %s, library %s)" % (name, src, lib))
     return None, None
 
 

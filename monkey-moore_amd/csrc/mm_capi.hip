@@ -1337,7 +1337,8 @@ extern "C" int mmh_scan_submit(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t b
       // scans: 0.76 ms per scan over 20, 0.73 over 50, 0.70 over 200.  Holding scan t back until the streaming
       // kernel of t-1 is 60 .. 95 % through its rounds, or until its first workgroups have finished -- it counts
       // in a word, a gate wave in front of scan t's kernel polls it -- was tried: 0.725-0.76 ms per scan in the
-      // steady state at every threshold against 0.698 without.)
+      // steady state at every threshold against 0.698 without; so was making the second scan of a burst wait
+      // for the end of the first one's streaming kernel: no better over 5 .. 50 scans.)
       // (scan t-2 was enqueued on this very stream: stream order is that wait)
       settle_lane_timing(c, lane);             // (before the lane's events are recorded again)
       for (auto &e : c->lane_ev[lane]) {
