@@ -139,7 +139,7 @@ int mmh_scan(mmh_ctx *ctx, const mmh_plan_desc *plan, uint64_t block_bytes, int 
 
 /* Scans in flight, for back-to-back scans (many keywords, many ROM partitions):
  * mmh_scan_submit enqueues a scan with the arguments of mmh_scan on one of three internal lanes
- * (own stream, workspace and result block) and returns a ticket; mmh_scan_collect waits for
+ * (own workspace and result block, on two streams of the context) and returns a ticket; mmh_scan_collect waits for
  * that scan and delivers its offsets exactly as mmh_scan would.  At most MMH_MAX_IN_FLIGHT
  * tickets may be outstanding (a further submit fails with MMH_E_STATE); collect them in the
  * order they were submitted; the ROM must not change while one is outstanding.  The host's share
