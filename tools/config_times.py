@@ -18,6 +18,21 @@ for name, n, kw, elem, wc, be in cfgs:
     for i in range(60):
         r = eng.scan(plan, block_bytes=524288, big_endian=be)
         tm = eng.timings(); f.append(tm["filter_ms"]); t.append(tm["total_ms"])
+    # the same scans with three tickets outstanding (mmh_scan_submit / mmh_scan_collect): wall time per scan
+    def in_flight(n):
+        tickets, last = [], None
+        t0 = time.perf_counter()
+        for _ in range(n):
+            tickets.append(eng.submit(plan, block_bytes=524288, big_endian=be))
+            if len(tickets) == 3:
+                last = eng.collect(tickets.pop(0))
+        while tickets:
+            last = eng.collect(tickets.pop(0))
+        return (time.perf_counter() - t0) / n * 1e3, last
+    in_flight(30)
+    per_scan, last = in_flight(200)
+    assert len(last) == len(r) and (last == r).all()
     k = 20
-    print("%-22s matches %6d  filter %.3f ms (%.0f GB/s)  total %.3f ms (%.0f GB/s)  %s %s" % (
-        name, len(r), sum(f[-k:]) / k, n / (sum(f[-k:]) / k) / 1e6, sum(t[-k:]) / k, n / (sum(t[-k:]) / k) / 1e6, eng.timings(), eng.counters()))
+    print("%-22s matches %6d  filter %.3f ms (%.0f GB/s)  total %.3f ms (%.0f GB/s)  in flight %.3f ms per scan (%.0f GB/s)  %s %s" % (
+        name, len(r), sum(f[-k:]) / k, n / (sum(f[-k:]) / k) / 1e6, sum(t[-k:]) / k, n / (sum(t[-k:]) / k) / 1e6, per_scan, n / per_scan / 1e6,
+        eng.timings(), eng.counters()))
