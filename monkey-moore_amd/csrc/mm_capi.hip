@@ -245,6 +245,7 @@ extern "C" void mmh_destroy(mmh_ctx *c)
    if (c->rom_host) (void)hipHostFree(c->rom_host);
    if (c->d_dense) (void)hipFree(c->d_dense);
    if (c->d_sort_in) (void)hipFree(c->d_sort_in);
+   if (c->d_domains) (void)hipFree(c->d_domains);
    if (c->d_sort_out) (void)hipFree(c->d_sort_out);
    if (c->d_sort_tmp) (void)hipFree(c->d_sort_tmp);
    for (auto &triple : c->ring) {
@@ -808,18 +809,22 @@ namespace {
 // the forward engine: (1) flag pass -- mm_resolve again, setting the bit of every domain that
 // holds an unsettled candidate; (2) forward engine over the flagged domains only; (3) the first
 // pass's verdicts stand everywhere else.  Engine mode only (a whole-buffer scan is one domain).
+// *handled = false: the flag pass did not see the candidates of the first pass (a candidate list overflowed --
+// the two passes may spread the candidates over the lists differently: single-launch kernel first, plain
+// streaming kernel here): the caller switches to the forward engine for everything
 int run_flagged_domains(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, uint64_t base_offset, uint32_t max_candidates,
-                        uint64_t first_pass_slots, std::vector<uint64_t> *merged, uint64_t *domains_flagged)
+                        uint64_t first_pass_slots, std::vector<uint64_t> *merged, uint64_t *domains_flagged, bool *handled)
 {
+   *handled = false;
    hipStream_t st = c->stream;
    MmWorkspace &w = c->ws[0];
    const uint64_t ndom = g.nblocks * g.S;
    const uint64_t words = (ndom + 31) / 32;
-   int rc = grow(&c->d_sort_in, &c->sort_in_cap, (words + 1) / 2 + ndom / 2 + 2);   // bitmap, then the domain list, as u32
+   int rc = grow(&c->d_domains, &c->domains_cap, (words + 1) / 2 + ndom / 2 + 2);   // bitmap, then the domain list, as u32
    if (rc != MMH_OK) {
       return rc;
    }
-   uint32_t *d_bits = reinterpret_cast<uint32_t *>(c->d_sort_in);
+   uint32_t *d_bits = reinterpret_cast<uint32_t *>(c->d_domains);
    HIP_TRY(hipMemsetAsync(d_bits, 0, words * sizeof(uint32_t), st));
    HIP_TRY(hipMemsetAsync(w.d_ctrl, 0, mm::ctrl_bytes(), st));
    w.ctrl_clean = false;
@@ -836,10 +841,17 @@ int run_flagged_domains(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, ui
    HIP_TRY(hipGetLastError());
    std::vector<uint32_t> bits(words);
    std::vector<uint64_t> slots(first_pass_slots);
+   unsigned long long seen = 0;
    HIP_TRY(hipMemcpyAsync(bits.data(), d_bits, words * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
    // every candidate got its slot again (same candidates; their order may differ from the first pass)
    HIP_TRY(hipMemcpyAsync(slots.data(), w.d_out, first_pass_slots * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+   HIP_TRY(hipMemcpyAsync(&seen, w.d_ctrl + MM_CTRL_TOTAL, sizeof seen, hipMemcpyDeviceToHost, st));
    HIP_TRY(hipStreamSynchronize(st));
+   if (seen != first_pass_slots) {
+      // (~0: a list overflowed and mm_resolve did nothing -- found by a fuzz soak: 'bbbb' on a two-symbol
+      // alphabet, 165 K candidates in 1 MiB, reported 527 of 43538 matches from stale slots)
+      return MMH_OK;
+   }
 
    std::vector<uint32_t> doms;
    for (uint64_t d = 0; d < ndom; d++) {
@@ -868,10 +880,24 @@ int run_flagged_domains(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, ui
       if (rc != MMH_OK) {
          return rc;
       }
+      if (getenv("MMOORE_TRACE")) {
+         fprintf(stderr, "run_flagged_domains: forward engine on %zu domains: %zu results\n", doms.size(), dense.size());
+      }
       merged->insert(merged->end(), dense.begin(), dense.end());
+   }
+   static const bool trace = getenv("MMOORE_TRACE") != nullptr;
+   if (trace) {
+      uint64_t holes = 0, in_flagged = 0;
+      for (uint64_t v : slots) {
+         holes += v == ~0ull;
+         in_flagged += v != ~0ull && flagged(v);
+      }
+      fprintf(stderr, "run_flagged_domains: %llu slots (%llu holes, %llu verdicts inside flagged domains), %zu of %llu domains flagged, %zu results after the merge\n",
+              (unsigned long long)slots.size(), (unsigned long long)holes, (unsigned long long)in_flagged, doms.size(), (unsigned long long)ndom, merged->size());
    }
    std::sort(merged->begin(), merged->end());       // search_engine.cpp:193-197
    w.ctrl_clean = false;
+   *handled = true;
    return MMH_OK;
 }
 
@@ -893,11 +919,11 @@ int run_candidate_floods(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, c
    }
    const uint64_t words = (ndom + 31) / 32;
    // one scratch allocation, as u32: [ndom counts][words bitmap][ndom domain list]
-   int rc = grow(&c->d_sort_in, &c->sort_in_cap, (2 * ndom + words) / 2 + 4);
+   int rc = grow(&c->d_domains, &c->domains_cap, (2 * ndom + words) / 2 + 4);
    if (rc != MMH_OK) {
       return rc;
    }
-   unsigned int *d_count = reinterpret_cast<unsigned int *>(c->d_sort_in);
+   unsigned int *d_count = reinterpret_cast<unsigned int *>(c->d_domains);
    uint32_t *d_bits = reinterpret_cast<uint32_t *>(d_count + ndom);
    uint32_t *d_list = d_bits + words;
    HIP_TRY(hipMemsetAsync(d_count, 0, ndom * sizeof(unsigned int), st));
@@ -1107,15 +1133,20 @@ int scan_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int b
       }
       if (mode == FAST && oc.hard_overflow && !g.whole && oc.candidates <= c->ws[0].out_cap && oc.candidates <= max_candidates) {
          // more left-overs than mm_resolve2 / mm_hard_resolve take: forward engine on their domains only
-         rc = run_flagged_domains(c, g, *plan, base_offset, max_candidates, oc.candidates, &long_list, &oc.tiles);
+         bool handled = false;
+         rc = run_flagged_domains(c, g, *plan, base_offset, max_candidates, oc.candidates, &long_list, &oc.tiles, &handled);
          if (rc != MMH_OK) {
             return rc;
          }
-         oc.matches = long_list.size();
-         host_list = true;
-         flagged_domains = true;
-         settled = true;
-         break;
+         if (handled) {
+            oc.matches = long_list.size();
+            host_list = true;
+            flagged_domains = true;
+            settled = true;
+            break;
+         }
+         mode = DENSE;
+         continue;
       }
       if (mode == FAST && !g.whole && (oc.candidates > c->ws[0].out_cap || oc.candidates > max_candidates)) {
          // candidate flood: forward engine on the flooded domains, the per-candidate path on the rest

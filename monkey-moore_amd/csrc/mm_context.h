@@ -119,6 +119,11 @@ struct mmh_ctx {
    size_t dense_bytes = 0;
    uint64_t *d_sort_in = nullptr;   // long lists: contiguous keys (dense engine), ordered keys, rocPRIM scratch
    uint64_t sort_in_cap = 0;
+   // domain bitmap / list / counts of run_flagged_domains and run_candidate_floods.  Its own buffer: the forward
+   // engine they call packs its finds into d_sort_in and may reallocate it (a fuzz soak found the domain list
+   // read from the freed buffer on the engine's second attempt: 527 of 43538 matches)
+   uint64_t *d_domains = nullptr;
+   uint64_t domains_cap = 0;
    uint64_t *d_sort_out = nullptr;
    uint64_t sort_out_cap = 0;
    void *d_sort_tmp = nullptr;

@@ -1366,7 +1366,13 @@ void launch_filter(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, con
                    unsigned int *dom_count, const uint32_t *skip_bits)
 {
    MmFilterArgs a;
-   fill_filter_args(a, g, pl, fc, cand, ctrl, cand_cap, filter_groups_per_span());
+   // small ROMs are cut fine, as launch_fused does: 64 workgroups fill the 64 candidate lists evenly (a 1 MiB
+   // ROM in spans of 7 groups is 10 workgroups = 10 lists, and a dense pattern overflows them) and every CU works
+   uint32_t gps = filter_groups_per_span();
+   while (gps > 1 && (g.nbytes / 4096) / gps < (uint64_t)MM_CAND_LISTS * MM_WAVES) {
+      gps >>= 1;
+   }
+   fill_filter_args(a, g, pl, fc, cand, ctrl, cand_cap, gps);
    a.dom_count = dom_count; a.skip_bits = skip_bits;
    with_shape(pl.elem_bytes, fc, [&](auto elem, auto shape) {
       constexpr int SHAPE = decltype(shape)::value;

@@ -78,6 +78,10 @@ def test_fuzz_against_oracle(mm, gpu_engine, oracle, seed):
         PATHS_SEEN.add(gpu_engine.counters()["path"])
         want = oracle.engine(oplan, rom, block, be)
         assert got.tolist() == want.tolist(), (seed, case, kw, elem, be, block, nbytes, alphabet)
+        # the same through the submit lanes (streaming kernel + tail kernel, never the single-launch kernel), three at a time
+        tickets = [gpu_engine.submit(plan, block_bytes=block, big_endian=be) for _ in range(3 if case % 4 == 0 else 1)]
+        for t in tickets:
+            assert gpu_engine.collect(t, cap=1 << 12).tolist() == want.tolist(), (seed, case, kw, elem, be, block, nbytes, alphabet, "lanes")
         whole = rom[: (nbytes // elem) * elem]
         data = whole if elem == 1 else whole.view("<u2")
         assert gpu_engine.scan(plan, cap=1 << 12).tolist() == oracle.search(oplan, data).tolist(), (seed, case, kw, "whole")

@@ -580,6 +580,25 @@ def test_flood_of_undecidable_candidates_uses_flagged_domains(mm, gpu_engine, or
     assert gpu_engine.collect(t).tolist() == want.tolist()
 
 
+def test_flagged_domains_with_a_long_list_from_the_forward_engine(mm, oracle):
+    # Found by a fuzz soak (seed 303 of test_gpu_fuzz.py): 'bbbb' on a two-symbol alphabet -- every domain is
+    # flagged (path 4) and the forward engine reports tens of thousands of matches.  Packing those for the sort
+    # reallocated the buffer the domain list lived in, and the engine's second attempt (its lists had to grow)
+    # read the list from freed memory: 527 of 43538 matches.  A FRESH context, so that every buffer starts small.
+    rng = np.random.default_rng(303)
+    rom = (rng.integers(0, 2, 1 << 20) + 0x60).astype(np.uint8)
+    plan, oplan = mm.plan_relative(1, "bbbb"), oracle.plan(1, "bbbb")
+    for block in (65536, 524288):
+        want = oracle.engine(oplan, rom, block)
+        assert len(want) > 30000
+        with mm.Engine(0) as eng:
+            eng.upload(rom)
+            got = eng.scan(plan, block_bytes=block, cap=1 << 12)
+            assert eng.counters()["path"] in (3, 4, 5), eng.counters()
+            assert got.tolist() == want.tolist(), block
+            assert eng.scan(plan, block_bytes=block).tolist() == want.tolist()      # and again, buffers grown
+
+
 @pytest.mark.parametrize("kw,elem,hard", [("abcde", 1, 0), ("aaaa", 1, 0), ("aaaa", 2, 0), ("abcde", 1, 360)])
 def test_candidate_flood_in_a_padding_run(mm, gpu_engine, oracle, kw, elem, hard):
     # The bench ROM has 1 MiB runs of 0x00, 0xFF and a +1 ramp.  A keyword that matches a whole run
