@@ -87,6 +87,45 @@ def test_fuzz_against_oracle(mm, gpu_engine, oracle, seed):
         assert gpu_engine.scan(plan, cap=1 << 12).tolist() == oracle.search(oplan, data).tolist(), (seed, case, kw, "whole")
 
 
+MEDIUM = int(os.environ.get("MM_FUZZ_MEDIUM", "6"))        # raise for a soak
+
+
+@pytest.mark.parametrize("seed", range(MEDIUM))
+def test_fuzz_medium_roms(mm, gpu_engine, oracle, seed):
+    """The same kind of case at 5 .. 48 MiB: beyond the single-launch kernel's sizes -- the plain streaming kernel's
+    full grid, the tail kernel, the flood / flagged-domain paths with hundreds of domains."""
+    rng = np.random.default_rng(91000 + seed)
+    elem = int(rng.choice([1, 1, 2]))
+    be = bool(elem == 2 and rng.random() < 0.5)
+    mode = str(rng.choice(["plain", "plain", "wild", "wild", "case", "seq"]))
+    for _ in range(20):
+        kw, wc, seq = _keyword(rng, mode)
+        try:
+            oplan = oracle.plan(elem, kw, wc, seq)
+            break
+        except RuntimeError:
+            continue
+    else:
+        pytest.skip("no acceptable keyword")
+    plan = mm.plan_relative(elem, kw, wc, seq)
+    nbytes = int(rng.integers(5 << 20, 48 << 20)) + int(rng.integers(0, 9))
+    alphabet = int(rng.choice([2, 3, 5, 16, 200 if elem == 1 else 40000]))
+    rom = _rom(rng, nbytes, elem, be, kw, wc, seq, alphabet)
+    if rng.random() < 0.5:
+        # a low-entropy stretch inside ordinary data (candidate floods in a few domains only)
+        a = int(rng.integers(0, nbytes // 2))
+        rom[a:a + (1 << 20)] = _rom(rng, 1 << 20, elem, be, kw, wc, seq, 2)
+    gpu_engine.upload(rom)
+    block = int(rng.choice([65536, 524288, 524288, 8 << 20]))
+    want = oracle.engine(oplan, rom, block, be)
+    got = gpu_engine.scan(plan, block_bytes=block, big_endian=be, cap=1 << 16)
+    PATHS_SEEN.add(gpu_engine.counters()["path"])
+    assert got.tolist() == want.tolist(), (seed, kw, elem, be, block, nbytes, alphabet, gpu_engine.counters())
+    tickets = [gpu_engine.submit(plan, block_bytes=block, big_endian=be) for _ in range(3)]
+    for t in tickets:
+        assert gpu_engine.collect(t, cap=1 << 16).tolist() == want.tolist(), (seed, kw, "lanes")
+
+
 def test_fuzz_reached_every_engine_path():
     # over all seeds: plain resolver path (0), hard resolver (2) and the dense fallback (3)
     assert {0, 2, 3} <= PATHS_SEEN, PATHS_SEEN
