@@ -16,8 +16,8 @@ SEEDS = int(os.environ.get("MM_FUZZ_SEEDS", "40"))          # 24 cases per seed;
 PATHS_SEEN = set()
 
 
-def _keyword(rng, mode):
-    L = int(rng.integers(2, 14))
+def _keyword(rng, mode, L=None):
+    L = int(rng.integers(2, 14)) if L is None else L
     if mode == "plain":
         return "".join(rng.choice(list(LOWER[: int(rng.integers(2, 27))]), L)), 0, None
     if mode == "wild":
@@ -124,6 +124,42 @@ def test_fuzz_medium_roms(mm, gpu_engine, oracle, seed):
     tickets = [gpu_engine.submit(plan, block_bytes=block, big_endian=be) for _ in range(3)]
     for t in tickets:
         assert gpu_engine.collect(t, cap=1 << 16).tolist() == want.tolist(), (seed, kw, "lanes")
+
+
+LONG = int(os.environ.get("MM_FUZZ_LONG", "8"))            # raise for a soak
+
+
+@pytest.mark.parametrize("seed", range(LONG))
+def test_fuzz_long_keywords(mm, gpu_engine, oracle, seed):
+    """Keywords of 33 .. 128 symbols (always the forward engine, phase maps of up to 127 phases handled by two
+    lanes each) and of 14 .. 32 (the resolvers' widest phase sets), random modes and alphabets."""
+    rng = np.random.default_rng(47000 + seed)
+    for case in range(6):
+        elem = int(rng.choice([1, 1, 2]))
+        be = bool(elem == 2 and rng.random() < 0.5)
+        mode = str(rng.choice(["plain", "plain", "wild", "case", "seq"]))
+        L = int(rng.integers(33, 129)) if case % 3 else int(rng.integers(14, 33))
+        kw, wc, seq = _keyword(rng, mode, L)
+        try:
+            oplan = oracle.plan(elem, kw, wc, seq)
+        except RuntimeError:
+            with pytest.raises(mm.MMError):
+                mm.plan_relative(elem, kw, wc, seq)
+            continue
+        plan = mm.plan_relative(elem, kw, wc, seq)
+        nbytes = int(rng.choice([40000, 300000, 2 << 20])) + int(rng.integers(0, 9))
+        alphabet = int(rng.choice([2, 3, 5, 16, 200 if elem == 1 else 40000]))
+        rom = _rom(rng, nbytes, elem, be, kw, wc, seq, alphabet)
+        gpu_engine.upload(rom)
+        block = int(rng.choice([4096, 65536, 524288]))
+        if block < 2 * L * elem:
+            block = 65536
+        got = gpu_engine.scan(plan, block_bytes=block, big_endian=be, cap=1 << 12)
+        want = oracle.engine(oplan, rom, block, be)
+        assert got.tolist() == want.tolist(), (seed, case, L, kw, elem, be, block, nbytes, alphabet)
+        whole = rom[: (nbytes // elem) * elem]
+        data = whole if elem == 1 else whole.view("<u2")
+        assert gpu_engine.scan(plan, cap=1 << 12).tolist() == oracle.search(oplan, data).tolist(), (seed, case, L, kw, "whole")
 
 
 def test_fuzz_reached_every_engine_path():
