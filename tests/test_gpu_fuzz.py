@@ -124,6 +124,23 @@ def test_fuzz_medium_roms(mm, gpu_engine, oracle, seed):
     tickets = [gpu_engine.submit(plan, block_bytes=block, big_endian=be) for _ in range(3)]
     for t in tickets:
         assert gpu_engine.collect(t, cap=1 << 16).tolist() == want.tolist(), (seed, kw, "lanes")
+    # one chain over the whole buffer (MonkeyMoore<T>::search semantics): long prefixes, the hard resolver
+    if not be:
+        whole = rom[: (nbytes // elem) * elem]
+        data = whole if elem == 1 else whole.view("<u2")
+        assert gpu_engine.scan(plan, cap=1 << 16).tolist() == oracle.search(oplan, data).tolist(), (seed, kw, "whole")
+    # the multi-GPU partition rule on this ROM: block-aligned partitions with keyword-length overlap, scanned one
+    # by one with their base offsets, concatenate to the whole file's list (mmh_partition; 3 or 5 "ranks")
+    nranks = 3 if seed % 2 else 5
+    parts = []
+    for r in range(nranks):
+        first, nb = mm.partition_range(nbytes, block, len(kw), elem, r, nranks)
+        if nb == 0:
+            continue
+        gpu_engine.upload(rom[first:first + nb])
+        parts.append(gpu_engine.scan(plan, block_bytes=block, big_endian=be, base_offset=first, cap=1 << 16))
+    merged = np.concatenate(parts) if parts else np.zeros(0, np.uint64)
+    assert merged.tolist() == want.tolist(), (seed, kw, "partitions", nranks)
 
 
 LONG = int(os.environ.get("MM_FUZZ_LONG", "8"))            # raise for a soak
