@@ -135,7 +135,7 @@ def pmc_traffic(mm, shard):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="C2",
                     help="C2: 4 GiB per GPU (the headline metric); C5: 8 GiB per GPU (64 GiB over 8 GPUs)")

@@ -1,7 +1,7 @@
 #!/bin/bash
 # SPDX-License-Identifier: GPL-3.0-or-later
 # Dev probe: bench.py with few steps (pipeline fill and drain inside the timed region).
-for k in 5 10 20 50 200; do
+for k in 5 10 20 50 200 400; do
 python bench.py --no-cpu-baseline --steps $k --warmup 3 2>&1 | python -c "
 import sys,json
 for l in sys.stdin:
