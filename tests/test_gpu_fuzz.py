@@ -184,9 +184,12 @@ def test_fuzz_reached_every_engine_path():
     assert {0, 2, 3} <= PATHS_SEEN, PATHS_SEEN
 
 
+VALUE_CASES = int(os.environ.get("MM_FUZZ_VALUES", "12"))   # raise for a soak
+
+
 def test_fuzz_value_scan(mm, gpu_engine, oracle):
     rng = np.random.default_rng(99)
-    for case in range(12):
+    for case in range(VALUE_CASES):
         elem = int(rng.choice([1, 2]))
         vals = [int(v) for v in rng.integers(-40, 41, int(rng.integers(2, 9)))]
         oplan, plan = oracle.plan_values(elem, vals), mm.plan_value_scan(elem, vals)
@@ -202,3 +205,5 @@ def test_fuzz_value_scan(mm, gpu_engine, oracle):
         gpu_engine.upload(rom)
         got = gpu_engine.scan(plan, block_bytes=65536)
         assert got.tolist() == oracle.engine(oplan, rom, 65536).tolist(), (case, vals, elem)
+        data = rom if elem == 1 else rom[: (rom.size // 2) * 2].view("<u2")
+        assert gpu_engine.scan(plan).tolist() == oracle.search(oplan, data).tolist(), (case, vals, elem, "whole")
