@@ -1,0 +1,196 @@
+// SPDX-License-Identifier: GPL-3.0-or-later
+// Differential test of the C++ facade against the reference core THROUGH THE PUBLIC API both share:
+// MonkeyMoore<T>::search (positions + equivalency maps) and SearchEngine<T>::run (byte offsets, maps,
+// decoded previews, callback count) on random inputs -- keyword modes (plain, wildcards, mixed case,
+// custom sequences, value scans), 8 / 16 bit, both byte orders, block sizes, preview widths.
+// Built by oracle/Makefile (harness) in the build container, where the reference sources are; the
+// binary travels to the GPU box with the other oracle/_ref files.  usage: facade_diff [cases] [seed]
+// STATUS (round 2): written and built at the end of the round, NOT yet run on a GPU -- the one attempt
+// coincided with a lost box of the pool (the command had not reported a start), and the round could not
+// afford a second.  It is therefore not part of the test suite; run it by hand, small case counts first.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <random>
+#include <string>
+#include <unistd.h>
+#include <vector>
+
+#include "facade_diff.hpp"
+
+namespace {
+std::mt19937_64 rng;
+uint64_t below(uint64_t n) { return n ? rng() % n : 0; }
+
+void make_keyword(DiffCase &c)
+{
+   const int mode = (int)below(5);                        // 0,1 plain  2 wildcards  3 mixed case  4 custom sequence
+   const int L = 2 + (int)below(12);
+   c.keyword.clear(); c.char_seq.clear(); c.values.clear(); c.wildcard = 0; c.use_values = false;
+   if (mode == 4) {
+      std::string seq = "0123456789abcdef";
+      std::shuffle(seq.begin(), seq.end(), rng);
+      for (char ch : seq) c.char_seq.push_back((char32_t)ch);
+      for (int i = 0; i < L; i++) c.keyword.push_back(c.char_seq[below(c.char_seq.size())]);
+      return;
+   }
+   const int alphabet = mode == 3 ? 8 : 2 + (int)below(25);
+   for (int i = 0; i < L; i++) {
+      char32_t ch = U'a' + (char32_t)below(alphabet);
+      if (mode == 3 && below(10) < 3) ch = ch - U'a' + U'A';
+      c.keyword.push_back(ch);
+   }
+   if (mode == 2 || mode == 3) {
+      c.wildcard = U'*';
+   }
+   if (mode == 2) {
+      int lits = std::max(2, L - 1 - (int)below(std::max(1, L / 2)));
+      std::vector<int> idx(L);
+      for (int i = 0; i < L; i++) idx[i] = i;
+      std::shuffle(idx.begin(), idx.end(), rng);
+      for (int i = 0; i < L - lits; i++) c.keyword[idx[i]] = U'*';
+      if (c.keyword.front() == U'*' && c.keyword.back() == U'*') c.keyword.front() = U'q';
+   }
+}
+
+void make_values(DiffCase &c)
+{
+   c.keyword.clear(); c.char_seq.clear(); c.wildcard = 0; c.use_values = true; c.values.clear();
+   const int n = 2 + (int)below(7);
+   for (int i = 0; i < n; i++) c.values.push_back((short)((int)below(81) - 40));
+}
+
+// elements of the pattern to plant (code points / sequence indices / running sums), -1 = wildcard slot
+std::vector<int> pattern_values(const DiffCase &c)
+{
+   std::vector<int> v;
+   if (c.use_values) {
+      // (mirrors tests/test_gpu_fuzz.py::test_fuzz_value_scan: a first element, then the listed differences)
+      int x = 0;
+      v.push_back(0);
+      for (short d : c.values) v.push_back(x += d);
+      return v;
+   }
+   for (char32_t ch : c.keyword) {
+      if (c.wildcard && ch == c.wildcard) { v.push_back(-1); continue; }
+      if (!c.char_seq.empty()) {
+         v.push_back((int)(std::find(c.char_seq.begin(), c.char_seq.end(), ch) - c.char_seq.begin()));
+      }
+      else {
+         v.push_back((int)ch);
+      }
+   }
+   return v;
+}
+
+std::vector<uint8_t> make_data(const DiffCase &c, uint64_t nelem, bool big_endian)
+{
+   const int hi = c.elem_bytes == 1 ? 256 : 65536;
+   const int choices[5] = {2, 3, 5, 16, c.elem_bytes == 1 ? 200 : 40000};
+   const int alphabet = choices[below(5)];
+   const int base = (int)below(hi - alphabet);
+   std::vector<int> d(nelem);
+   for (auto &x : d) x = base + (int)below(alphabet);
+   const std::vector<int> pat = pattern_values(c);
+   int lo = 1 << 30, top = -(1 << 30);
+   for (int v : pat) if (v >= 0 || c.use_values) { lo = std::min(lo, v); top = std::max(top, v); }
+   if (lo <= top && top - lo < hi && nelem > pat.size() + 1) {
+      const int plants = (int)below(40);
+      for (int k = 0; k < plants; k++) {
+         const uint64_t pos = below(nelem - pat.size());
+         const int shift = -lo + (int)below(hi - (top - lo));
+         for (size_t j = 0; j < pat.size(); j++) {
+            if (pat[j] >= 0 || c.use_values) d[pos + j] = pat[j] + shift;
+         }
+      }
+   }
+   std::vector<uint8_t> bytes(nelem * c.elem_bytes);
+   for (uint64_t i = 0; i < nelem; i++) {
+      if (c.elem_bytes == 1) bytes[i] = (uint8_t)d[i];
+      else if (big_endian) { bytes[2 * i] = (uint8_t)(d[i] >> 8); bytes[2 * i + 1] = (uint8_t)d[i]; }
+      else { bytes[2 * i] = (uint8_t)d[i]; bytes[2 * i + 1] = (uint8_t)(d[i] >> 8); }
+   }
+   return bytes;
+}
+
+std::string describe(const DiffCase &c)
+{
+   std::string s = c.use_values ? "values[" : "keyword[";
+   if (c.use_values) for (short v : c.values) s += std::to_string(v) + ",";
+   else for (char32_t ch : c.keyword) s += ch < 128 ? std::string(1, (char)ch) : "?";
+   s += "] elem " + std::to_string(c.elem_bytes) + (c.char_seq.empty() ? "" : " custom-seq") + (c.wildcard ? " wildcard" : "");
+   return s;
+}
+
+bool same(const DiffOutcome &a, const DiffOutcome &b, bool compare_callbacks, std::string *why)
+{
+   if (a.threw != b.threw) { *why = "one side threw: ref '" + a.what + "' gpu '" + b.what + "'"; return false; }
+   if (a.threw) { if (a.what != b.what) { *why = "messages differ: '" + a.what + "' / '" + b.what + "'"; return false; } return true; }
+   if (a.matches.size() != b.matches.size()) { *why = "ref " + std::to_string(a.matches.size()) + " matches, gpu " + std::to_string(b.matches.size()); return false; }
+   for (size_t i = 0; i < a.matches.size(); i++) {
+      if (!(a.matches[i] == b.matches[i])) {
+         *why = "match " + std::to_string(i) + ": ref at " + std::to_string(a.matches[i].where) + " gpu at " + std::to_string(b.matches[i].where) +
+                (a.matches[i].map == b.matches[i].map ? "" : " (maps differ)") + (a.matches[i].preview == b.matches[i].preview ? "" : " (previews differ: '" + a.matches[i].preview + "' / '" + b.matches[i].preview + "')");
+         return false;
+      }
+   }
+   if (compare_callbacks && a.callbacks != b.callbacks) { *why = "callbacks: ref " + std::to_string(a.callbacks) + " gpu " + std::to_string(b.callbacks); return false; }
+   return true;
+}
+} // namespace
+
+int main(int argc, char **argv)
+{
+   const int cases = argc > 1 ? atoi(argv[1]) : 300;
+   rng.seed(argc > 2 ? strtoull(argv[2], nullptr, 10) : 20261003ull);
+   const std::string path = "/dev/shm/facade_diff_" + std::to_string(getpid()) + ".bin";
+   int failures = 0;
+   uint64_t matches = 0, with_maps = 0, with_previews = 0, threw = 0;
+   for (int k = 0; k < cases && failures < 5; k++) {
+      DiffCase c;
+      c.elem_bytes = below(3) == 0 ? 2 : 1;
+      if (below(6) == 0) make_values(c); else make_keyword(c);
+      std::string why;
+      if (k % 2 == 0) {
+         // MonkeyMoore<T>::search on host memory (element order = host order: little endian)
+         const uint64_t sizes[5] = {300, 5000, 70000, 300000, 1200000};
+         const uint64_t nelem = sizes[below(5)] + below(9);
+         const std::vector<uint8_t> bytes = make_data(c, nelem, false);
+         const DiffOutcome r = diff_search_ref(c, bytes.data(), nelem), g = diff_search_gpu(c, bytes.data(), nelem);
+         if (!same(r, g, false, &why)) {
+            failures++;
+            std::fprintf(stderr, "case %d search %s, %llu elements: %s\n", k, describe(c).c_str(), (unsigned long long)nelem, why.c_str());
+         }
+         matches += r.matches.size(); threw += r.threw;
+         for (const auto &m : r.matches) with_maps += !m.map.empty();
+      }
+      else {
+         // SearchEngine<T>::run on a file
+         const uint64_t sizes[4] = {3000, 40000, 400000, 3000000};
+         const uint64_t nbytes = sizes[below(4)] + below(9);
+         c.big_endian = c.elem_bytes == 2 && below(2);
+         const int blocks[5] = {4096, 8191, 65536, 524288, 1 << 20};
+         c.block_size = blocks[below(5)];
+         c.threads = 1 + (int)below(8);
+         c.preview_width = 10 + (int)below(41);
+         c.previews = below(3) != 0;
+         c.path = path;
+         std::vector<uint8_t> bytes = make_data(c, nbytes / c.elem_bytes, c.big_endian);
+         bytes.resize(nbytes, 0x5A);
+         { std::ofstream f(path, std::ios::binary); f.write((const char *)bytes.data(), (std::streamsize)bytes.size()); }
+         const DiffOutcome r = diff_engine_ref(c), g = diff_engine_gpu(c);
+         if (!same(r, g, true, &why)) {
+            failures++;
+            std::fprintf(stderr, "case %d engine %s, %llu bytes, %s, block %d, previews %d width %d: %s\n", k, describe(c).c_str(),
+                         (unsigned long long)nbytes, c.big_endian ? "BE" : "LE", c.block_size, (int)c.previews, c.preview_width, why.c_str());
+         }
+         matches += r.matches.size(); threw += r.threw;
+         for (const auto &m : r.matches) { with_maps += !m.map.empty(); with_previews += !m.preview.empty(); }
+      }
+   }
+   unlink(path.c_str());
+   std::printf("facade_diff: %d cases, %llu matches compared (%llu with equivalency maps, %llu with previews), %llu cases both sides rejected, %d failures\n",
+               cases, (unsigned long long)matches, (unsigned long long)with_maps, (unsigned long long)with_previews, (unsigned long long)threw, failures);
+   return failures ? 1 : 0;
+}
