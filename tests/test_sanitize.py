@@ -78,3 +78,34 @@ def test_facade_under_thread_sanitizer():
         r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, env=dict(os.environ, **env))
         assert r.returncode == 0 and "ThreadSanitizer" not in r.stdout, r.stdout[-4000:]
         assert " 0 failures" in r.stdout
+
+
+def test_facade_differential_against_the_reference_core():
+    """tests/cpp/facade_diff_*.cpp with the CPU test double behind the facade: MonkeyMoore<T>::search (positions +
+    equivalency maps) and SearchEngine<T>::run (byte offsets, maps, decoded previews, callback counts) of this
+    repository's facade against the reference core -- its own sources, class and namespace renamed on the command
+    line so that both fit one binary -- on 400 random cases.  The facade's side runs under ASan + UBSan (the
+    reference's side does not: it reads 16-bit elements at odd addresses by design, byteswap.hpp:75)."""
+    ref = "/root/reference"
+    if not os.path.exists(os.path.join(ref, "src", "core", "search_engine.cpp")):
+        pytest.skip("reference sources not present")
+    os.makedirs(BUILD, exist_ok=True)
+    rename = ["-DMonkeyMoore=MonkeyMooreRef", "-Dmmoore=mmoore_ref"]
+    plain = ["g++", "-std=c++17", "-O1", "-pthread"]
+    objs = []
+    for name, src, extra in (("diff_ref_mm.o", os.path.join(ref, "src", "core", "monkey_moore.cpp"), ["-DNDEBUG"]),
+                             ("diff_ref_se.o", os.path.join(ref, "src", "core", "search_engine.cpp"), ["-DNDEBUG"]),
+                             ("diff_side_ref.o", os.path.join(CPP, "facade_diff_side.cpp"), ["-DDIFF_SIDE=ref", "-I" + CPP])):
+        obj = os.path.join(BUILD, name)
+        subprocess.check_call(plain + rename + extra + ["-I" + os.path.join(ref, "include"), "-I" + os.path.join(ref, "src", "core"), "-c", src, "-o", obj])
+        objs.append(obj)
+    side = os.path.join(BUILD, "diff_side_gpu.o")
+    san = [a for a in SAN if a != "-O0"] + ["-O1"]
+    subprocess.check_call(san + ["-DDIFF_SIDE=gpu", "-I" + CPP, "-c", os.path.join(CPP, "facade_diff_side.cpp"), "-o", side])
+    exe = os.path.join(BUILD, "facade_diff_cpu")
+    subprocess.check_call(san + ["-I" + CPP, os.path.join(CPP, "facade_diff_main.cpp"), side] + objs + FACADE + ["-o", exe])
+    r = subprocess.run([exe, "400"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, env=ENV)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert " 0 failures" in r.stdout and "Sanitizer" not in r.stdout and "runtime error" not in r.stdout, r.stdout[-3000:]
+    compared = int(r.stdout.split(" matches compared")[0].split()[-1])
+    assert compared > 50000, r.stdout[-500:]
