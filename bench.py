@@ -2,8 +2,11 @@
 # SPDX-License-Identifier: GPL-3.0-or-later
 """bench.py -- GB/s scanned by the MI355X relative-search engine.
 
-  python bench.py --gpus N --steps K --warmup W [--config C2|C5]
-  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+  python bench.py --gpus N --steps K --warmup W [--config C2|C3|C4|C5]
+  N > 1 without RANK / WORLD_SIZE in the environment: bench.py launches its N ranks itself
+  (python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...) before anything
+  touches the GPU, passes rank 0's JSON line through and exits with the children's code.  Under a
+  launcher WORLD_SIZE must equal --gpus, else the run is refused.
 
 Workload (BASELINE.json configs[1], "C2"): 8-bit relative search, 12-character
 keyword, engine semantics with the reference's default 512 KiB blocks, on a
@@ -34,11 +37,51 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-KEYWORD = "relativesrch"
 BLOCK = 524288
 SEED = 42
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak 8 TB/s (measured achievable ~6.3)
-CONFIGS = {"C2": 4.0, "C5": 8.0}  # GiB per GPU
+# BASELINE.json configs[1..4]: GiB per GPU, element bytes, keyword, wildcard, byte order
+CONFIGS = {
+    "C2": dict(gib=4.0, elem=1, keyword="relativesrch", wildcard=None, be=False,
+               what="8-bit relative search, keyword 'relativesrch' (L=12)"),
+    "C3": dict(gib=4.0, elem=1, keyword="re*ative*ear*hxy", wildcard=ord("*"), be=False,
+               what="8-bit relative search, keyword 're*ative*ear*hxy' (L=16, 3 wildcards)"),
+    "C4": dict(gib=8.0, elem=2, keyword="textsrch", wildcard=None, be=False,
+               what="16-bit little-endian relative search, keyword 'textsrch' (L=8), both byte alignments"),
+    "C4BE": dict(gib=8.0, elem=2, keyword="textsrch", wildcard=None, be=True,
+                 what="16-bit big-endian relative search, keyword 'textsrch' (L=8), both byte alignments"),
+    "C5": dict(gib=8.0, elem=1, keyword="relativesrch", wildcard=None, be=False,
+               what="8-bit relative search, keyword 'relativesrch' (L=12), one GPU's shard of the 64 GiB / 8 GPU configuration"),
+}
+OTHER_CONFIGS = ("C3", "C4", "C4BE")   # measured behind the timed region of the default (C2, N = 1) run
+
+
+def launch_ranks(n, argv, dry):
+    """--gpus N > 1 outside a launcher: start the N ranks as children of THIS process -- which has neither
+    imported torch nor touched the GPU (a process that has must not start another program in its place) --
+    and hand their exit code back.  Rank 0's JSON line reaches stdout through the inherited descriptor."""
+    import socket
+    import subprocess
+    if not dry:
+        # (torch.cuda.device_count() does not initialise the GPU on this stack; it still runs in a child)
+        probe = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        have = int(probe.stdout.strip() or 0) if probe.returncode == 0 else 0
+        if have < n:
+            sys.stderr.write("bench.py --gpus %d: only %d GPU(s) visible on this node -- refusing to run (one rank per GPU, "
+                             "no oversubscription, no CPU fallback)\n" % (n, have))
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("GPU_MAX_HW_QUEUES", "8")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    sys.stderr.write("bench.py: launching %d ranks: %s\n" % (n, " ".join(cmd)))
+    return subprocess.run(cmd, env=env).returncode
 
 
 def _timed(fn, warmups, runs):
@@ -52,20 +95,21 @@ def _timed(fn, warmups, runs):
     return times, last
 
 
-def cpu_baseline(eng, shard_bytes, plan_kw, want_bytes, warmups, runs):
+def cpu_baseline(eng, shard_bytes, cfg, want_bytes, warmups, runs):
     """the reference CPU engine on the bench ROM written to tmpfs,
     hardware_concurrency threads, 512 KiB blocks, >= 3 warm-ups, >= 10 timed runs, median + min.
     Returns (json object, offsets, bytes covered)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from _oracle import Oracle, Ref
     cores = os.cpu_count() or 1
+    plan_kw, elem, wc, be = cfg["keyword"], cfg["elem"], cfg["wildcard"] or 0, cfg["be"]
     if not Ref.available():
         # no compiled reference on this box: the scalar C restatement on a bounded sample
         n = min(shard_bytes, 256 << 20)
         rom = eng.download(0, n)
         orc = Oracle()
         t0 = time.perf_counter()
-        offs = orc.engine(orc.plan(1, plan_kw), rom, BLOCK)
+        offs = orc.engine(orc.plan(elem, plan_kw, wc), rom, BLOCK, be)
         dt = time.perf_counter() - t0
         return dict(value=n / dt / 1e9, unit="GB/s", cores=1, kind="port",
                     sample="first %d MiB of the bench ROM, scalar C restatement, 1 run" % (n >> 20)), offs, n
@@ -86,8 +130,8 @@ def cpu_baseline(eng, shard_bytes, plan_kw, want_bytes, warmups, runs):
             piece = 512 << 20
             for at in range(0, n, piece):                     # 512 MiB at a time: no second copy of the ROM in RAM
                 f.write(memoryview(eng.download(at, min(piece, n - at))))
-        times, offs = _timed(lambda: ref.engine(1, None, plan_kw, ord("*"), None, threads=cores, block_size=BLOCK, path=path),
-                             warmups, runs)
+        times, offs = _timed(lambda: ref.engine(elem, None, plan_kw, wc or ord("*"), None, big_endian=be, threads=cores,
+                                                block_size=BLOCK, path=path), warmups, runs)
     finally:
         if os.path.exists(path):
             os.unlink(path)
@@ -100,7 +144,7 @@ def cpu_baseline(eng, shard_bytes, plan_kw, want_bytes, warmups, runs):
         single[kw] = dict(median_GBps=(16 << 20) / float(np.median(t1)) / 1e9, best_GBps=(16 << 20) / min(t1) / 1e9)
     med, best = float(np.median(times)), min(times)
     return dict(value=n / med / 1e9, unit="GB/s", cores=cores, kind="reference",
-                sample="%s%d MiB of the bench ROM in a tmpfs file, SearchEngine<uint8_t>::run built from the reference sources, "
+                sample="%s%d MiB of the bench ROM in a tmpfs file, SearchEngine<T>::run built from the reference sources, "
                        "%d threads, 512 KiB blocks, no previews; %d warm-ups, %d timed runs, value = median"
                        % ("(tmpfs too small for 4 GiB) " if shrunk else "", n >> 20, cores, warmups, runs),
                 median_GBps=n / med / 1e9, best_GBps=n / best / 1e9, runs=runs, warmups=warmups, bytes=n,
@@ -112,7 +156,7 @@ def cpu_baseline(eng, shard_bytes, plan_kw, want_bytes, warmups, runs):
 def pmc_traffic(mm, shard):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes -- only when they were taken
     with THIS device code (the summary carries the hash of the library's sources), else null."""
-    for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+    for name in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -132,13 +176,76 @@ def pmc_traffic(mm, shard):
     return None, None
 
 
+def other_config(mm, torch, dev, name, scans, steps):
+    """One of BASELINE.json's other single-GPU configurations behind the timed region: `scans` synchronous scans
+    (mmh_scan) for the kernel's own duration and the caller's latency, `steps` steps with three scans in flight
+    for the throughput, and parity of the offsets with the oracle on the blocks inside a 256 MiB prefix."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _oracle import Oracle, oracle_engine_parallel
+    cfg = CONFIGS[name]
+    kw, elem, wc, be = cfg["keyword"], cfg["elem"], cfg["wildcard"], cfg["be"]
+    nbytes = int(cfg["gib"] * (1 << 30))
+    buf = torch.empty(nbytes + 32, dtype=torch.uint8, device=dev)
+    eng = mm.Engine(dev.index or 0)
+    try:
+        eng.attach(buf.data_ptr(), nbytes)
+        mm.synth.RomSpec(SEED, nbytes, kw, elem, wc, be, BLOCK).apply_device(eng)
+        plan = mm.plan_relative(elem, kw, wc or 0)
+        for _ in range(5):
+            offs = eng.scan(plan, block_bytes=BLOCK, big_endian=be)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(scans):
+            offs = eng.scan(plan, block_bytes=BLOCK, big_endian=be)
+        sync_s = time.perf_counter() - t0
+        filt, tot = eng.timing_history(min(scans, 64))
+        ctr = eng.counters()
+        tickets, last = [], None
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tickets.append(eng.submit(plan, block_bytes=BLOCK, big_endian=be))
+            if len(tickets) == 3:
+                last = eng.collect(tickets.pop(0))
+        while tickets:
+            last = eng.collect(tickets.pop(0))
+        flight_s = time.perf_counter() - t0
+        assert np.array_equal(last, offs), name + ": scans in flight delivered another list"
+        n = 256 << 20
+        rom = eng.download(0, n)
+        orc = Oracle()
+        want = oracle_engine_parallel(orc, orc.plan(elem, kw, wc or 0), rom, BLOCK, be)
+        lim = (n // BLOCK - 1) * BLOCK
+        g, c = offs[offs < lim].tolist(), [int(x) for x in want if x < lim]
+        assert g == c, name + ": GPU offsets differ from the oracle on the first %d MiB" % (lim >> 20)
+        k = float(np.mean(filt))
+        return {
+            "workload": "%s: %s, engine semantics, 512 KiB blocks, %.1f GiB splitmix64 ROM resident in HBM" % (name, cfg["what"], cfg["gib"]),
+            "kernel": "mm_filter_u%d<%d>" % (8 * elem, mm.filter_shape(plan)["shape"]),
+            "kernel_ms": k, "kernel_ms_min": float(np.min(filt)), "scan_device_ms": float(np.mean(tot)),
+            "achieved_GBps": nbytes / (k * 1e-3) / 1e9, "frac": nbytes / (k * 1e-3) / 1e9 / PEAK_HBM_GBS,
+            "synchronous": {"scans": scans, "ms_per_scan": sync_s / scans * 1e3, "GBps": nbytes * scans / sync_s / 1e9},
+            "in_flight": {"steps": steps, "ms_per_step": flight_s / steps * 1e3, "GBps": nbytes * steps / flight_s / 1e9},
+            "matches": int(len(offs)), "candidates": ctr["candidates"], "path": ctr["path"],
+            "parity": "first %d MiB: %d offsets identical to the oracle (C restatement, all host cores)" % (lim >> 20, len(g)),
+        }
+    finally:
+        eng.close()
+        del buf
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="C2",
-                    help="C2: 4 GiB per GPU (the headline metric); C5: 8 GiB per GPU (64 GiB over 8 GPUs)")
+                    help="C2: 4 GiB per GPU, 12-char 8-bit keyword (the headline metric); C3: 16 chars with 3 wildcards; C4 / C4BE: 8 GiB "
+                         "16-bit LE / BE; C5: 8 GiB per GPU (64 GiB over 8 GPUs)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the C3 / C4 / C4BE measurements behind the timed region of the default run (`other_configs`)")
+    ap.add_argument("--other-scans", type=int, default=10, help="synchronous scans per configuration in `other_configs`")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="tests: every rank prints its RANK / WORLD_SIZE as one JSON line and exits before anything touches a GPU")
     ap.add_argument("--gib-per-gpu", type=float, default=None, help="overrides the config's size")
     ap.add_argument("--cpu-sample-mib", type=int, default=4096)
     ap.add_argument("--cpu-runs", type=int, default=10)
@@ -163,6 +270,20 @@ def main():
                     help="skip the extra K steps at the other depth after the timed region (the 'synchronous' / 'in_flight' object)")
     args = ap.parse_args()
 
+    in_launcher = "RANK" in os.environ or "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not in_launcher:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], args.dry_launch))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to print a line whose n_gpus is not what was asked for\n"
+                         % (args.gpus, world))
+        raise SystemExit(2)
+    if args.dry_launch:
+        print(json.dumps({"dry_launch": True, "rank": rank, "local_rank": local_rank, "world": world, "gpus": args.gpus}), flush=True)
+        return
+
     # (the pool's host driver only supports dmabuf IPC: RCCL across processes needs this; exported on the boxes already)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # HIP streams beyond the 4th share hardware queues by default and then serialize: at N > 1 the process has
@@ -171,9 +292,9 @@ def main():
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d needs GPU %d, %d visible: the engine has no CPU fallback" % (rank, local_rank,
+                                                                                                         torch.cuda.device_count()))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -192,22 +313,25 @@ def main():
         if multi:
             dist.barrier()
 
-    gib = args.gib_per_gpu if args.gib_per_gpu is not None else CONFIGS[args.config]
+    cfg = CONFIGS[args.config]
+    KEYWORD, ELEM, WC, BE = cfg["keyword"], cfg["elem"], cfg["wildcard"], cfg["be"]
+    gib = args.gib_per_gpu if args.gib_per_gpu is not None else cfg["gib"]
     per_gpu = int(gib * (1 << 30)) // BLOCK * BLOCK
     total = per_gpu * world
     L = len(KEYWORD)
     # block-aligned partition + pattern-length overlap into the next one
-    base, shard = mm.partition_range(total, BLOCK, L, 1, rank, world)
+    base, shard = mm.partition_range(total, BLOCK, L, ELEM, rank, world)
 
     # HBM-resident shard owned by torch; the engine borrows the pointer and runs on torch's stream
     buf = torch.empty(shard + 32, dtype=torch.uint8, device=dev)
     eng = mm.Engine(local_rank)
     eng.attach(buf.data_ptr(), shard)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
-    spec = mm.synth.RomSpec(SEED, total, KEYWORD, 1, None, False, BLOCK, base=base, nbytes=shard, partitions=8)
+    spec = mm.synth.RomSpec(SEED, total, KEYWORD, ELEM, WC, BE, BLOCK, base=base, nbytes=shard, partitions=8)
     spec.apply_device(eng)
     torch.cuda.synchronize()
-    plan = mm.plan_relative(1, KEYWORD)
+    plan = mm.plan_relative(ELEM, KEYWORD, WC or 0)
+    kernel_name = "mm_filter_u%d<%d>" % (8 * ELEM, mm.filter_shape(plan)["shape"])
 
     # N > 1: the gather of the per-GPU offset lists (already ascending, partitions in rank order).
     # Product path: the library's own communicator -- rank 0 makes the RCCL id, torch.distributed
@@ -225,18 +349,29 @@ def main():
                 eng.comm_init_rank(box[0], world, rank)
                 gather_backend = "librccl via the C ABI (mmh_gather_start / mmh_gather_finish), lists sent from HBM"
             except Exception as e:                            # noqa: BLE001 -- a box the builder could not test on
-                gather_note = "NATIVE RCCL COMMUNICATOR FAILED (%s: %s) -- fell back to the torch.distributed test double" % (
-                    type(e).__name__, e)
+                gather_note = "NATIVE RCCL COMMUNICATOR FAILED on rank %d (%s: %s)" % (rank, type(e).__name__, e)
                 sys.stderr.write("rank %d: %s\n" % (rank, gather_note))
         # all ranks must take the same path
-        ok = torch.tensor([1 if gather_backend else 0], device=dev)
+        ok = torch.tensor([1 if (gather_backend or args.torch_gather) else 0], device=dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
-            gather_backend = None
+            # The product path is the library's own collective.  Timing the torch.distributed double in its place would
+            # print a throughput the product did not deliver: say so in a line without a value and fail the run.
+            if rank == 0:
+                print(json.dumps({"metric": "GB/s scanned (%g GiB synthetic ROM per GPU)" % gib, "value": None, "unit": "GB/s",
+                                  "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+                                  "scaling": "weak", "config": {"workload": cfg["what"], "name": args.config},
+                                  "error": "the library's RCCL communicator did not come up on every rank; nothing was timed "
+                                           "(--torch-gather runs the test double instead, for diagnosis only)",
+                                  "gather_note": gather_note}), flush=True)
+            dist.barrier()
+            dist.destroy_process_group()
+            raise SystemExit(3)
+        if args.torch_gather:
             gatherer = mm.partition.OffsetGather(rank, world, dev, dist)
     native = multi and gather_backend is not None
     if multi and not native:
-        gather_backend = "torch.distributed all_gather (test double)"
+        gather_backend = "torch.distributed all_gather (test double, --torch-gather: NOT the product path)"
     in_flight = []
     gather_dev_ms, gather_host_ms = [], []
 
@@ -287,9 +422,9 @@ def main():
         for _ in range(k):
             late_host()
             if depth == 1:
-                last = deliver(eng.scan(plan, block_bytes=BLOCK, base_offset=base))
+                last = deliver(eng.scan(plan, block_bytes=BLOCK, big_endian=BE, base_offset=base))
             else:
-                tickets.append(eng.submit(plan, block_bytes=BLOCK, base_offset=base))
+                tickets.append(eng.submit(plan, block_bytes=BLOCK, big_endian=BE, base_offset=base))
                 if len(tickets) == depth:
                     last = deliver(eng.collect(tickets.pop(0)))
         while tickets:
@@ -308,7 +443,7 @@ def main():
     t_pre = time.perf_counter()
     prewarm_scans = 0
     while time.perf_counter() - t_pre < args.prewarm_s:
-        eng.scan(plan, block_bytes=BLOCK, base_offset=base)
+        eng.scan(plan, block_bytes=BLOCK, big_endian=BE, base_offset=base)
         prewarm_scans += 1
     run_steps(args.warmup, args.depth)
     fence()
@@ -338,7 +473,7 @@ def main():
     # scan of every rank -- the first place the native collective meets a real second rank
     gather_check = None
     if native:
-        local = eng.scan(plan, block_bytes=BLOCK, base_offset=base)
+        local = eng.scan(plan, block_bytes=BLOCK, big_endian=BE, base_offset=base)
         eng.gather_start(None, want_list=(rank == 0))
         mine = eng.gather_finish(want_list=(rank == 0))
         theirs = mm.partition.gather_offsets(local, rank, world, dev, dist)
@@ -371,9 +506,11 @@ def main():
         assert filt > 0, "the library reported no streaming-phase timing"
         assert float(np.mean(filt_ms)) > 0
         achieved = shard / (filt * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(mm, shard)
+        traffic, traffic_src = pmc_traffic(mm, shard) if kernel_name == "mm_filter_u8<4>" else (
+            None, "the committed PMC passes were taken on mm_filter_u8<4> (C2 / C5), not on " + kernel_name)
         res = {
-            "metric": "GB/s scanned (%g GiB synthetic ROM per GPU, 12-char 8-bit relative pattern)" % gib,
+            "metric": "GB/s scanned (%g GiB synthetic ROM per GPU, %d-char %d-bit relative pattern%s)" % (
+                gib, L, 8 * ELEM, "" if not WC else ", %d wildcards" % KEYWORD.count(chr(WC))),
             "value": total * args.steps / elapsed / 1e9,
             "unit": "GB/s",
             "n_gpus": world,
@@ -383,12 +520,12 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u8",
+            "dtype": "u%d" % (8 * ELEM),
             "data": "synthetic",
             "config": {
-                "workload": "%s: 8-bit relative search, keyword '%s' (L=12), engine semantics, 512 KiB blocks, "
+                "workload": "%s: %s, engine semantics, 512 KiB blocks, "
                             "%.1f GiB splitmix64 ROM per GPU resident in HBM, 1 planted match/MiB + boundary straddlers "
-                            "+ 0x00/0xFF/ramp runs" % (args.config if args.gib_per_gpu is None else "custom", KEYWORD,
+                            "+ 0x00/0xFF/ramp runs" % (args.config if args.gib_per_gpu is None else "custom", cfg["what"],
                                                        per_gpu / (1 << 30)),
                 "name": args.config if args.gib_per_gpu is None else "custom",
                 "rom_bytes_total": total,
@@ -406,7 +543,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "mm_filter_u8<4>",
+                "kernel": kernel_name,
                 "achieved": achieved,
                 "peak": PEAK_HBM_GBS,
                 "unit": "GB/s",
@@ -461,8 +598,12 @@ def main():
                     "through mmh_scan_submit / mmh_scan_collect, %d tickets outstanding" % other_depth if other_depth > 1 else
                     "through mmh_scan, one scan at a time: the latency of a single 4 GiB scan as a caller sees it"),
             }
+        if not multi and args.config == "C2" and args.gib_per_gpu is None and not args.no_other_configs:
+            # BASELINE.json's other single-GPU configurations, NOT part of `value`
+            res["other_configs"] = {name: other_config(mm, torch, dev, name, args.other_scans, 2 * args.other_scans)
+                                    for name in OTHER_CONFIGS}
         if not multi and not args.no_cpu_baseline:
-            cb, cpu_offs, ncov = cpu_baseline(eng, shard, KEYWORD, args.cpu_sample_mib << 20, args.cpu_warmups, args.cpu_runs)
+            cb, cpu_offs, ncov = cpu_baseline(eng, shard, cfg, args.cpu_sample_mib << 20, args.cpu_warmups, args.cpu_runs)
             res["cpu_baseline"] = cb
             # parity of the timed configuration: the whole ROM when the CPU run covered it, else
             # the blocks fully inside the covered prefix

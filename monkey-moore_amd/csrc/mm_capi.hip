@@ -429,6 +429,21 @@ bool fused_enabled()
    return on;
 }
 
+// An outstanding gather may still be sending the device-side result copy a pipeline is about to publish into
+// (mmh_gather_start(NULL, 0) sends a scan's list from there, and overlaps the scans that follow): wait for its
+// collective.  Called for every pipeline launch -- a scan that retries (out_cap grown, left-overs to the flagged-
+// domains or flood path) toggles the copies again and would otherwise overwrite the one still being sent.
+int wait_for_gather_reading(mmh_ctx *c, const uint64_t *buffer)
+{
+   for (auto &s : c->mg.slot) {
+      if (s.busy && !s.from_host && s.src && s.src == buffer) {
+         HIP_TRY(hipSetDevice(c->device));
+         HIP_TRY(hipEventSynchronize(s.end));
+      }
+   }
+   return MMH_OK;
+}
+
 int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev, const MmGeom &g, const mmh_plan_desc &pl,
                      const mm::FilterChoice &fc, bool sequential, uint64_t base_offset, uint32_t max_candidates,
                      const uint32_t *skip_bits = nullptr, bool allow_polled = false, bool allow_single_launch = false)
@@ -441,7 +456,13 @@ int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev,
    const int count_index = sequential ? 1 : 0;
 
    w.h_result[6] = 0;                          // mm_rank_scatter publishes "matches + 1" here
-   w.result_turn ^= 1;                         // the other device-side copy may still be feeding a gather
+   w.result_turn ^= 1;                         // the other device-side copy may still be feeding a gather ...
+   {
+      const int rc = wait_for_gather_reading(c, w.d_result[w.result_turn]);   // ... and so may this one (two gathers outstanding, retries)
+      if (rc != MMH_OK) {
+         return rc;
+      }
+   }
    if (!w.ctrl_clean) {
       HIP_TRY(hipMemsetAsync(w.d_ctrl, 0, mm::ctrl_bytes(), st));
    }
@@ -1218,21 +1239,6 @@ int scan_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int b
 }
 } // namespace
 
-namespace {
-// An outstanding gather may still be sending the device-side result copy the next scan in this workspace is
-// about to overwrite (the scan before the last one there): wait for its collective.
-int wait_for_gather_of(mmh_ctx *c, const MmWorkspace &w)
-{
-   for (auto &s : c->mg.slot) {
-      if (s.busy && !s.from_host && s.src && s.src == w.d_result[w.result_turn ^ 1]) {
-         HIP_TRY(hipSetDevice(c->device));
-         HIP_TRY(hipEventSynchronize(s.end));
-      }
-   }
-   return MMH_OK;
-}
-} // namespace
-
 // mmh_scan proper + what the multi-GPU gather needs to know about its list (mm_multi.hip)
 extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian,
                         uint64_t base_offset, uint64_t *out, uint64_t cap, uint64_t *out_count)
@@ -1241,10 +1247,7 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
       c->mg.last_src = nullptr;
       c->mg.last_count = 0;
       c->mg.last_list.clear();
-      int rc = wait_for_gather_of(c, c->ws[0]);
-      if (rc != MMH_OK) {
-         return rc;
-      }
+      c->mg.last_end = nullptr;
    }
    std::vector<uint64_t> host_list;
    bool on_device = false;
@@ -1252,6 +1255,7 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
    if (c && (rc == MMH_OK || rc == MMH_E_CAPACITY)) {
       c->mg.last_count = *out_count;
       c->mg.last_src = on_device ? c->ws[0].d_result[c->ws[0].result_turn] : nullptr;
+      c->mg.last_end = on_device ? c->ev[2] : nullptr;   // the gather's stream waits for the scan's last kernel to retire
       if (!on_device && c->mg.comm) {
          c->mg.last_list.swap(host_list);            // only kept when a communicator may ask for it
       }
@@ -1313,10 +1317,6 @@ extern "C" int mmh_scan_submit(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t b
    HIP_TRY(hipSetDevice(c->device));
    MmWorkspace &w = c->ws[1 + lane];
    rc = ensure_workspace(c, w, std::max<uint64_t>(w.out_cap, kInitialCap));
-   if (rc != MMH_OK) {
-      return rc;
-   }
-   rc = wait_for_gather_of(c, w);
    if (rc != MMH_OK) {
       return rc;
    }
@@ -1464,6 +1464,7 @@ extern "C" int mmh_scan_collect(mmh_ctx *c, int ticket, uint64_t *out, uint64_t 
    p.active = false;
    // (mmh_gather_start(NULL, 0) sends this ticket's list from the lane's device-side copy)
    c->mg.last_src = w.d_result[w.result_turn];
+   c->mg.last_end = p.ev[2];
    c->mg.last_count = oc.matches;
    c->mg.last_list.clear();
    return MMH_OK;

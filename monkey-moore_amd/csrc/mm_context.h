@@ -65,6 +65,8 @@ struct MmGatherSlot {
    bool from_host = false;          // the local list came from host memory (long lists, forward engine)
    const uint64_t *src = nullptr;   // else: the device-side result copy (of the scan's workspace) it sends
    uint64_t local_count = 0;        // this rank's list length
+   std::vector<uint64_t> host_list; // a host-resident list too long for a record: kept HERE for the second phase, so that no
+                                    // later scan can take it away (all ranks must enter that phase or none)
    double start_wall_s = 0;         // host time spent in mmh_gather_start
 };
 
@@ -85,6 +87,9 @@ struct MmComm {
    const uint64_t *last_src = nullptr; // the most recent scan's (or collected ticket's) list sits ordered in this device-side
                                     // result copy of its workspace; null: it only exists on the host (last_list)
    uint64_t last_count = 0;
+   hipEvent_t last_end = nullptr;   // end event of the scan that left last_src: a polled scan returns when its flag word shows in
+                                    // pinned memory, which may be before its last kernel has retired and its plain stores to
+                                    // last_src are visible device-wide -- the gather's stream waits for this event first
    float last_device_ms = 0;        // collective + packing of the last finished gather (HIP events)
    double last_wall_ms = 0;         // host time inside mmh_gather_start + mmh_gather_finish of it
 };

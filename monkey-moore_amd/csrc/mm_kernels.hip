@@ -1133,7 +1133,8 @@ const Tuning &tuning()
       k.filter_blocks = (uint64_t)number("MMOORE_FILTER_BLOCKS", 256 * 6);
       k.filter_groups_per_span = (uint32_t)number("MMOORE_FILTER_GPS", 7);
       k.resolve_blocks = (unsigned)number("MMOORE_RESOLVE_BLOCKS", 4096);
-      k.tail_blocks = (unsigned)number("MMOORE_TAIL_BLOCKS", 2048);
+      // (mm_arrive_last counts arrivals in MM_ARRIVE_LINES - 1 groups of MM_ARRIVE_FAN: more workgroups would spill into the next lines)
+      k.tail_blocks = (unsigned)std::min<long>(number("MMOORE_TAIL_BLOCKS", 2048), (long)MM_ARRIVE_FAN * (MM_ARRIVE_LINES - 1));
       k.max_candidates = (uint32_t)number("MMOORE_MAX_CANDIDATES", 262144);
       return k;
    }();

@@ -262,6 +262,7 @@ void comm_release(mmh_ctx *c)
    m.nranks = 1;
    m.last_list.clear();
    m.last_src = nullptr;
+   m.last_end = nullptr;
 }
 
 } // namespace
@@ -382,6 +383,10 @@ int gather_prepare(mmh_ctx *c, const uint64_t *offsets, uint64_t n, const uint64
          s.src = m.last_src;
          s.local_count = m.last_count;
          *send = m.last_src;
+         if (m.last_end) {
+            // the scan's kernels ran on another stream; its end shows in pinned memory before the kernel retires
+            HIP_TRY(hipStreamWaitEvent(m.stream, m.last_end, 0));
+         }
       }
       else {
          offsets = m.last_list.data();
@@ -396,8 +401,11 @@ int gather_prepare(mmh_ctx *c, const uint64_t *offsets, uint64_t n, const uint64
       }
       hipLaunchKernelGGL(mm_gather_stamp, dim3(1), dim3(64), 0, m.stream, m.d_send, n);
       HIP_TRY(hipGetLastError());
-      if (n > MM_MAX_RANK_SORT && offsets != m.last_list.data()) {
-         m.last_list.assign(offsets, offsets + n);      // the second phase sends it from here
+      if (n > MM_MAX_RANK_SORT) {
+         s.host_list.assign(offsets, offsets + n);      // the second phase sends it from here, whatever scans run in between
+      }
+      else {
+         s.host_list.clear();
       }
       *send = m.d_send;
    }
@@ -455,11 +463,11 @@ int long_prepare(mmh_ctx *c, MmGatherSlot &s, uint64_t longest)
    }
    if (s.local_count) {
       if (s.from_host) {
-         if (m.last_list.size() != s.local_count) {
-            mmh_set_error("mmh_gather_finish: the list handed to mmh_gather_start is gone (a scan ran in between)");
+         if (s.host_list.size() != s.local_count) {
+            mmh_set_error("mmh_gather_finish: the gather slot lost its host list (internal error)");
             return MMH_E_STATE;
          }
-         HIP_TRY(hipMemcpyAsync(m.d_long + kMergedHeader, m.last_list.data(), s.local_count * sizeof(uint64_t), hipMemcpyHostToDevice,
+         HIP_TRY(hipMemcpyAsync(m.d_long + kMergedHeader, s.host_list.data(), s.local_count * sizeof(uint64_t), hipMemcpyHostToDevice,
                                 m.stream));
       }
       else {

@@ -134,18 +134,15 @@ constexpr uint64_t kMinBytesPerDevice = 1ull << 30;
 struct DeviceSet {
    std::mutex lock;                         // one run() at a time drives the set
    std::vector<mmh_ctx *> ctx;
-   ~DeviceSet()
-   {
-      for (mmh_ctx *c : ctx) {
-         mmh_destroy(c);
-      }
-   }
 };
 
+// The set lives for the rest of the process and is deliberately never destroyed: a static destructor would call
+// ncclCommDestroy / hipFree at exit, when HIP or RCCL (other shared objects, unspecified destruction order) may be
+// gone already -- a known source of exit-time hangs.  The driver reclaims everything when the process ends.
 DeviceSet &device_set()
 {
-   static DeviceSet set;
-   return set;
+   static DeviceSet *set = new DeviceSet();
+   return *set;
 }
 
 int devices_wanted(uint64_t file_size, bool *forced)
@@ -156,6 +153,10 @@ int devices_wanted(uint64_t file_size, bool *forced)
    if (mmh_device_count(&visible) != MMH_OK || visible < 1) {
       return 1;                             // thread_context() reports the missing device properly
    }
+   // (the set starts at device MMOORE_HIP_DEVICE: only the devices from there on count)
+   const char *first_env = std::getenv("MMOORE_HIP_DEVICE");
+   const int first = first_env ? std::max(0, std::atoi(first_env)) : 0;
+   visible = std::max(1, visible - first);
    const char *cap = std::getenv("MMOORE_HIP_DEVICES");
    int most = cap && std::atoi(cap) > 0 ? std::min(visible, std::atoi(cap)) : visible;
    const uint64_t by_size = std::max<uint64_t>(1, file_size / kMinBytesPerDevice);
@@ -176,6 +177,11 @@ void ensure_devices(DeviceSet &set, int n)
    set.ctx.clear();
    const char *env = std::getenv("MMOORE_HIP_DEVICE");
    const int first = env ? std::atoi(env) : 0;
+   int visible = 0;
+   if (mmh_device_count(&visible) != MMH_OK || first < 0 || first + n > visible) {
+      throw std::runtime_error("MMOORE_HIP_DEVICE=" + std::to_string(first) + " with " + std::to_string(n) + " devices wanted, but " +
+                               std::to_string(visible) + " are visible");
+   }
    for (int i = 0; i < n; i++) {
       mmh_ctx *c = nullptr;
       if (mmh_create(first + i, &c) != MMH_OK) {

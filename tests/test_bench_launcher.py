@@ -1,0 +1,66 @@
+# SPDX-License-Identifier: GPL-3.0-or-later
+"""bench.py's own launcher (CPU): `python bench.py --gpus N` starts its N ranks itself -- before
+torch is imported or a GPU touched --, a world size that is not --gpus is refused, and a node
+with fewer GPUs than ranks is refused instead of being oversubscribed."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env=None, timeout=300):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, BENCH] + args, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                          timeout=timeout)
+
+
+def _lines(out):
+    return [json.loads(ln) for ln in out.splitlines() if ln.startswith("{")]
+
+
+def test_gpus_n_launches_n_ranks_by_itself():
+    r = _run(["--gpus", "3", "--dry-launch", "--steps", "2", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = sorted(_lines(r.stdout), key=lambda d: d["rank"])
+    assert [d["rank"] for d in got] == [0, 1, 2]
+    assert [d["local_rank"] for d in got] == [0, 1, 2]
+    assert all(d["world"] == 3 and d["gpus"] == 3 and d["dry_launch"] for d in got)
+    assert "torch.distributed.run" in r.stderr and "--master-addr 127.0.0.1" in r.stderr
+
+
+def test_single_gpu_default_does_not_spawn():
+    r = _run(["--dry-launch"])
+    assert r.returncode == 0
+    assert _lines(r.stdout) == [{"dry_launch": True, "rank": 0, "local_rank": 0, "world": 1, "gpus": 1}]
+    assert "launching" not in r.stderr
+
+
+def test_world_size_that_is_not_gpus_is_refused():
+    # the way round 2's bench would have lied: --gpus 8 under a world of 1 (or no launcher at all)
+    r = _run(["--gpus", "8", "--dry-launch"], env={"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr and not _lines(r.stdout)
+    r = _run(["--gpus", "1", "--dry-launch"], env={"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0"})
+    assert r.returncode == 2 and not _lines(r.stdout)
+
+
+def test_under_a_launcher_no_second_launch():
+    r = _run(["--gpus", "2", "--dry-launch"], env={"RANK": "1", "WORLD_SIZE": "2", "LOCAL_RANK": "1"})
+    assert r.returncode == 0 and "launching" not in r.stderr
+    assert _lines(r.stdout) == [{"dry_launch": True, "rank": 1, "local_rank": 1, "world": 2, "gpus": 2}]
+
+
+def test_more_ranks_than_gpus_is_refused():
+    # (this container has no GPU at all; a 1-GPU box refuses --gpus 2 the same way: tests/test_gpu_multi.py)
+    import torch
+    have = torch.cuda.device_count()
+    r = _run(["--gpus", str(have + 2), "--steps", "2"])
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    assert "only %d GPU(s) visible" % have in r.stderr and "refusing" in r.stderr
+    assert not _lines(r.stdout)
