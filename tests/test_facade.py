@@ -98,3 +98,41 @@ def test_reference_suites_through_the_facade(mm):
     print(r.stdout[-3000:])
     assert r.returncode == 0, r.stdout[-3000:]
     assert " 0 failures" in r.stdout
+
+
+@pytest.mark.gpu
+def test_facade_differential_against_the_reference_core_on_the_gpu(mm):
+    """oracle/_ref/facade_diff (tests/cpp/facade_diff_*.cpp, prebuilt in the build container): MonkeyMoore<T>::search and
+    SearchEngine<T>::run of the MI355X facade against the reference core in ONE process through the API both share --
+    positions, equivalency maps, previews, callback counts -- on 200 random cases.  The reference side can be made to
+    allocate without bound by keywords the generator avoids: the program watches its own resident size, and
+    so does this test from outside (a second, independent watchdog), besides a wall-clock limit.  The same 200 cases
+    run against the CPU double in the CPU suite (tests/test_sanitize.py), so the reference side's behaviour on them is
+    known before they ever reach a GPU box."""
+    import time
+    exe = os.path.join(REF_BIN, "facade_diff")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/facade_diff was not prebuilt (needs /root/reference in the build container)")
+    mm.build.build_all()
+    cases = os.environ.get("MM_FACADE_DIFF_CASES", "200")
+    p = subprocess.Popen([exe, cases], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    t0, killed = time.time(), None
+    page = os.sysconf("SC_PAGESIZE")
+    while p.poll() is None:
+        time.sleep(0.05)
+        try:
+            with open("/proc/%d/statm" % p.pid) as f:
+                resident = int(f.read().split()[1]) * page
+        except (OSError, IndexError, ValueError):
+            resident = 0
+        if resident > (8 << 30) or time.time() - t0 > 900:
+            killed = "resident %d MiB after %.0f s" % (resident >> 20, time.time() - t0)
+            p.kill()
+            break
+    out = p.communicate()[0]
+    print(out[-3000:])
+    assert killed is None, killed
+    assert p.returncode == 0, out[-3000:]
+    assert "%s cases" % cases in out and " 0 failures" in out
+    compared = int(out.split(" matches compared")[0].split()[-1])
+    assert compared > 20000, out[-500:]
