@@ -13,8 +13,11 @@
 //   * block offsets are 64 bit (the reference multiplies in 32 bit, :241-242, and breaks
 //     above 4 GiB)
 //   * progress: (0, Initializing), (0, Searching), one (pct, Searching) per reference block,
-//     (100, GeneratingPreviews) -- blocks + 3 calls, monotone, all from the calling thread
-//   * abort: polled after every progress callback and between partitions; run() returns {}
+//     (100, GeneratingPreviews) -- blocks + 3 calls, monotone, all from the calling thread; a block's tick
+//     comes when its bytes have landed in HBM (the ingest is where the time goes), a round's last one
+//     after its scan
+//   * abort: polled after every progress callback, every 0.2 ms while a partition streams to the GPU (the
+//     readers stop at the next 4 MiB piece) and between ingest, scan and gather; run() returns {}
 //   * a missing file throws std::runtime_error("File not found") before any callback
 #ifndef MMOORE_AMD_SEARCH_ENGINE_HPP
 #define MMOORE_AMD_SEARCH_ENGINE_HPP

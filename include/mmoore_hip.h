@@ -46,7 +46,8 @@ enum {
    MMH_E_PLAN = -2,             /* keyword the reference rejects or cannot terminate on */
    MMH_E_DEVICE = -3,           /* HIP error / no device */
    MMH_E_CAPACITY = -4,         /* out buffer too small; *out_count holds the need */
-   MMH_E_STATE = -5             /* no ROM attached, etc. */
+   MMH_E_STATE = -5,            /* no ROM attached, etc. */
+   MMH_E_ABORTED = -6           /* mmh_rom_load_file_watched: the caller's abort word was raised */
 };
 
 enum { MMH_MODE_SIMPLE = 1, MMH_MODE_WILDCARD = 2, MMH_MODE_VALUE_SCAN = 3 };
@@ -109,6 +110,16 @@ int mmh_rom_download(mmh_ctx *ctx, uint64_t first_byte, void *host, uint64_t nby
  * and PCIe transfers overlap.  Replaces the workers' per-block ifstream reads of
  * src/core/search_engine.cpp:120-145.  MMH_E_ARG: cannot open / short read. */
 int mmh_rom_load_file(mmh_ctx *ctx, const char *path, uint64_t file_offset, uint64_t nbytes, int threads);
+/* The same load, watched from another thread -- the reference's dispatcher polls its abort flag between blocks and
+ * reports progress per block while the workers read (src/core/search_engine.cpp:161-187); here the bulk of a
+ * file search's time is this ingest, so it is what has to be interruptible and observable:
+ *   abort_word  (may be NULL) is read before every 4 MiB piece; once it is non-zero the readers stop, the copies
+ *               already queued are drained and the call returns MMH_E_ABORTED (the ROM's contents are then undefined);
+ *   bytes_done  (may be NULL) is set to 0 at the start and raised by the size of every piece whose read has finished
+ *               and whose host-to-device copy has been queued (monotone; nbytes once a load has succeeded).
+ * Both words are accessed with relaxed atomic loads / adds; the caller polls bytes_done from its own thread. */
+int mmh_rom_load_file_watched(mmh_ctx *ctx, const char *path, uint64_t file_offset, uint64_t nbytes, int threads,
+                              const volatile int32_t *abort_word, volatile uint64_t *bytes_done);
 /* wall time, size and reader count of the last mmh_rom_load_file */
 int mmh_last_load_stats(mmh_ctx *ctx, double *seconds, uint64_t *bytes, int *threads);
 /* Packed copy of bytes_each bytes at each of n ROM byte offsets into host_out (n * bytes_each

@@ -21,14 +21,14 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = _build.CAPI_SO
 
 MMH_MAX_KEYWORD = 128
-MMH_OK, MMH_E_ARG, MMH_E_PLAN, MMH_E_DEVICE, MMH_E_CAPACITY, MMH_E_STATE = 0, -1, -2, -3, -4, -5
+MMH_OK, MMH_E_ARG, MMH_E_PLAN, MMH_E_DEVICE, MMH_E_CAPACITY, MMH_E_STATE, MMH_E_ABORTED = 0, -1, -2, -3, -4, -5, -6
 
 EXPORTS = [
     "mmh_last_error", "mmh_plan_relative", "mmh_plan_value_scan", "mmh_device_count", "mmh_create", "mmh_destroy",
     "mmh_set_stream", "mmh_rom_upload", "mmh_rom_attach", "mmh_rom_download", "mmh_rom_alloc", "mmh_rom_synth",
     "mmh_rom_poke", "mmh_rom_fill", "mmh_scan", "mmh_set_engine", "mmh_last_timings", "mmh_last_counters",
     "mmh_timing_history", "mmh_filter_shape", "mmh_rom_load_file", "mmh_last_load_stats", "mmh_rom_gather",
-    "mmh_scan_submit", "mmh_scan_collect",
+    "mmh_scan_submit", "mmh_scan_collect", "mmh_rom_load_file_watched",
     "mmh_partition", "mmh_comm_unique_id", "mmh_comm_init_rank", "mmh_comm_init_all", "mmh_comm_info", "mmh_comm_destroy",
     "mmh_gather_start", "mmh_gather_finish", "mmh_last_gather_timings", "mmh_scan_multi", "mmh_selftest_gather_pack",
 ]
@@ -110,6 +110,7 @@ def lib():
         L.mmh_last_counters.argtypes = [C.c_void_p, u64p]
         L.mmh_filter_shape.argtypes = [C.POINTER(PlanDesc), C.POINTER(C.c_uint32)]
         L.mmh_rom_load_file.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_int]
+        L.mmh_rom_load_file_watched.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_int32), u64p]
         L.mmh_last_load_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double), u64p, C.POINTER(C.c_int)]
         L.mmh_rom_gather.argtypes = [C.c_void_p, u64p, C.c_uint64, C.c_uint32, C.c_void_p]
         L.mmh_timing_history.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
@@ -265,9 +266,16 @@ class Engine:
         _check(lib().mmh_rom_download(self._h, first_byte, out.ctypes.data, nbytes))
         return out
 
-    def load_file(self, path, file_offset, nbytes, threads=0):
-        """ROM <- bytes [file_offset, file_offset + nbytes) of a file (parallel readers + overlapped copies)."""
-        _check(lib().mmh_rom_load_file(self._h, os.fsencode(path), file_offset, nbytes, threads))
+    def load_file(self, path, file_offset, nbytes, threads=0, abort_word=None, bytes_done=None):
+        """ROM <- bytes [file_offset, file_offset + nbytes) of a file (parallel readers + overlapped copies).
+        abort_word / bytes_done: ctypes c_int32 / c_uint64 another thread raises / polls (mmh_rom_load_file_watched);
+        an aborted load raises MMError with code MMH_E_ABORTED."""
+        if abort_word is None and bytes_done is None:
+            _check(lib().mmh_rom_load_file(self._h, os.fsencode(path), file_offset, nbytes, threads))
+        else:
+            _check(lib().mmh_rom_load_file_watched(self._h, os.fsencode(path), file_offset, nbytes, threads,
+                                                   C.byref(abort_word) if abort_word is not None else None,
+                                                   C.byref(bytes_done) if bytes_done is not None else None))
         s, b, t = C.c_double(0), C.c_uint64(0), C.c_int(0)
         _check(lib().mmh_last_load_stats(self._h, C.byref(s), C.byref(b), C.byref(t)))
         return {"seconds": s.value, "bytes": b.value, "threads": t.value}

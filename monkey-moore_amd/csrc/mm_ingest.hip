@@ -68,9 +68,18 @@ bool ingest_resources(mmh_ctx *c, int threads, std::string *err)
 
 extern "C" int mmh_rom_load_file(mmh_ctx *c, const char *path, uint64_t file_offset, uint64_t nbytes, int threads)
 {
+   return mmh_rom_load_file_watched(c, path, file_offset, nbytes, threads, nullptr, nullptr);
+}
+
+extern "C" int mmh_rom_load_file_watched(mmh_ctx *c, const char *path, uint64_t file_offset, uint64_t nbytes, int threads,
+                                         const volatile int32_t *abort_word, volatile uint64_t *bytes_done)
+{
    if (!c || !path || threads < 0) {
       mmh_set_error("mmh_rom_load_file: bad argument");
       return MMH_E_ARG;
+   }
+   if (bytes_done) {
+      __atomic_store_n(bytes_done, (uint64_t)0, __ATOMIC_RELAXED);
    }
    const auto t0 = std::chrono::steady_clock::now();
    int rc = mmh_rom_alloc(c, nbytes);
@@ -102,7 +111,7 @@ extern "C" int mmh_rom_load_file(mmh_ctx *c, const char *path, uint64_t file_off
    close(probe);
 
    std::atomic<uint64_t> next{0};
-   std::atomic<bool> failed{false};
+   std::atomic<bool> failed{false}, aborted{false};
    std::mutex err_lock;
    MmIngest &in = c->ingest;
    auto reader = [&](int t) {
@@ -120,7 +129,12 @@ extern "C" int mmh_rom_load_file(mmh_ctx *c, const char *path, uint64_t file_off
          return give_up(std::string("cannot open ") + path + ": " + strerror(errno));
       }
       bool used[2] = {false, false};
-      for (unsigned turn = 0; !failed; turn++) {
+      for (unsigned turn = 0; !failed && !aborted; turn++) {
+         // the caller's abort word, once per piece (a piece is ~1 ms of reading)
+         if (abort_word && __atomic_load_n(abort_word, __ATOMIC_RELAXED) != 0) {
+            aborted = true;
+            break;
+         }
          const uint64_t k = next.fetch_add(1);
          if (k >= npieces) {
             break;
@@ -154,6 +168,9 @@ extern "C" int mmh_rom_load_file(mmh_ctx *c, const char *path, uint64_t file_off
             break;
          }
          used[turn & 1] = true;
+         if (bytes_done) {
+            __atomic_fetch_add(bytes_done, len, __ATOMIC_RELAXED);
+         }
       }
       if (hipStreamSynchronize(in.streams[t]) != hipSuccess) {
          give_up("hipStreamSynchronize failed in a reader thread");
@@ -171,6 +188,10 @@ extern "C" int mmh_rom_load_file(mmh_ctx *c, const char *path, uint64_t file_off
    in.last_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
    in.last_bytes = nbytes;
    in.last_threads = threads;
+   if (aborted && !failed) {
+      mmh_set_error("mmh_rom_load_file: aborted by the caller");
+      return MMH_E_ABORTED;
+   }
    if (failed) {
       mmh_set_error("mmh_rom_load_file: %s", err.c_str());
       return err.find("short read") != std::string::npos || err.find("cannot open") != std::string::npos ? MMH_E_ARG : MMH_E_DEVICE;

@@ -9,6 +9,7 @@
 #include "mmoore/search_engine.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <fstream>
 #include <mutex>
@@ -263,33 +264,77 @@ std::vector<mmoore::SearchResult<DataType>> mmoore::SearchEngine<DataType>::run(
          parts[i].base = b0 * block;
          parts[i].bytes = b1 > b0 ? std::min((b1 - b0) * block + overlap, file_size - parts[i].base) : 0;   // pattern-length overlap
       }
-      // file -> HBM through parallel readers and overlapped copies (mm_ingest.hip), every device
-      // at once over its own PCIe link; no host copy is kept
+      // file -> HBM through parallel readers and overlapped copies (mm_ingest.hip), every device at once over its
+      // own PCIe link; no host copy is kept.  The ingest is where a file search spends its time (80 ms per 4 GiB
+      // against < 1 ms of scan), so it is what reports progress and listens for the abort flag: the loaders run on
+      // threads of their own, this thread polls what has landed -- one progress tick per reference block whose bytes
+      // are in HBM, like the reference's workers tick as they finish blocks (search_engine.cpp:161-165) -- and
+      // raises the loaders' abort word as soon as the caller's flag is up (:177-187: polled every 5 ms there;
+      // here every 0.2 ms, and the readers look at the word before every 4 MiB piece).
       std::vector<std::string> load_error(ctxs.size());
+      std::vector<int> load_rc(ctxs.size(), MMH_OK);
+      std::vector<uint64_t> landed(ctxs.size(), 0);           // raised by the library (relaxed atomics)
+      int32_t stop_loading = 0;
+      std::atomic<int> loading{(int)ctxs.size()};
       auto load = [&](size_t i) {
-         if (mmh_rom_load_file(ctxs[i], path.c_str(), parts[i].base, parts[i].bytes, 0) != MMH_OK) {
+         load_rc[i] = mmh_rom_load_file_watched(ctxs[i], path.c_str(), parts[i].base, parts[i].bytes, 0, &stop_loading, &landed[i]);
+         if (load_rc[i] != MMH_OK) {
             load_error[i] = mmh_last_error();
          }
+         loading--;
       };
       std::vector<std::thread> loaders;
-      for (size_t i = 1; i < ctxs.size(); i++) {
+      for (size_t i = 0; i < ctxs.size(); i++) {
          loaders.emplace_back(load, i);
       }
-      load(0);
+      uint64_t ticked = 0;                                     // progress ticks of this round so far
+      bool aborted = false;
+      auto tick_landed_blocks = [&]() {
+         uint64_t bytes = 0;
+         for (size_t i = 0; i < ctxs.size(); i++) {
+            bytes += __atomic_load_n(&landed[i], __ATOMIC_RELAXED);
+         }
+         // the round's last tick waits for the scan: progress only reaches a round's share once its results exist
+         const uint64_t may = std::min<uint64_t>(bytes / block, round_blocks - 1);
+         while (ticked < may && !aborted) {
+            ticked++;
+            progress += progress_step;
+            on_progress(static_cast<int>(progress), SearchStep::Searching);
+            aborted = abort_flag;
+         }
+      };
+      const auto poll_start = std::chrono::steady_clock::now();
+      while (loading > 0 && !aborted) {
+         // (small files are in HBM within microseconds: spin first, sleep only once the load turns out to take a while)
+         if (std::chrono::steady_clock::now() - poll_start < std::chrono::microseconds(300)) {
+            std::this_thread::yield();
+         }
+         else {
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+         }
+         aborted = aborted || abort_flag;
+         if (!aborted) {
+            tick_landed_blocks();
+         }
+      }
+      if (aborted) {
+         __atomic_store_n(&stop_loading, 1, __ATOMIC_RELAXED);
+      }
       for (auto &t : loaders) {
          t.join();
       }
-      for (const std::string &why : load_error) {
-         if (why.empty()) {
+      if (aborted || abort_flag) {
+         return {};
+      }
+      for (size_t i = 0; i < ctxs.size(); i++) {
+         const std::string &why = load_error[i];
+         if (load_rc[i] == MMH_OK) {
             continue;
          }
          if (why.find("short read") != std::string::npos) {
             throw std::runtime_error("Short read from " + path);
          }
          throw std::runtime_error("streaming a file partition to the GPU failed: " + why);
-      }
-      if (abort_flag) {                                       // polled between ingest, scan and gather (search_engine.cpp:177-187)
-         return {};
       }
       uint64_t count = 0;
       for (;;) {
@@ -344,8 +389,8 @@ std::vector<mmoore::SearchResult<DataType>> mmoore::SearchEngine<DataType>::run(
          auto elem = [at, order](int k) { return element_at<DataType>(at + static_cast<size_t>(k) * sizeof(DataType), order); };
          results.push_back({offsets[i], build_values_map<DataType>(st, elem), std::string()});
       }
-      // one progress tick per reference block, then the abort poll (search_engine.cpp:161-187)
-      for (uint64_t b = 0; b < round_blocks; b++) {
+      // the round's remaining ticks (one per reference block in all), each followed by the abort poll (search_engine.cpp:161-187)
+      for (uint64_t b = ticked; b < round_blocks; b++) {
          progress += progress_step;
          on_progress(static_cast<int>(progress), SearchStep::Searching);
          if (abort_flag) {

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -82,6 +83,47 @@ extern "C" int mmh_rom_load_file(mmh_ctx *c, const char *path, uint64_t file_off
       return MMH_E_ARG;
    }
    return MMH_OK;
+}
+
+// the watched load: 4 MiB pieces, the abort word read before each, bytes_done raised behind each;
+// MMOORE_DOUBLE_PIECE_US slows every piece down (a stand-in for a file that takes a while to cross PCIe)
+extern "C" int mmh_rom_load_file_watched(mmh_ctx *c, const char *path, uint64_t file_offset, uint64_t nbytes, int,
+                                         const volatile int32_t *abort_word, volatile uint64_t *bytes_done)
+{
+   FILE *f = std::fopen(path, "rb");
+   if (!f) {
+      mmh_set_error("double: cannot open %s", path);
+      return MMH_E_ARG;
+   }
+   if (bytes_done) {
+      __atomic_store_n(bytes_done, (uint64_t)0, __ATOMIC_RELAXED);
+   }
+   const char *slow = getenv("MMOORE_DOUBLE_PIECE_US");
+   const long piece_us = slow && *slow ? atol(slow) : 0;
+   c->rom.assign(nbytes, 0);
+   int rc = std::fseek(f, (long)file_offset, SEEK_SET) == 0 ? MMH_OK : MMH_E_ARG;
+   for (uint64_t at = 0; rc == MMH_OK && at < nbytes; at += 4u << 20) {
+      if (abort_word && __atomic_load_n(abort_word, __ATOMIC_RELAXED) != 0) {
+         mmh_set_error("double: aborted by the caller");
+         rc = MMH_E_ABORTED;
+         break;
+      }
+      const uint64_t len = std::min<uint64_t>(4u << 20, nbytes - at);
+      if (std::fread(c->rom.data() + at, 1, len, f) != len) {
+         mmh_set_error("double: short read of %s", path);
+         rc = MMH_E_ARG;
+         break;
+      }
+      if (piece_us) {
+         struct timespec ts = {0, piece_us * 1000};
+         nanosleep(&ts, nullptr);
+      }
+      if (bytes_done) {
+         __atomic_fetch_add(bytes_done, len, __ATOMIC_RELAXED);
+      }
+   }
+   std::fclose(f);
+   return rc;
 }
 
 extern "C" int mmh_rom_gather(mmh_ctx *c, const uint64_t *offs, uint64_t n, uint32_t each, void *host_out)
