@@ -50,9 +50,13 @@ def test_facade_under_sanitizers():
     subprocess.check_call(["python3", os.path.join(CPP, "gen_cases.py"), os.path.join(BUILD, "cases.inc")])
     exe = os.path.join(BUILD, "facade_tests_asan")
     subprocess.check_call(SAN + ["-I" + BUILD, os.path.join(CPP, "facade_tests.cpp")] + FACADE + ["-o", exe])
-    assert " 0 failures" in _run(exe)
+    # (MMOORE_DOUBLE_PIECE_US: the double's ingest takes 2 ms per 4 MiB piece, so that the 8192-block file of the facade
+    # tests streams in over ~30 ms -- ticks arrive meanwhile, and the aborts raised 1 / 6 / 15 ms in hit the ingest)
+    out = _run(exe, MMOORE_DOUBLE_PIECE_US="2000")
+    assert " 0 failures" in out
+    assert out.count("run() back") >= 2, out[-2000:]
     # run()'s multi-device rounds: three "devices", partitions dealt out over them
-    assert " 0 failures" in _run(exe, MMOORE_DOUBLE_DEVICES="3", MMOORE_HIP_MULTI="1")
+    assert " 0 failures" in _run(exe, MMOORE_DOUBLE_DEVICES="3", MMOORE_HIP_MULTI="1", MMOORE_DOUBLE_PIECE_US="500")
 
 
 def test_reference_unit_tests_on_the_facade_under_sanitizers():
