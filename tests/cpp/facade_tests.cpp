@@ -290,7 +290,10 @@ int main()
          const double late_ms = std::chrono::duration<double, std::milli>(back - raised).count();
          if (got.empty()) {
             std::printf("big file: abort %.0f ms into the search: run() back %.2f ms after the flag, %d callbacks\n", after_ms, late_ms, calls);
-            CHECK(late_ms < 10.0, "abort during the ingest took %.2f ms to return", late_ms);
+            // (10 ms on the device; the sanitizer builds of the CPU double are slower by orders of magnitude and say so)
+            const char *limit_env = getenv("MMOORE_TEST_ABORT_MS");
+            const double limit_ms = limit_env && atof(limit_env) > 0 ? atof(limit_env) : 10.0;
+            CHECK(late_ms < limit_ms, "abort during the ingest took %.2f ms to return (limit %.0f)", late_ms, limit_ms);
             CHECK(calls < (int)nblocks + 3, "aborted run made all %d callbacks", calls);
          }
          else {

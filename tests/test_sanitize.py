@@ -27,7 +27,9 @@ SAN = ["g++", "-std=c++17", "-O0", "-g", "-fsanitize=address,undefined", "-fno-s
        "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-I" + HOST]
 FACADE = [os.path.join(CPP, "cpu_backend_double.cpp"), os.path.join(CSRC, "mm_plan.cpp"), os.path.join(HOST, "monkey_moore.cpp"),
           os.path.join(HOST, "search_engine.cpp")]
-ENV = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+# (MMOORE_TEST_ABORT_MS: the facade tests hold an aborted run() to 10 ms on the device; instrumented builds of the CPU double
+# need far longer for the 4 MiB piece they are in the middle of)
+ENV = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1", MMOORE_TEST_ABORT_MS="2000")
 
 
 def _run(exe, **env):
@@ -79,7 +81,8 @@ def test_facade_under_thread_sanitizer():
     tsan = [a if not a.startswith("-fsanitize=") else "-fsanitize=thread" for a in SAN if a != "-fno-sanitize-recover=all"]
     subprocess.check_call(tsan + ["-I" + BUILD, os.path.join(CPP, "facade_tests.cpp")] + FACADE + ["-o", exe])
     for env in ({}, {"MMOORE_DOUBLE_DEVICES": "3", "MMOORE_HIP_MULTI": "1"}):
-        r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, env=dict(os.environ, **env))
+        r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
+                           env=dict(os.environ, MMOORE_TEST_ABORT_MS="5000", **env))
         assert r.returncode == 0 and "ThreadSanitizer" not in r.stdout, r.stdout[-4000:]
         assert " 0 failures" in r.stdout
 
