@@ -64,6 +64,32 @@ extern "C" const char *mmh_last_error(void) { return g_error.c_str(); }
 
 namespace {
 
+mm::ResolveBuffers resolve_buffers(const MmWorkspace &w)
+{
+   mm::ResolveBuffers rb;
+   rb.cand = w.d_cand; rb.cand_cap = w.cand_cap; rb.out = w.d_out; rb.out_cap = w.out_cap; rb.ctrl = w.d_ctrl;
+   rb.mid_off = w.d_mid_off; rb.mid_hi = w.d_mid_hi; rb.mid_set = w.d_mid_set; rb.mid_slot = w.d_mid_slot;
+   rb.hard_off = w.d_hard_off; rb.hard_hi = w.d_hard_hi; rb.hard_set = w.d_hard_set; rb.hard_slot = w.d_hard_slot;
+   rb.scratch = w.d_scratch;
+   rb.bcand = w.d_bcand; rb.bcount = w.d_bcount;
+   return rb;
+}
+
+// the bucketed candidate store of a workspace (big ROMs only: 32 MiB), counters zeroed
+int ensure_buckets(mmh_ctx *c, MmWorkspace &w, hipStream_t st)
+{
+   if (!w.d_bcand) {
+      HIP_TRY(hipSetDevice(c->device));
+      HIP_TRY(hipMalloc(&w.d_bcand, mm::bucket_cand_bytes()));
+      HIP_TRY(hipMalloc(&w.d_bcount, mm::bucket_count_bytes()));
+      w.buckets_clean = false;
+   }
+   if (!w.buckets_clean) {
+      HIP_TRY(hipMemsetAsync(w.d_bcount, 0, mm::bucket_count_bytes(), st));
+   }
+   return MMH_OK;
+}
+
 int ensure_workspace(mmh_ctx *c, MmWorkspace &w, uint64_t out_cap)
 {
    HIP_TRY(hipSetDevice(c->device));
@@ -121,6 +147,8 @@ void free_workspace(MmWorkspace &w)
    if (w.d_hard_slot) (void)hipFree(w.d_hard_slot);
    if (w.d_scratch) (void)hipFree(w.d_scratch);
    if (w.d_partials) (void)hipFree(w.d_partials);
+   if (w.d_bcand) (void)hipFree(w.d_bcand);
+   if (w.d_bcount) (void)hipFree(w.d_bcount);
    if (w.h_result) (void)hipHostFree(w.h_result);
    for (auto d : w.d_result) {
       if (d) (void)hipFree(d);
@@ -145,6 +173,7 @@ void begin_scan_events(mmh_ctx *c, bool has_filter)
 
 void release_rom(mmh_ctx *c)
 {
+   (void)mm_ingest_drain(c);                // (copies of an aborted file load may still be writing the ROM)
    if (c->rom_own) {
       (void)hipFree(c->rom_own);
    }
@@ -287,6 +316,12 @@ extern "C" int mmh_rom_alloc(mmh_ctx *c, uint64_t nbytes)
       return MMH_E_ARG;
    }
    HIP_TRY(hipSetDevice(c->device));
+   {
+      const int rc = mm_ingest_drain(c);
+      if (rc != MMH_OK) {
+         return rc;
+      }
+   }
    uint64_t need = ((nbytes + 15) / 16) * 16 + 16;
    if (!(c->rom_own && c->rom_alloc >= need)) {
       release_rom(c);
@@ -420,6 +455,17 @@ struct Outcome {
 // A scan that finds the lock taken simply runs the plain kernels.
 std::mutex g_fused_lock;
 
+// MMOORE_BUCKETS=0: big ROMs take mm_scan_tail over the 64 candidate lists (round 2's tail) instead of the bucketed
+// store + mm_scan_tail2
+bool buckets_enabled()
+{
+   static const bool on = [] {
+      const char *v = getenv("MMOORE_BUCKETS");
+      return !(v && *v == '0');
+   }();
+   return on;
+}
+
 bool fused_enabled()
 {
    static const bool on = [] {
@@ -446,14 +492,21 @@ int wait_for_gather_reading(mmh_ctx *c, const uint64_t *buffer)
 
 int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev, const MmGeom &g, const mmh_plan_desc &pl,
                      const mm::FilterChoice &fc, bool sequential, uint64_t base_offset, uint32_t max_candidates,
-                     const uint32_t *skip_bits = nullptr, bool allow_polled = false, bool allow_single_launch = false)
+                     const uint32_t *skip_bits = nullptr, bool allow_polled = false, bool allow_single_launch = false,
+                     hipStream_t tail_st = nullptr, unsigned tail_blocks = 0)
 {
-   mm::ResolveBuffers rb;
-   rb.cand = w.d_cand; rb.cand_cap = w.cand_cap; rb.out = w.d_out; rb.out_cap = w.out_cap; rb.ctrl = w.d_ctrl;
-   rb.mid_off = w.d_mid_off; rb.mid_hi = w.d_mid_hi; rb.mid_set = w.d_mid_set; rb.mid_slot = w.d_mid_slot;
-   rb.hard_off = w.d_hard_off; rb.hard_hi = w.d_hard_hi; rb.hard_set = w.d_hard_set; rb.hard_slot = w.d_hard_slot;
-   rb.scratch = w.d_scratch;
    const int count_index = sequential ? 1 : 0;
+   const bool polled = allow_polled && !sequential && !skip_bits && fused_enabled();
+   const bool single_launch = polled && allow_single_launch && c->fused_ok && mm::fused_applies(g);
+   const bool bucketed = polled && !single_launch && buckets_enabled();
+   if (bucketed) {
+      const int rc = ensure_buckets(c, w, st);
+      if (rc != MMH_OK) {
+         return rc;
+      }
+   }
+   w.bucketed = false;
+   const mm::ResolveBuffers rb = resolve_buffers(w);
 
    w.h_result[6] = 0;                          // mm_rank_scatter publishes "matches + 1" here
    w.result_turn ^= 1;                         // the other device-side copy may still be feeding a gather ...
@@ -469,10 +522,10 @@ int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev,
    w.ctrl_clean = false;
    w.fused = false;
    w.polled = false;
-   if (allow_polled && !sequential && !skip_bits && fused_enabled()) {
+   if (polled) {
       // the scan's end is announced in pinned memory (finish_pipeline polls): either everything in one
       // launch (small ROMs), or the streaming kernel + ONE tail kernel
-      if (allow_single_launch && c->fused_ok && mm::fused_applies(g) && g_fused_lock.try_lock()) {
+      if (single_launch && g_fused_lock.try_lock()) {
          w.seq++;
          if (mm::launch_fused(st, g, pl, fc, rb, base_offset, max_candidates, w.h_result, w.d_result[w.result_turn], kMaxRankSort,
                               w.seq, ev[0], ev[2])) {
@@ -488,9 +541,23 @@ int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev,
          c->fused_ok = false;                   // the occupancy query failed: never try again
       }
       w.seq++;
-      mm::launch_filter(st, g, pl, fc, w.d_cand, w.d_ctrl, w.cand_cap, ev[0], ev[1], nullptr, nullptr);
-      mm::launch_tail(st, g, pl, fc, rb, base_offset, max_candidates, w.h_result, w.d_result[w.result_turn], kMaxRankSort, w.seq,
-                      ev[2]);
+      if (bucketed) {
+         // big ROMs: candidates into buckets of their ROM neighbourhood, mm_scan_tail2 behind (mm_tail2.h).  tail_st:
+         // the tail kernel goes to a stream of its own, behind the streaming kernel's end event (scans in flight)
+         w.buckets_clean = false;                 // (until the tail kernel has been seen to finish: it zeroes the counters)
+         w.bucketed = true;
+         mm::launch_filter_buckets(st, g, pl, fc, rb, ev[0], ev[1]);
+         if (tail_st && tail_st != st) {
+            HIP_TRY(hipStreamWaitEvent(tail_st, ev[1], 0));
+         }
+         mm::launch_tail2(tail_st ? tail_st : st, g, pl, fc, rb, base_offset, max_candidates, w.h_result, w.d_result[w.result_turn], w.seq,
+                          ev[2], tail_blocks);
+      }
+      else {
+         mm::launch_filter(st, g, pl, fc, w.d_cand, w.d_ctrl, w.cand_cap, ev[0], ev[1], nullptr, nullptr);
+         mm::launch_tail(st, g, pl, fc, rb, base_offset, max_candidates, w.h_result, w.d_result[w.result_turn], kMaxRankSort, w.seq,
+                         ev[2]);
+      }
       HIP_TRY(hipGetLastError());
       w.polled = true;
       return MMH_OK;
@@ -594,9 +661,21 @@ int finish_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev, 
          // correct results come from the plain kernels below; do not try again on this context
          c->fused_ok = false;
       }
+      const bool was_bucketed = w.bucketed;
+      w.bucketed = false;
+      if (was_bucketed) {
+         w.buckets_clean = true;                  // mm_scan_tail2's last workgroup zeroed the bucket counters before it raised the flag
+      }
       if (flags & 1) {
          // one slot per candidate, in offset order; ~0 = a candidate the reference does not report
          oc->candidates = w.h_result[0];
+         if ((flags & 4) && (w.h_result[5] & 0xFFFFFFFFu) == 0 && oc->candidates != 0) {
+            // a long list: the slots were only written to the device-side copy of the block (a PCIe write per slot
+            // would take longer than the scan): one copy brings them over
+            HIP_TRY(hipMemcpyAsync(w.h_result + kHeaderWords, w.d_result[w.result_turn] + kHeaderWords, oc->candidates * sizeof(uint64_t),
+                                   hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+         }
          oc->listed = oc->candidates;
          oc->tiles = w.h_result[2];
          oc->hard = 0;
@@ -618,14 +697,23 @@ int finish_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev, 
          }
          // left-overs: the second phase below orders the slots again with the rank kernels
       }
+      else if (was_bucketed) {
+         // a bucket overflowed (a flood of candidates in one ROM neighbourhood) or there are more candidates than the
+         // published block holds: the list-based kernels, from the start (they take floods apart domain by domain)
+         mm::FilterChoice fc;
+         mm::choose_filter(pl, &fc);
+         w.ctrl_clean = false;
+         const int again = enqueue_pipeline(c, w, st, ev, g, pl, fc, false, base_offset, max_candidates, nullptr, false, false);
+         if (again != MMH_OK) {
+            return again;
+         }
+         HIP_TRY(hipEventSynchronize(ev[2]));
+         read_outcome(w, sequential, oc);
+      }
       else {
          // too many candidates for the in-kernel ranking, or the kernel gave up: the plain
          // kernels take over on the candidate lists it left (control block kept)
-         mm::ResolveBuffers rb;
-         rb.cand = w.d_cand; rb.cand_cap = w.cand_cap; rb.out = w.d_out; rb.out_cap = w.out_cap; rb.ctrl = w.d_ctrl;
-         rb.mid_off = w.d_mid_off; rb.mid_hi = w.d_mid_hi; rb.mid_set = w.d_mid_set; rb.mid_slot = w.d_mid_slot;
-         rb.hard_off = w.d_hard_off; rb.hard_hi = w.d_hard_hi; rb.hard_set = w.d_hard_set; rb.hard_slot = w.d_hard_slot;
-         rb.scratch = w.d_scratch;
+         const mm::ResolveBuffers rb = resolve_buffers(w);
          w.h_result[6] = 0;
          mm::launch_resolve(st, g, pl, rb, base_offset, max_candidates);
          mm::launch_rank_sort(st, w.d_out, w.d_ctrl, 0, w.out_cap, kMaxRankSort, w.d_partials, w.h_result, w.d_result[w.result_turn],
@@ -651,11 +739,7 @@ int finish_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev, 
    if (leftovers > mm::mid_cap() || oc->candidates > w.out_cap || oc->candidates > max_candidates) {
       return MMH_OK;                            // the caller switches engines (hard_overflow / too many candidates)
    }
-   mm::ResolveBuffers rb;
-   rb.cand = w.d_cand; rb.cand_cap = w.cand_cap; rb.out = w.d_out; rb.out_cap = w.out_cap; rb.ctrl = w.d_ctrl;
-   rb.mid_off = w.d_mid_off; rb.mid_hi = w.d_mid_hi; rb.mid_set = w.d_mid_set; rb.mid_slot = w.d_mid_slot;
-   rb.hard_off = w.d_hard_off; rb.hard_hi = w.d_hard_hi; rb.hard_set = w.d_hard_set; rb.hard_slot = w.d_hard_slot;
-   rb.scratch = w.d_scratch;
+   const mm::ResolveBuffers rb = resolve_buffers(w);
    w.h_result[6] = 0;
    mm::launch_leftovers(st, g, pl, rb, base_offset);
    mm::launch_rank_sort(st, w.d_out, w.d_ctrl, 0, w.out_cap, kMaxRankSort, w.d_partials, w.h_result, w.d_result[w.result_turn]);
@@ -852,11 +936,7 @@ int run_flagged_domains(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, ui
    // the candidate lists of the first pass are gone with the control block: run the filter again
    mm::FilterChoice fc;
    mm::choose_filter(pl, &fc);
-   mm::ResolveBuffers rb;
-   rb.cand = w.d_cand; rb.cand_cap = w.cand_cap; rb.out = w.d_out; rb.out_cap = w.out_cap; rb.ctrl = w.d_ctrl;
-   rb.mid_off = w.d_mid_off; rb.mid_hi = w.d_mid_hi; rb.mid_set = w.d_mid_set; rb.mid_slot = w.d_mid_slot;
-   rb.hard_off = w.d_hard_off; rb.hard_hi = w.d_hard_hi; rb.hard_set = w.d_hard_set; rb.hard_slot = w.d_hard_slot;
-   rb.scratch = w.d_scratch;
+   const mm::ResolveBuffers rb = resolve_buffers(w);
    mm::launch_filter(st, g, pl, fc, w.d_cand, w.d_ctrl, w.cand_cap);
    mm::launch_resolve(st, g, pl, rb, base_offset, max_candidates, d_bits);
    HIP_TRY(hipGetLastError());
@@ -990,11 +1070,7 @@ int run_candidate_floods(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, c
    if (oc.hard_overflow) {
       // On top of the flood, more undecidable candidates than the left-over lists take: flag
       // their domains as well (the flag pass of run_flagged_domains, flooded domains masked out).
-      mm::ResolveBuffers rb;
-      rb.cand = w.d_cand; rb.cand_cap = w.cand_cap; rb.out = w.d_out; rb.out_cap = w.out_cap; rb.ctrl = w.d_ctrl;
-      rb.mid_off = w.d_mid_off; rb.mid_hi = w.d_mid_hi; rb.mid_set = w.d_mid_set; rb.mid_slot = w.d_mid_slot;
-      rb.hard_off = w.d_hard_off; rb.hard_hi = w.d_hard_hi; rb.hard_set = w.d_hard_set; rb.hard_slot = w.d_hard_slot;
-      rb.scratch = w.d_scratch;
+         const mm::ResolveBuffers rb = resolve_buffers(w);
       // (the second resolver phase may have run and left the control block zeroed: filter again)
       HIP_TRY(hipMemsetAsync(w.d_ctrl, 0, mm::ctrl_bytes(), st));
       mm::launch_filter(st, g, pl, fc, w.d_cand, w.d_ctrl, w.cand_cap, nullptr, nullptr, nullptr, d_bits);
@@ -1107,6 +1183,10 @@ int scan_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int b
       return rc;
    }
    HIP_TRY(hipSetDevice(c->device));
+   rc = mm_ingest_drain(c);
+   if (rc != MMH_OK) {
+      return rc;
+   }
    const MmGeom g = scan_geometry(c, plan, block_bytes, big_endian);
 
    rc = ensure_workspace(c, c->ws[0], std::max<uint64_t>(c->ws[0].out_cap, kInitialCap));

@@ -17,6 +17,7 @@ struct MmIngest {
    std::vector<void *> staging;
    std::vector<hipEvent_t> events;
    std::vector<hipStream_t> streams;
+   bool undrained = false;           // an aborted load left copies in flight on `streams` (mm_ingest_drain)
    double last_seconds = 0;
    uint64_t last_bytes = 0;
    int last_threads = 0;
@@ -40,6 +41,10 @@ struct MmWorkspace {
    uint32_t *d_hard_slot = nullptr;
    uint8_t *d_scratch = nullptr;    // tile maps of hard candidates
    uint32_t *d_partials = nullptr;  // rank sort partial counts
+   uint64_t *d_bcand = nullptr;     // bucketed candidate store (big ROMs; mm_internal.h MM_BUCKET_*), allocated on first use
+   unsigned int *d_bcount = nullptr;   // its bucket and super-bucket counters, left zeroed by mm_scan_tail2
+   bool buckets_clean = false;      // ... unless a scan did not get that far
+   bool bucketed = false;           // the scan under way went through the bucketed store
    uint64_t *h_result = nullptr;    // pinned: [kHeaderWords counters][kMaxRankSort ordered matches], written by the device
    // Device-side copies of that block, written by the same kernel: what the multi-GPU offset
    // gather (mm_multi.hip) sends -- the collective never waits for a host round trip.  Two of
@@ -168,5 +173,7 @@ struct mmh_ctx {
 
 // defined in mm_capi.hip
 int mmh_workspace(mmh_ctx *c);
+// defined in mm_ingest.hip: waits for the copies an aborted mmh_rom_load_file_watched left in flight (no-op otherwise)
+int mm_ingest_drain(mmh_ctx *c);
 
 #endif

@@ -37,6 +37,7 @@
 // header word 4 of the published block
 constexpr unsigned long long MM_HDR_SPARSE = 1;     // the list holds one slot per candidate, ~0 = hole
 constexpr unsigned long long MM_HDR_GAVE_UP = 2;    // a barrier timed out: nothing was resolved
+constexpr unsigned long long MM_HDR_ON_DEVICE = 4;  // the slots were only written to the device-side copy (long lists): the host fetches them
 
 struct MmFusedArgs {
    MmTileArgs t;
@@ -51,6 +52,12 @@ struct MmFusedArgs {
    uint64_t list_cap;
    unsigned int *dom_count;            // always null here
    const uint32_t *skip_bits;          // always null here
+   uint64_t *bcand;                    // bucketed store (mm_tail2.h); null in the single-launch kernel
+   unsigned int *bcount;
+   unsigned int *bsuper;
+   unsigned long long *boverflow;
+   uint32_t bshift;
+   uint32_t nbuckets;
    uint64_t ngroups;
    uint32_t groups_per_span;
    uint64_t edge_first;

@@ -20,6 +20,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -66,6 +68,24 @@ bool ingest_resources(mmh_ctx *c, int threads, std::string *err)
 
 } // namespace
 
+// copies an aborted load left in flight: wait for them before the ROM or the staging buffers are used again
+int mm_ingest_drain(mmh_ctx *c)
+{
+   if (c && c->ingest.undrained) {
+      c->ingest.undrained = false;
+      if (hipSetDevice(c->device) != hipSuccess) {
+         return MMH_E_DEVICE;
+      }
+      for (hipStream_t s : c->ingest.streams) {
+         if (hipStreamSynchronize(s) != hipSuccess) {
+            mmh_set_error("draining an aborted file load failed");
+            return MMH_E_DEVICE;
+         }
+      }
+   }
+   return MMH_OK;
+}
+
 extern "C" int mmh_rom_load_file(mmh_ctx *c, const char *path, uint64_t file_offset, uint64_t nbytes, int threads)
 {
    return mmh_rom_load_file_watched(c, path, file_offset, nbytes, threads, nullptr, nullptr);
@@ -82,7 +102,11 @@ extern "C" int mmh_rom_load_file_watched(mmh_ctx *c, const char *path, uint64_t 
       __atomic_store_n(bytes_done, (uint64_t)0, __ATOMIC_RELAXED);
    }
    const auto t0 = std::chrono::steady_clock::now();
-   int rc = mmh_rom_alloc(c, nbytes);
+   int rc = mm_ingest_drain(c);
+   if (rc != MMH_OK) {
+      return rc;
+   }
+   rc = mmh_rom_alloc(c, nbytes);
    if (rc != MMH_OK) {
       return rc;
    }
@@ -172,7 +196,9 @@ extern "C" int mmh_rom_load_file_watched(mmh_ctx *c, const char *path, uint64_t 
             __atomic_fetch_add(bytes_done, len, __ATOMIC_RELAXED);
          }
       }
-      if (hipStreamSynchronize(in.streams[t]) != hipSuccess) {
+      // An aborted load does not wait for the copies it has queued (up to two pieces per reader): the caller wants
+      // its thread back now.  They are drained before the staging buffers or the ROM are touched again (mm_ingest_drain).
+      if (!aborted && hipStreamSynchronize(in.streams[t]) != hipSuccess) {
          give_up("hipStreamSynchronize failed in a reader thread");
       }
       close(fd);
@@ -188,6 +214,13 @@ extern "C" int mmh_rom_load_file_watched(mmh_ctx *c, const char *path, uint64_t 
    in.last_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
    in.last_bytes = nbytes;
    in.last_threads = threads;
+   if (aborted) {
+      in.undrained = true;
+      static const bool trace = getenv("MMOORE_INGEST_TRACE") != nullptr;
+      if (trace) {
+         fprintf(stderr, "mmh_rom_load_file: aborted after %.2f ms, %d readers joined\n", in.last_seconds * 1e3, threads);
+      }
+   }
    if (aborted && !failed) {
       mmh_set_error("mmh_rom_load_file: aborted by the caller");
       return MMH_E_ABORTED;

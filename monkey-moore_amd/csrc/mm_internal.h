@@ -46,11 +46,31 @@ constexpr uint32_t MM_RESOLVER_MAX_KEYWORD = 32;
 // mapped, [3] hard candidates / overflow flag, [5] left-overs, [6] matches + 1 (0: not ordered on the
 // device), [7] which of words 0 / 1 is the list length.
 constexpr uint64_t MM_RESULT_HEADER_WORDS = 8;
-constexpr uint32_t MM_MAX_RANK_SORT = 16384;      // longest list the device orders (and a gather record holds)
-// the pinned block has a few more words behind the slots: the fused scan kernel raises the scan's
+constexpr uint32_t MM_MAX_RANK_SORT = 16384;      // longest list the rank kernels / the single-launch kernel order (and a gather record holds)
+// slots the published block holds: the tail kernel behind the bucketed filter (mm_tail2.h) ranks a candidate with
+// two loads whatever their number, so it orders far longer lists than the count-the-smaller-ones kernels above
+constexpr uint32_t MM_MAX_PUBLISH = 131072;
+// ... up to this many candidates every slot is also stored straight into pinned host memory (one PCIe write each: the
+// host has the list the moment the flag word changes); beyond, the slots only exist in the device-side copy and the
+// host fetches them with one DMA copy (a hundred thousand 8-byte PCIe writes would take longer than the scan)
+constexpr uint32_t MM_DIRECT_PUBLISH = 8192;
+// the pinned block has a few more words behind the slots: the scan's last kernel raises the scan's
 // sequence number in the first of them when everything is published (the host polls it)
-constexpr uint64_t MM_HDR_FLAG_WORD = MM_RESULT_HEADER_WORDS + MM_MAX_RANK_SORT;
+constexpr uint64_t MM_HDR_FLAG_WORD = MM_RESULT_HEADER_WORDS + MM_MAX_PUBLISH;
 constexpr uint64_t MM_RESULT_BLOCK_WORDS = MM_HDR_FLAG_WORD + 8;
+
+// ---- bucketed candidate store (big ROMs: streaming kernel + mm_scan_tail2) ---------------------------------------
+// The ROM is cut into nb <= MM_MAX_BUCKETS buckets of 2^shift bytes (>= 4 KiB, so a wave's 1 KiB piece lies in one
+// bucket); the streaming kernel appends a candidate to the bucket its anchor chunk lies in (one returning atomic per
+// wave and piece on that bucket's counter, one non-returning one on the counter of its super-bucket of MM_SUPER
+// buckets).  Buckets are in offset order, so a candidate's place in the ascending list is
+//     candidates in the buckets before its own  +  members of its own bucket with a smaller offset
+// -- a scan over <= 256 super counters (once per workgroup), one over the 64 counters of its super-bucket and a ballot
+// over its bucket's members, instead of comparing it with every other candidate.
+constexpr uint32_t MM_BUCKET_CAP = 256;           // candidates a bucket holds (more: the scan takes the list-based path)
+constexpr uint32_t MM_MAX_BUCKETS = 16384;
+constexpr uint32_t MM_SUPER = 64;                 // buckets per super-bucket
+constexpr uint32_t MM_MIN_BUCKET_SHIFT = 12;
 
 // ---- per-scan control block (device memory, zeroed before every scan), in u64 words --
 //
@@ -65,6 +85,7 @@ enum {
    MM_CTRL_HARD = 3,         // lo 32: hard candidates, hi 32: "prefix too long" flag
    MM_CTRL_TICKET = 4,       // arrival ticket of mm_rank_scatter's blocks (the last one re-zeroes the block)
    MM_CTRL_NOMATCH = 6,      // keys of the ordered list that are "not a match" slots (counted by mm_rank_scatter's blocks)
+   MM_CTRL_BOVERFLOW = 7,    // bucketed store: appends that found their bucket full (non-zero: nothing is resolved from the buckets)
    MM_CTRL_DECISION = 25,    // mm_scan_fused: outcome of its grid barrier (1 everybody arrived, 2 timed out: nothing is resolved)
    MM_CTRL_T_START = 26,     //   ... wall clock at the kernel's start / when the last workgroup left the streaming phase
    MM_CTRL_T_BARRIER = 27,

@@ -14,7 +14,8 @@ struct Tuning {
    uint64_t filter_blocks;           // MMOORE_FILTER_BLOCKS    (1536 workgroups: 6 of the 8 workgroup slots of a CU)
    uint32_t filter_groups_per_span;  // MMOORE_FILTER_GPS       (7 groups of 4 KiB)
    unsigned resolve_blocks;          // MMOORE_RESOLVE_BLOCKS   (4096 workgroups)
-   unsigned tail_blocks;             // MMOORE_TAIL_BLOCKS      (2048 workgroups of mm_scan_tail)
+   unsigned tail_blocks;             // MMOORE_TAIL_BLOCKS      (2048 workgroups of mm_scan_tail / mm_scan_tail2)
+   unsigned lane_tail_blocks;        // MMOORE_LANE_TAIL_BLOCKS (workgroups of mm_scan_tail2 behind a scan of the submit lanes)
    uint32_t max_candidates;          // MMOORE_MAX_CANDIDATES   (262144 per scan)
 };
 const Tuning &tuning();
@@ -59,7 +60,17 @@ struct ResolveBuffers {
    uint32_t *hard_set;
    uint32_t *hard_slot;
    uint8_t *scratch;
+   // bucketed candidate store (mm_internal.h MM_BUCKET_*), zeroed by mm_scan_tail2's last workgroup
+   uint64_t *bcand = nullptr;       // [MM_MAX_BUCKETS][MM_BUCKET_CAP]
+   unsigned int *bcount = nullptr;  // [MM_MAX_BUCKETS] then [MM_MAX_BUCKETS / MM_SUPER] super-bucket counters
 };
+// geometry of the bucketed store for a ROM: 2^shift-byte buckets, nb of them
+struct BucketGeom {
+   uint32_t shift, nb;
+};
+BucketGeom bucket_geom(uint64_t nbytes);
+size_t bucket_cand_bytes();
+size_t bucket_count_bytes();
 
 // flag_bits != nullptr: the flag pass -- mm_resolve alone, setting the bit of every domain that
 // holds a candidate its two windows cannot settle (one bit per domain, zeroed by the caller)
@@ -73,6 +84,13 @@ bool launch_fused(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, cons
                   uint64_t seq, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 // does the single-launch kernel suit this ROM (small enough) and this device?
 bool fused_applies(const MmGeom &g);
+// Big ROMs: the streaming kernel filling the bucketed store of rb, and mm_scan_tail2 (mm_tail2.h) behind it: results,
+// header and `seq` as launch_fused; tail_blocks = 0: the default grid (one wave per candidate for up to 8 K of them)
+void launch_filter_buckets(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc, const ResolveBuffers &rb,
+                           hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+void launch_tail2(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc, const ResolveBuffers &rb,
+                  uint64_t base_offset, uint32_t max_candidates, uint64_t *host_result, uint64_t *dev_result, uint64_t seq,
+                  hipEvent_t stop = nullptr, unsigned tail_blocks = 0);
 // the same tail as a kernel of its own behind launch_filter (mm_scan_tail): results, header and `seq` as launch_fused
 void launch_tail(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc, const ResolveBuffers &rb,
                  uint64_t base_offset, uint32_t max_candidates, uint64_t *host_result, uint64_t *dev_result, uint32_t max_rank,

@@ -244,6 +244,12 @@ struct MmFilterArgs {
    // candidate floods (engine mode, see run_candidate_floods in mm_capi.hip); both null in a normal scan
    unsigned int *dom_count;          // count pass: candidates per domain instead of the lists
    const uint32_t *skip_bits;        // filtered pass: candidates of flagged domains are dropped
+   // bucketed store (mm_internal.h MM_BUCKET_*; null: the lists above): big ROMs, read by mm_scan_tail2
+   uint64_t *bcand;                  // [nb][MM_BUCKET_CAP] candidate byte offsets
+   unsigned int *bcount;             // [nb] members of every bucket
+   unsigned int *bsuper;             // [nb / MM_SUPER] members of every super-bucket
+   unsigned long long *boverflow;    // appends that found their bucket full
+   uint32_t bshift;                  // log2 of a bucket's width in bytes
 
    uint64_t ngroups;       // span kernel: number of whole 4 KiB groups it covers
    uint32_t groups_per_span;
@@ -311,6 +317,38 @@ __device__ __forceinline__ uint64_t *mm_cand_reserve(const A &a, uint32_t cnt, u
    *first = incl - cnt;
    *room = b >= a.list_cap ? 0u : (uint32_t)((a.list_cap - b) > 0xFFFFFFFFull ? 0xFFFFFFFFull : (a.list_cap - b));
    return a.cand + (uint64_t)c * a.list_cap + b;
+}
+
+// Bucketed store: all survivors of the wave's piece (1 KiB, aligned, starting at byte piece0: one bucket) at once.
+// Every lane brings `cnt` candidates; returns (wave uniform) the address of the wave's first reserved slot,
+// *first = this lane's first slot relative to it, *room = how many of the wave's slots exist (bucket capacity).
+template <class A>
+__device__ __forceinline__ uint64_t *mm_bucket_reserve(const A &a, uint64_t piece0, uint32_t cnt, uint32_t *first, uint32_t *room)
+{
+   uint32_t incl = cnt;
+#pragma unroll
+   for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t v = (uint32_t)__shfl_up((int)incl, d);
+      incl += (int)__lane_id() >= d ? v : 0u;
+   }
+   const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+   *first = incl - cnt;
+   *room = 0;
+   if (total == 0) {
+      return a.bcand;
+   }
+   const uint64_t b = piece0 >> a.bshift;
+   unsigned int base = 0;
+   if (__lane_id() == 0) {
+      base = atomicAdd(a.bcount + b, total);
+      atomicAdd(a.bsuper + (b / MM_SUPER), total);           // (result unused: a fire-and-forget atomic)
+      if (base + total > MM_BUCKET_CAP) {
+         atomicAdd(a.boverflow, 1ull);
+      }
+   }
+   base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+   *room = base >= MM_BUCKET_CAP ? 0u : MM_BUCKET_CAP - base;
+   return a.bcand + b * MM_BUCKET_CAP + base;
 }
 
 __device__ __forceinline__ uint4 mm_load_chunk(const uint8_t *rom, uint64_t nbytes, uint64_t byte0)
@@ -413,6 +451,32 @@ template <class A>
 __device__ __forceinline__ void mm_f8_survivors(const A &a, uint64_t chunk0, uint32_t bits)
 {
    const bool head = __ballot(bits != 0 && chunk0 < MMH_MAX_KEYWORD) != 0;   // a survivor may lie in front of the anchor
+   if (a.bcount) {
+      // bucketed store: what must be checked per survivor (in front of the ROM / the compare loop) first, lane by
+      // lane, then everything that is left in one go
+      if (a.verify || head) {
+         uint32_t keep = 0;
+         for (uint32_t todo = bits; todo; todo &= todo - 1) {
+            const int bit = __ffs((int)todo) - 1;
+            const int64_t o = (int64_t)(chunk0 + 4 * (bit & 3) + (bit >> 3)) - (int64_t)a.iA;
+            if (a.verify ? mm_is_candidate(a.t.g, a.t.plan, o) : (o >= 0)) {
+               keep |= 1u << bit;
+            }
+         }
+         bits = keep;
+      }
+      uint32_t slot, room;
+      uint64_t *list = mm_bucket_reserve(a, mm_uniform64_k(chunk0), (uint32_t)__popc(bits), &slot, &room);
+      while (bits) {
+         const int bit = __ffs((int)bits) - 1;
+         bits &= bits - 1;
+         if (slot < room) {
+            mm_store_shared(list + slot, chunk0 + 4 * (bit & 3) + (bit >> 3) - a.iA);
+         }
+         slot++;
+      }
+      return;
+   }
    bool batch = !a.verify && !a.dom_count && !a.skip_bits && !head;
    if (!a.verify && !head && !batch && !a.t.g.whole) {
       // Flood handling passes, 8-bit: a piece lies in ONE block (= domain) nearly always.  Then
@@ -700,6 +764,36 @@ __device__ __forceinline__ uint32_t mm_f16_pack(const uint32_t (&he)[4], const u
 template <class A>
 __device__ __forceinline__ void mm_f16_survivors(const A &a, uint64_t chunk0, uint32_t bits)
 {
+   if (a.bcount) {
+      // bucketed store (see mm_f8_survivors).  The odd stream's first position of a chunk starts one byte in front of it,
+      // but no candidate of chunk c lies behind one of chunk c + 1: buckets (whole pieces) stay in offset order.
+      auto offset_of = [&](int bit) {
+         const int j = bit >> 2, odd = (bit >> 1) & 1, half = bit & 1;
+         return (int64_t)(chunk0 + 4 * j + 2 * half) - odd - 2 * (int64_t)a.iA;
+      };
+      if (a.verify || __ballot(bits != 0 && chunk0 < 2 * MMH_MAX_KEYWORD + 2) != 0) {
+         uint32_t keep = 0;
+         for (uint32_t todo = bits; todo; todo &= todo - 1) {
+            const int bit = __ffs((int)todo) - 1;
+            const int64_t o = offset_of(bit);
+            if (a.verify ? mm_is_candidate(a.t.g, a.t.plan, o) : (o >= 0)) {
+               keep |= 1u << bit;
+            }
+         }
+         bits = keep;
+      }
+      uint32_t slot, room;
+      uint64_t *list = mm_bucket_reserve(a, mm_uniform64_k(chunk0), (uint32_t)__popc(bits), &slot, &room);
+      while (bits) {
+         const int bit = __ffs((int)bits) - 1;
+         bits &= bits - 1;
+         if (slot < room) {
+            mm_store_shared(list + slot, (uint64_t)offset_of(bit));
+         }
+         slot++;
+      }
+      return;
+   }
    if (!a.verify && !a.dom_count && !a.skip_bits && __ballot(bits != 0 && chunk0 < 2 * MMH_MAX_KEYWORD + 2) == 0) {
       uint32_t slot, room;
       uint64_t *list = mm_cand_reserve(a, (uint32_t)__popc(bits), &slot, &room);
@@ -857,7 +951,7 @@ __global__ __launch_bounds__(256) void mm_filter_u8(MmFilterArgs a)
 }
 
 template <int SHAPE>
-__global__ __launch_bounds__(256) void mm_filter_u16(MmFilterArgs a)
+__global__ __launch_bounds__(256, 7) void mm_filter_u16(MmFilterArgs a)
 {
    mm_stream_u16<SHAPE>(a);
 }
@@ -865,6 +959,7 @@ __global__ __launch_bounds__(256) void mm_filter_u16(MmFilterArgs a)
 #include "mm_tiles.h"
 #include "mm_forward.h"
 #include "mm_fused.h"
+#include "mm_tail2.h"
 
 // --------------------------------------------------------------------------
 // sequential engine: one lane per domain, exact by construction
@@ -1135,6 +1230,7 @@ const Tuning &tuning()
       k.resolve_blocks = (unsigned)number("MMOORE_RESOLVE_BLOCKS", 4096);
       // (mm_arrive_last counts arrivals in MM_ARRIVE_LINES - 1 groups of MM_ARRIVE_FAN: more workgroups would spill into the next lines)
       k.tail_blocks = (unsigned)std::min<long>(number("MMOORE_TAIL_BLOCKS", 2048), (long)MM_ARRIVE_FAN * (MM_ARRIVE_LINES - 1));
+      k.lane_tail_blocks = (unsigned)std::min<long>(number("MMOORE_LANE_TAIL_BLOCKS", 2048), (long)MM_ARRIVE_FAN * (MM_ARRIVE_LINES - 1));
       k.max_candidates = (uint32_t)number("MMOORE_MAX_CANDIDATES", 262144);
       return k;
    }();
@@ -1356,6 +1452,7 @@ static void fill_filter_args(A &a, const MmGeom &g, const mmh_plan_desc &pl, con
    }
    a.cand = cand; a.list_count = ctrl + MM_CTRL_LISTS; a.list_cap = cand_cap / MM_CAND_LISTS;
    a.dom_count = nullptr; a.skip_bits = nullptr;
+   a.bcand = nullptr; a.bcount = nullptr; a.bsuper = nullptr; a.boverflow = nullptr; a.bshift = 0;
    // whole 4 KiB groups go to the span code, the ragged end to the bounds-checked one
    a.ngroups = g.nbytes / 4096;
    a.groups_per_span = groups_per_span;
@@ -1473,6 +1570,63 @@ void launch_tail(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const
    // one wave per candidate for up to 8 K of them in one round (the count is only known on the device)
    // (5 waves per SIMD measured best: 6 and 8 spill and run 4-15 us longer; 1280 .. 4096 workgroups: no difference)
    launch_timed(mm_scan_tail<5>, dim3(tuning().tail_blocks), dim3(64 * MM_WAVES), st, nullptr, stop, a);
+}
+
+// ---- big ROMs: bucketed candidate store + mm_scan_tail2 (mm_tail2.h) ----------------------------------------------
+
+BucketGeom bucket_geom(uint64_t nbytes)
+{
+   BucketGeom b;
+   b.shift = MM_MIN_BUCKET_SHIFT;
+   while (((nbytes + 15) >> b.shift) >= MM_MAX_BUCKETS) {      // (+ 15: survivors in the padding of the last 16-byte chunk)
+      b.shift++;
+   }
+   b.nb = (uint32_t)(((nbytes + 15) >> b.shift) + 1);
+   return b;
+}
+size_t bucket_cand_bytes() { return (size_t)MM_MAX_BUCKETS * MM_BUCKET_CAP * sizeof(uint64_t); }
+size_t bucket_count_bytes() { return (size_t)(MM_MAX_BUCKETS + MM_MAX_BUCKETS / MM_SUPER) * sizeof(unsigned int); }
+
+template <class A>
+static void fill_bucket_args(A &a, const MmGeom &g, const ResolveBuffers &rb)
+{
+   const BucketGeom b = bucket_geom(g.nbytes);
+   a.bcand = rb.bcand; a.bcount = rb.bcount; a.bsuper = rb.bcount + MM_MAX_BUCKETS;
+   a.boverflow = rb.ctrl + MM_CTRL_BOVERFLOW; a.bshift = b.shift;
+}
+
+void launch_filter_buckets(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc, const ResolveBuffers &rb,
+                           hipEvent_t start, hipEvent_t stop)
+{
+   MmFilterArgs a;
+   uint32_t gps = filter_groups_per_span();
+   while (gps > 1 && (g.nbytes / 4096) / gps < (uint64_t)MM_CAND_LISTS * MM_WAVES) {
+      gps >>= 1;
+   }
+   fill_filter_args(a, g, pl, fc, rb.cand, rb.ctrl, rb.cand_cap, gps);
+   fill_bucket_args(a, g, rb);
+   with_shape(pl.elem_bytes, fc, [&](auto elem, auto shape) {
+      constexpr int SHAPE = decltype(shape)::value;
+      if constexpr (decltype(elem)::value == 1) {
+         launch_filter_pair(mm_filter_u8<SHAPE>, mm_filter_u8_edge<SHAPE>, st, a, g, start, stop);
+      }
+      else {
+         launch_filter_pair(mm_filter_u16<SHAPE>, mm_filter_u16_edge<SHAPE>, st, a, g, start, stop);
+      }
+   });
+}
+
+void launch_tail2(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc, const ResolveBuffers &rb,
+                  uint64_t base_offset, uint32_t max_candidates, uint64_t *host_result, uint64_t *dev_result, uint64_t seq,
+                  hipEvent_t stop, unsigned tail_blocks)
+{
+   MmFusedArgs a;
+   fill_filter_args(a, g, pl, fc, rb.cand, rb.ctrl, rb.cand_cap, filter_groups_per_span());
+   fill_tail_args(a, rb, base_offset, max_candidates, host_result, dev_result, MM_MAX_PUBLISH, seq);
+   fill_bucket_args(a, g, rb);
+   a.nbuckets = bucket_geom(g.nbytes).nb;
+   a.has_edge = 0;
+   launch_timed(mm_scan_tail2<6>, dim3(tail_blocks ? tail_blocks : tuning().tail_blocks), dim3(64 * MM_WAVES), st, nullptr, stop, a);
 }
 
 static MmTileArgs tile_args(const MmGeom &g, const mmh_plan_desc &pl)

@@ -104,8 +104,11 @@ __global__ void mm_gather_stamp(uint64_t *rec, uint64_t count)
 // rank r behind the lists of the ranks before it -- one ascending list in pinned host memory --
 // and block 0 writes the header: [0] total, [1] longest list, [2] nranks, [3] 1 when some list is
 // longer than a record (then nothing is copied: the second phase follows), [8 + r] count of rank r.
+// limit: the longest list (or, for a list with holes, slot count) a record of this table can hold -- MM_MAX_RANK_SORT for
+// the records an all-gather delivered; anything longer only exists in full in its rank's own published block
+// (up to MM_MAX_PUBLISH slots), which the second phase packs with limit = MM_MAX_PUBLISH.
 __global__ __launch_bounds__(256) void mm_gather_pack(const uint64_t *table, uint32_t nranks, uint64_t words, uint64_t *merged,
-                                                      uint64_t merged_cap, uint32_t want_list)
+                                                      uint64_t merged_cap, uint32_t want_list, uint32_t limit)
 {
    __shared__ unsigned long long sh_before, sh_total, sh_longest;
    const uint32_t r = blockIdx.x;
@@ -114,9 +117,12 @@ __global__ __launch_bounds__(256) void mm_gather_pack(const uint64_t *table, uin
       for (uint32_t q = 0; q < nranks; q++) {
          const unsigned long long w6 = table[(uint64_t)q * words + 6];
          const unsigned long long n = w6 ? w6 - 1 : 0;
+         // what the record would have to hold: the list, or one slot per candidate when it has holes
+         const unsigned long long slots_q = (table[(uint64_t)q * words + 4] & 1) ? table[(uint64_t)q * words] : 0;
+         const unsigned long long extent = slots_q > n ? slots_q : n;
          before += q < r ? n : 0;
          total += n;
-         longest = n > longest ? n : longest;
+         longest = extent > longest ? extent : longest;
          if (r == 0) {
             merged[8 + q] = n;
          }
@@ -124,11 +130,11 @@ __global__ __launch_bounds__(256) void mm_gather_pack(const uint64_t *table, uin
       sh_before = before; sh_total = total; sh_longest = longest;
       if (r == 0) {
          merged[0] = total; merged[1] = longest; merged[2] = nranks;
-         merged[3] = longest > MM_MAX_RANK_SORT ? 1 : 0;
+         merged[3] = longest > limit ? 1 : 0;
       }
    }
    __syncthreads();
-   if (!want_list || sh_longest > MM_MAX_RANK_SORT || sh_total > merged_cap) {
+   if (!want_list || sh_longest > limit || sh_total > merged_cap) {
       return;
    }
    const uint64_t *rec = table + (uint64_t)r * words;
@@ -430,7 +436,7 @@ int gather_pack(mmh_ctx *c, int want_list)
    HIP_TRY(hipSetDevice(c->device));
    const double t0 = now_s();
    hipLaunchKernelGGL(mm_gather_pack, dim3((unsigned)m.nranks), dim3(256), 0, m.stream, s.d_table, (uint32_t)m.nranks, kRecordWords,
-                      s.h_merged, s.merged_cap, want_list ? 1u : 0u);
+                      s.h_merged, s.merged_cap, want_list ? 1u : 0u, (uint32_t)MM_MAX_RANK_SORT);
    HIP_TRY(hipGetLastError());
    HIP_TRY(hipEventRecord(s.end, m.stream));
    s.busy = true;
@@ -471,10 +477,11 @@ int long_prepare(mmh_ctx *c, MmGatherSlot &s, uint64_t longest)
                                 m.stream));
       }
       else {
-         // its record in the table is intact whatever the scans did since; it may have holes (one slot per
-         // candidate): the packing kernel on that one record leaves the list behind a header nobody reads
-         hipLaunchKernelGGL(mm_gather_pack, dim3(1), dim3(256), 0, m.stream, s.d_table + (uint64_t)m.rank * kRecordWords, 1u, kRecordWords,
-                            m.d_long, longest, 1u);
+         // the scan's published block in HBM (nothing overwrites it while the gather is outstanding: enqueue_pipeline
+         // waits for gathers that read the copy it is about to publish into); it may have holes (one slot per
+         // candidate): the packing kernel on that one block leaves the list behind a header nobody reads
+         hipLaunchKernelGGL(mm_gather_pack, dim3(1), dim3(256), 0, m.stream, s.src, 1u, (uint64_t)MM_RESULT_BLOCK_WORDS,
+                            m.d_long, longest, 1u, (uint32_t)MM_MAX_PUBLISH);
          HIP_TRY(hipGetLastError());
       }
    }
@@ -684,7 +691,7 @@ extern "C" int mmh_selftest_gather_pack(mmh_ctx *c, const uint64_t *records, int
    }
    if (rc == MMH_OK) {
       hipLaunchKernelGGL(mm_gather_pack, dim3((unsigned)nranks), dim3(256), 0, c->stream, d_table, (uint32_t)nranks, kRecordWords, h_merged,
-                         merged_cap, 1u);
+                         merged_cap, 1u, (uint32_t)MM_MAX_RANK_SORT);
       if (!hip_ok(hipGetLastError(), "mm_gather_pack") || !hip_ok(hipStreamSynchronize(c->stream), "hipStreamSynchronize")) {
          rc = MMH_E_DEVICE;
       }

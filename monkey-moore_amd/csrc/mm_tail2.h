@@ -1,0 +1,229 @@
+// SPDX-License-Identifier: GPL-3.0-or-later
+// mm_tail2.h -- the tail of a big-ROM scan over the BUCKETED candidate store (mm_internal.h MM_BUCKET_*).
+// Included by mm_kernels.hip after mm_fused.h (device code only).
+//
+// mm_scan_tail (mm_fused.h) ranks a candidate by comparing it with every other candidate: each workgroup reads the
+// whole candidate set once per round -- 34 KiB at the bench ROM's 4 K candidates, fine; 512 KiB per workgroup and
+// round at 64 K, where the ordering had to be left to a radix sort behind the scan and the scan fell below 0.6 of the
+// HBM roofline (profiles/r03_candidate_density.log, "before").  Here the streaming kernel has already dropped every
+// candidate into the bucket of its ROM neighbourhood, buckets are in offset order, and a wave needs three loads to
+// know a candidate and its place in the ascending list, whatever the number of candidates:
+//     the 64 member counts of the candidate's super-bucket   -> which bucket, which slot, candidates in front of the bucket
+//     the bucket's members (one per lane, <= 4 rounds)       -> the candidate itself and how many members are smaller
+// (the candidates in front of the super-bucket come from <= 256 super counters, scanned once per workgroup).
+// No workgroup-wide step is left inside the candidate loop: waves run on their own, with 20 .. 40 registers fewer
+// than mm_scan_tail -- the kernel fits beside the streaming kernel of the NEXT scan (scans in flight).
+//
+// Everything else is mm_scan_tail's: the reference's compare loop + chain membership through the two look-back windows
+// (mm_resolve_candidate), the verdict stored in slot `rank` of the published block, left-overs handed to the second
+// phase, the last workgroup writes the header, zeroes the control block and the bucket counters and raises the flag.
+// Lists of more than MM_DIRECT_PUBLISH slots are only written to the device-side copy of the block (header word 4,
+// MM_HDR_ON_DEVICE): the host fetches them with one copy.  A bucket that overflowed (MM_BUCKET_CAP members: a flood),
+// or more candidates than the block holds: nothing is resolved, header word 4 carries no MM_HDR_SPARSE and the host
+// runs the list-based path.
+#ifndef MM_TAIL2_H
+#define MM_TAIL2_H
+
+struct MmTail2Lds {
+   unsigned int super_excl[MM_MAX_BUCKETS / MM_SUPER + 1];   // candidates in front of every super-bucket; [nsuper] = all
+   unsigned int holes, walked;
+   int last_block;
+};
+
+template <int OCC>
+__global__ __launch_bounds__(64 * MM_WAVES, OCC) void mm_scan_tail2(MmFusedArgs a)
+{
+   __shared__ MmPlanLds P;
+   __shared__ MmWaveLdsShort Wv[MM_WAVES];
+   __shared__ MmTail2Lds T;
+   const int wave = (int)mm_uniform(threadIdx.x >> 6);
+   const int lane = threadIdx.x & 63;
+   const uint32_t nsuper = (a.nbuckets + MM_SUPER - 1) / MM_SUPER;        // <= 256
+
+   // ---- candidates in front of every super-bucket (wave 0; the plan goes to LDS meanwhile) --------------------------
+   if (threadIdx.x < 64) {
+      unsigned int carry = 0;
+      for (uint32_t s0 = 0; s0 < nsuper; s0 += 64) {
+         const uint32_t s = s0 + (uint32_t)lane;
+         const unsigned int n = s < nsuper ? a.bsuper[s] : 0u;
+         unsigned int incl = n;
+#pragma unroll
+         for (int d = 1; d < 64; d <<= 1) {
+            const unsigned int up = (unsigned int)__shfl_up((int)incl, d);
+            incl += lane >= d ? up : 0u;
+         }
+         if (s < nsuper) {
+            T.super_excl[s] = carry + incl - n;
+         }
+         carry += (unsigned int)__builtin_amdgcn_readlane((int)incl, 63);
+      }
+      if (lane == 0) {
+         T.super_excl[nsuper] = carry;
+         T.holes = 0;
+         T.walked = 0;
+      }
+   }
+   mm_plan_to_lds(P, a.t.plan);                                           // ends with a __syncthreads()
+   const uint64_t ncand = T.super_excl[nsuper];
+   const bool overflow = __hip_atomic_load(a.boverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+   const bool resolvable = !overflow && ncand <= a.out_cap && ncand <= a.max_candidates && ncand <= a.max_rank;
+   const bool direct = ncand <= MM_DIRECT_PUBLISH;                        // slots go to pinned host memory as well
+   unsigned long long walked = 0;
+   unsigned int holes = 0;
+   if (resolvable) {
+      const uint64_t nwaves = (uint64_t)gridDim.x * MM_WAVES;
+      for (uint64_t ci = (uint64_t)blockIdx.x * MM_WAVES + wave; ci < ncand; ci += nwaves) {
+         // which super-bucket: the last one whose first candidate is <= ci (lane l looks at entries l, l + 64, ...)
+         uint32_t s = 0;
+         for (uint32_t s0 = 0; s0 < nsuper; s0 += 64) {
+            const uint32_t k = s0 + (uint32_t)lane;
+            const unsigned long long le = __ballot(k < nsuper && T.super_excl[k] <= ci);
+            s = le ? s0 + 63u - (uint32_t)__builtin_clzll(le) : s;
+            if (le != ~0ull) {
+               break;
+            }
+         }
+         const uint32_t in_super = (uint32_t)(ci - T.super_excl[s]);
+         // which bucket of it: one counter per lane
+         const uint32_t b_lane = s * MM_SUPER + (uint32_t)lane;
+         const unsigned int n_lane = b_lane < a.nbuckets ? a.bcount[b_lane] : 0u;
+         unsigned int incl = n_lane;
+#pragma unroll
+         for (int d = 1; d < 64; d <<= 1) {
+            const unsigned int up = (unsigned int)__shfl_up((int)incl, d);
+            incl += lane >= d ? up : 0u;
+         }
+         const unsigned int excl = incl - n_lane;
+         // (the last non-empty bucket that starts at or in front of the candidate; ci < ncand: there is one)
+         const unsigned long long starts = __ballot(excl <= in_super && n_lane != 0);
+         const int bl = starts ? 63 - __builtin_clzll(starts) : 0;
+         const uint32_t bucket = s * MM_SUPER + (uint32_t)bl;
+         const uint32_t before = (uint32_t)T.super_excl[s] + (uint32_t)__shfl((int)excl, bl);   // candidates in front of the bucket
+         const uint32_t members = (uint32_t)__shfl((int)n_lane, bl);
+         const uint32_t slot = in_super - (uint32_t)__shfl((int)excl, bl);
+         // the bucket's members, one per lane and round: the candidate itself and how many of them lie in front of it
+         const unsigned long long *mem = reinterpret_cast<const unsigned long long *>(a.bcand) + (uint64_t)bucket * MM_BUCKET_CAP;
+         unsigned long long m[MM_BUCKET_CAP / 64];
+#pragma unroll
+         for (int r = 0; r < (int)(MM_BUCKET_CAP / 64); r++) {
+            const uint32_t k = 64u * r + (uint32_t)lane;
+            m[r] = (64u * r < members && k < members) ? mem[k] : ~0ull;
+         }
+         uint64_t o = 0;
+#pragma unroll
+         for (int r = 0; r < (int)(MM_BUCKET_CAP / 64); r++) {
+            if ((slot >> 6) == (uint32_t)r) {
+               o = mm_uniform64(__shfl(m[r], (int)(slot & 63)));
+            }
+         }
+         uint32_t rank = before;
+#pragma unroll
+         for (int r = 0; r < (int)(MM_BUCKET_CAP / 64); r++) {
+            rank += (uint32_t)__popcll(__ballot(m[r] < o));
+         }
+         int64_t hi = 0; uint32_t set = 0; uint64_t dom = 0;
+         const int verdict = mm_resolve_candidate(a, P, Wv[wave], o, lane, &walked, &hi, &set, &dom);
+         if (lane == 0) {
+            const uint64_t value = verdict == 1 ? mm_report_value(a.t.g, o, a.base_offset) : MM_NO_MATCH;
+            a.out[ci] = value;
+            if (direct) {
+               // system-scope store: written through to host memory, complete once this wave's vmcnt drains
+               __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.host_result) + MM_RESULT_HEADER_WORDS + rank,
+                                  (unsigned long long)value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            a.dev_result[MM_RESULT_HEADER_WORDS + rank] = value;
+            holes += verdict != 1 ? 1u : 0u;
+            if (verdict == -1) {
+               mm_resolve_hand_over(a, o, ci, hi, set, dom);
+            }
+         }
+      }
+   }
+   // ---- statistics, header, flag (as mm_scan_tail_phase) ------------------------------------------------------------
+   if (lane == 0) {
+      if (walked) {
+         atomicAdd(&T.walked, (unsigned int)walked);
+      }
+      if (holes) {
+         atomicAdd(&T.holes, holes);
+      }
+   }
+   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's result stores have arrived
+   __syncthreads();
+   if (threadIdx.x == 0) {
+      if (T.walked) {
+         atomicAdd(a.tiles_walked + (blockIdx.x % MM_STAT_STRIPES), (unsigned long long)T.walked);
+      }
+      if (T.holes) {
+         atomicAdd(a.ctrl + MM_CTRL_NOMATCH, (unsigned long long)T.holes);
+      }
+      T.last_block = mm_arrive_last(a.ctrl + MM_CTRL_ARRIVE_END, gridDim.x);
+   }
+   __syncthreads();
+   if (!T.last_block) {
+      return;
+   }
+   if (threadIdx.x < 64) {
+      unsigned long long v = 0;
+      if (lane < 32) {
+         v = __hip_atomic_load(a.ctrl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      unsigned long long tiles = lane >= MM_CTRL_TILES && lane < MM_CTRL_TILES + MM_STAT_STRIPES ? v : 0;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+         tiles += __shfl_xor(tiles, d);
+      }
+      const unsigned long long nomatch = __shfl(v, MM_CTRL_NOMATCH), mid = __shfl(v, MM_CTRL_MID);
+      unsigned long long h = 0;
+      switch (lane) {
+      case 0: h = overflow ? ~0ull : ncand; break;         // candidates = slots (~0: a bucket overflowed)
+      case 2: h = tiles; break;
+      case 4: h = (resolvable ? MM_HDR_SPARSE : 0) | (resolvable && !direct ? MM_HDR_ON_DEVICE : 0); break;
+      case 5: h = mid; break;
+      case 6: h = resolvable ? ncand - nomatch + 1 : 0; break;   // matches + 1 (0: not ordered here)
+      default: break;
+      }
+      if (lane < (int)MM_RESULT_HEADER_WORDS) {
+         a.host_result[lane] = h;
+         a.dev_result[lane] = h;
+      }
+      if (lane == 0) {
+         T.walked = (unsigned int)(mid & 0xFFFFFFFFull);   // (for the decision below)
+      }
+   }
+   __syncthreads();
+   // The control block and the bucket counters go back to zero for the next scan.  Left-overs: the second phase
+   // needs the hand-over counters and MM_CTRL_TOTAL (the rank kernels order a.out[0 .. ncand)); it never looks at
+   // the buckets.  Not resolvable: the host starts over with the list-based kernels (they zero what they need).
+   const bool keep = resolvable && T.walked != 0;
+   if (keep) {
+      if (threadIdx.x == 0) {
+         a.ctrl[MM_CTRL_NOMATCH] = 0;
+         a.ctrl[MM_CTRL_BOVERFLOW] = 0;
+         a.ctrl[MM_CTRL_TOTAL] = ncand;
+      }
+      for (uint32_t k = MM_CTRL_ARRIVE_BARRIER + threadIdx.x; k < MM_CTRL_WORDS; k += blockDim.x) {
+         a.ctrl[k] = 0;
+      }
+   }
+   else {
+      for (uint32_t k = threadIdx.x; k < a.ctrl_words; k += blockDim.x) {
+         a.ctrl[k] = 0;
+      }
+   }
+   for (uint32_t k = threadIdx.x; k < a.nbuckets; k += blockDim.x) {
+      a.bcount[k] = 0;
+   }
+   for (uint32_t k = threadIdx.x; k < nsuper; k += blockDim.x) {
+      a.bsuper[k] = 0;
+   }
+   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+   __syncthreads();
+   if (threadIdx.x == 0) {
+      __threadfence_system();
+      __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.host_result) + MM_HDR_FLAG_WORD, (unsigned long long)a.seq,
+                         __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+   }
+}
+
+#endif
