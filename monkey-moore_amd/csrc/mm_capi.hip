@@ -1400,15 +1400,42 @@ extern "C" int mmh_scan_submit(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t b
    if (rc != MMH_OK) {
       return rc;
    }
-   const int sidx = c->next_ticket % mmh_ctx::kLaneStreams;
-   if (!c->lane_stream[sidx]) {
-      HIP_TRY(hipStreamCreateWithFlags(&c->lane_stream[sidx], hipStreamNonBlocking));
+   // Which streams a lane scan's kernels go to (MMOORE_LANE_MODE, development knob):
+   //   0  two streams, scan t's streaming kernel AND tail kernel on stream t % 2 (round 2's arrangement)
+   //   1  every streaming kernel on stream 0, back to back; the tail kernels on stream 1, each behind its streaming
+   //      kernel's end event: the next scan's streaming kernel never waits for a tail kernel
+   //   2  streaming kernels alternate between streams 0 and 1, tail kernels on stream 2
+   static const int lane_mode = [] { const char *e = getenv("MMOORE_LANE_MODE"); return e && *e ? atoi(e) : 0; }();
+   const int sidx = lane_mode == 1 ? 0 : c->next_ticket % 2;
+   const int tidx = lane_mode == 1 ? 1 : lane_mode == 2 ? 2 : sidx;
+   for (int k : {sidx, tidx}) {
+      if (!c->lane_stream[k]) {
+         HIP_TRY(hipStreamCreateWithFlags(&c->lane_stream[k], hipStreamNonBlocking));
+      }
    }
    const hipStream_t lane_st = c->lane_stream[sidx];
+   const hipStream_t tail_st = c->lane_stream[tidx];
+   c->pending_tail_stream[lane] = tail_st;
    if (!c->lane_fence) {
       HIP_TRY(hipEventCreateWithFlags(&c->lane_fence, hipEventDisableTiming));
    }
+   // Scans in flight share the device best half a streaming kernel apart: the tail kernel of one runs while the other
+   // streams.  From an empty pipeline the first two scans would start together, END together -- both tail kernels then run
+   // with nothing streaming beside them -- and their successors start together again: the pairs only drift apart over
+   // some tens of scans (0.74 ms per 4 GiB scan over the first 20, 0.70 in the steady state).  So the second scan of
+   // a burst is held back by a gate (one sleeping wave in front of its streaming kernel) for MMOORE_LANE_GATE percent
+   // (default 50) of the time a streaming kernel takes: the stagger is there from the start.
+   int others = 0;
+   bool behind_first = false;
+   for (const MmPending &q : c->pending) {
+      if (q.active) {
+         others++;
+         behind_first = behind_first || (q.first_of_burst && !q.needs_rescan && q.ticket + 1 == c->next_ticket);
+      }
+   }
    p = MmPending();
+   p.first_of_burst = others == 0;
+   const bool gated = others == 1 && behind_first;
    p.ticket = c->next_ticket;
    p.plan = *plan;
    p.block_bytes = block_bytes;
@@ -1426,6 +1453,11 @@ extern "C" int mmh_scan_submit(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t b
       // the ROM may still be in the making on the context's stream (upload, synth, poke)
       HIP_TRY(hipEventRecord(c->lane_fence, c->stream));
       HIP_TRY(hipStreamWaitEvent(lane_st, c->lane_fence, 0));
+      static const int gate_percent = [] { const char *e = getenv("MMOORE_LANE_GATE"); return e && *e ? atoi(e) : 50; }();
+      if (gated && gate_percent > 0) {
+         // (a streaming kernel reads ~6 TB/s)
+         mm::launch_gate(lane_st, (double)g.nbytes / 6.0e9 * gate_percent / 100.0);
+      }
       // How scans in flight share the device (rocprofv3 kernel trace, tools/lane_trace.sh).  Scan t starts
       // behind scan t-2 (same stream) and runs beside scan t-1.  The tail kernel of t-2 (96 VGPRs) finds
       // registers only here and there beside the streaming kernel of t-1 (6 waves x 72 VGPRs per SIMD leave
@@ -1460,7 +1492,8 @@ extern "C" int mmh_scan_submit(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t b
       std::copy(c->lane_ev[lane], c->lane_ev[lane] + 3, p.ev);
       // (filter + tail kernel, the end polled in the lane's own pinned block; never the single-launch kernel:
       // its grid barrier wants the device to itself)
-      rc = enqueue_pipeline(c, w, lane_st, p.ev, g, *plan, fc, false, base_offset, p.max_candidates, nullptr, true, false);
+      rc = enqueue_pipeline(c, w, lane_st, p.ev, g, *plan, fc, false, base_offset, p.max_candidates, nullptr, true, false, tail_st,
+                            mm::tuning().lane_tail_blocks);
       if (rc != MMH_OK) {
          return rc;
       }
@@ -1491,7 +1524,7 @@ extern "C" int mmh_scan_collect(mmh_ctx *c, int ticket, uint64_t *out, uint64_t 
       const MmGeom g = scan_geometry(c, &p.plan, p.block_bytes, p.big_endian);
       // (a second phase, if any, goes behind whatever later scans have been enqueued on the ticket's stream: it
       // works on this ticket's own workspace)
-      const hipStream_t lane_st = c->lane_stream[ticket % mmh_ctx::kLaneStreams];
+      const hipStream_t lane_st = c->pending_tail_stream[lane];
       int rc = finish_pipeline(c, w, lane_st, p.ev, g, p.plan, p.base_offset, p.max_candidates, false, &oc);
       if (rc != MMH_OK) {
          p.active = false;
@@ -1505,12 +1538,14 @@ extern "C" int mmh_scan_collect(mmh_ctx *c, int ticket, uint64_t *out, uint64_t 
             (void)hipEventRecord(base, lane_st);
             (void)hipEventSynchronize(base);
          }
-         float t0 = 0, t1 = 0, own = 0;
+         float t0 = 0, t1 = 0, t2 = 0, own = 0;
+         (void)hipEventSynchronize(p.ev[2]);
          (void)hipEventElapsedTime(&t0, base, p.ev[0]);
          (void)hipEventElapsedTime(&t1, base, p.ev[1]);
+         (void)hipEventElapsedTime(&t2, base, p.ev[2]);
          (void)hipEventElapsedTime(&own, p.ev[0], p.ev[1]);
-         fprintf(stderr, "lane %d ticket %d: streaming kernel dispatched %.1f us, ended %.1f us after the first collect; ran %.1f us\n",
-                 lane, ticket, t0 * 1e3, t1 * 1e3, own * 1e3);
+         fprintf(stderr, "lane %d ticket %d: streaming kernel dispatched %.1f us, ended %.1f us, tail kernel ended %.1f us after the first collect; streaming kernel ran %.1f us\n",
+                 lane, ticket, t0 * 1e3, t1 * 1e3, t2 * 1e3, own * 1e3);
       }
       // the lane's timings enter the history: now when its last event has completed, else a little later
       const int slot = (int)(c->scans_recorded % mmh_ctx::kRing);

@@ -103,6 +103,7 @@ struct MmComm {
 struct MmPending {
    bool active = false;
    bool needs_rescan = false;       // plan / engine choice the lanes do not run: collect scans synchronously
+   bool first_of_burst = false;     // it was submitted into an empty pipeline
    int ticket = 0;
    mmh_plan_desc plan{};
    uint64_t block_bytes = 0;
@@ -157,8 +158,9 @@ struct mmh_ctx {
    // order, and the context stays within the 4 hardware queues a process gets by default (GPU_MAX_HW_QUEUES):
    // its own stream, these two and the gather's.  Streams that share a hardware queue serialize -- a third lane
    // stream cost 0.706 -> 0.728 ms per scan as soon as a fifth stream existed in the process.
-   static constexpr int kLaneStreams = 2;
+   static constexpr int kLaneStreams = 3;               // (the third only in the experimental lane mode 2)
    hipStream_t lane_stream[kLaneStreams] = {};
+   hipStream_t pending_tail_stream[kLanes] = {};        // the stream a lane's tail kernel (and any follow-up work) went to
    hipEvent_t lane_fence = nullptr;                     // orders a lane behind earlier work on `stream`
    hipEvent_t lane_ev[kLanes][3] = {};                  // event triples of the lanes
    int64_t lane_timing_owed[kLanes] = {-1, -1, -1};

@@ -54,9 +54,10 @@ struct MmFusedArgs {
    const uint32_t *skip_bits;          // always null here
    uint64_t *bcand;                    // bucketed store (mm_tail2.h); null in the single-launch kernel
    unsigned int *bcount;
-   unsigned int *bsuper;
    unsigned long long *boverflow;
    uint32_t bshift;
+   uint32_t exp;
+   unsigned long long *span_tickets;   // always null here (static span hand-out)
    uint32_t nbuckets;
    uint64_t ngroups;
    uint32_t groups_per_span;

@@ -65,10 +65,10 @@ constexpr uint64_t MM_RESULT_BLOCK_WORDS = MM_HDR_FLAG_WORD + 8;
 // wave and piece on that bucket's counter, one non-returning one on the counter of its super-bucket of MM_SUPER
 // buckets).  Buckets are in offset order, so a candidate's place in the ascending list is
 //     candidates in the buckets before its own  +  members of its own bucket with a smaller offset
-// -- a scan over <= 256 super counters (once per workgroup), one over the 64 counters of its super-bucket and a ballot
+// -- a scan over the 64 super-bucket sums (once per workgroup), one over the 64 counters of its super-bucket and a ballot
 // over its bucket's members, instead of comparing it with every other candidate.
-constexpr uint32_t MM_BUCKET_CAP = 256;           // candidates a bucket holds (more: the scan takes the list-based path)
-constexpr uint32_t MM_MAX_BUCKETS = 16384;
+constexpr uint32_t MM_BUCKET_CAP = 1024;          // candidates a bucket holds (more: the scan takes the list-based path)
+constexpr uint32_t MM_MAX_BUCKETS = 4096;         // (every workgroup of mm_scan_tail2 sums all the counters: 16 KiB from L2)
 constexpr uint32_t MM_SUPER = 64;                 // buckets per super-bucket
 constexpr uint32_t MM_MIN_BUCKET_SHIFT = 12;
 

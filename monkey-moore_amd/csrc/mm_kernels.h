@@ -62,7 +62,7 @@ struct ResolveBuffers {
    uint8_t *scratch;
    // bucketed candidate store (mm_internal.h MM_BUCKET_*), zeroed by mm_scan_tail2's last workgroup
    uint64_t *bcand = nullptr;       // [MM_MAX_BUCKETS][MM_BUCKET_CAP]
-   unsigned int *bcount = nullptr;  // [MM_MAX_BUCKETS] then [MM_MAX_BUCKETS / MM_SUPER] super-bucket counters
+   unsigned int *bcount = nullptr;  // [MM_MAX_BUCKETS] members of every bucket
 };
 // geometry of the bucketed store for a ROM: 2^shift-byte buckets, nb of them
 struct BucketGeom {
@@ -132,6 +132,8 @@ void launch_rank_sort(hipStream_t st, const uint64_t *in, unsigned long long *ct
 // ascending order of n 64-bit keys (mm_sort.hip, rocPRIM radix sort); in and out must not overlap
 size_t sort_temp_bytes(uint64_t n);
 hipError_t sort_keys(hipStream_t st, const uint64_t *in, uint64_t *out, uint64_t n, void *temp, size_t temp_bytes);
+// holds the stream back for `ms` milliseconds (one sleeping wave)
+void launch_gate(hipStream_t st, double ms);
 void launch_synth(hipStream_t st, uint8_t *rom, uint64_t nbytes, uint64_t seed, uint64_t base_offset);
 void launch_gather(hipStream_t st, const uint8_t *rom, uint64_t nbytes, const uint64_t *offsets, uint64_t n, uint32_t each,
                    uint8_t *out);

@@ -247,9 +247,12 @@ struct MmFilterArgs {
    // bucketed store (mm_internal.h MM_BUCKET_*; null: the lists above): big ROMs, read by mm_scan_tail2
    uint64_t *bcand;                  // [nb][MM_BUCKET_CAP] candidate byte offsets
    unsigned int *bcount;             // [nb] members of every bucket
-   unsigned int *bsuper;             // [nb / MM_SUPER] members of every super-bucket
    unsigned long long *boverflow;    // appends that found their bucket full
    uint32_t bshift;                  // log2 of a bucket's width in bytes
+   uint32_t exp;                     // development: MMOORE_EXP bits (timing experiments, results are wrong when set)
+   // Dynamic span hand-out (bucketed scans; null: the static round-robin): MM_CAND_LISTS ticket counters, one 128-byte
+   // line each.  Counter c hands out the spans of the c-th 64th of the ROM to the workgroups with blockIdx % 64 == c.
+   unsigned long long *span_tickets;
 
    uint64_t ngroups;       // span kernel: number of whole 4 KiB groups it covers
    uint32_t groups_per_span;
@@ -340,8 +343,14 @@ __device__ __forceinline__ uint64_t *mm_bucket_reserve(const A &a, uint64_t piec
    const uint64_t b = piece0 >> a.bshift;
    unsigned int base = 0;
    if (__lane_id() == 0) {
-      base = atomicAdd(a.bcount + b, total);
-      atomicAdd(a.bsuper + (b / MM_SUPER), total);           // (result unused: a fire-and-forget atomic)
+      if (a.exp & 4) {
+         __hip_atomic_fetch_add(a.bcount + b, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      else {
+         base = atomicAdd(a.bcount + b, total);
+      }
+      // (no counter per super-bucket here: 256 of them are 8 cache lines, and 64 K fire-and-forget atomics on 8 lines
+      // cost the streaming kernel 65 us -- mm_scan_tail2's workgroups sum the bucket counters instead)
       if (base + total > MM_BUCKET_CAP) {
          atomicAdd(a.boverflow, 1ull);
       }
@@ -470,8 +479,13 @@ __device__ __forceinline__ void mm_f8_survivors(const A &a, uint64_t chunk0, uin
       while (bits) {
          const int bit = __ffs((int)bits) - 1;
          bits &= bits - 1;
-         if (slot < room) {
-            mm_store_shared(list + slot, chunk0 + 4 * (bit & 3) + (bit >> 3) - a.iA);
+         if (slot < room && !(a.exp & 2)) {
+            if (a.exp & 8) {
+               list[slot] = chunk0 + 4 * (bit & 3) + (bit >> 3) - a.iA;
+            }
+            else {
+               mm_store_shared(list + slot, chunk0 + 4 * (bit & 3) + (bit >> 3) - a.iA);
+            }
          }
          slot++;
       }
@@ -537,6 +551,58 @@ __device__ __forceinline__ void mm_f8_survivors(const A &a, uint64_t chunk0, uin
    }
 }
 
+
+// Which span a wave works on next.  Static (tickets == null): round i hands span i*nwaves + ((wave + 2731 i) mod nwaves)
+// to this wave -- neighbouring waves stream neighbouring spans, and anything periodic in the ROM (candidates at every
+// 32 MiB, say) lands on a different wave every round instead of piling up on a few.  Dynamic: the wave draws a ticket
+// from the counter of its workgroup's share of the ROM.  With every wave owning a fixed 1 / nwaves of the ROM a kernel
+// ends when its LAST-started workgroup has done its whole share -- next to another scan's streaming kernel (scans in
+// flight) workgroups start up to 0.7 ms apart, the early ones leave their slots idle long before the kernel ends, and
+// the device ran 2 % below its streaming rate; with tickets whoever is running takes what is left.
+struct MmSpanCursor {
+   uint64_t round, nwaves, wave, nspans;
+   unsigned long long *ticket;
+   uint64_t first, end;                     // dynamic: this counter's spans
+};
+
+template <class A>
+__device__ __forceinline__ MmSpanCursor mm_span_cursor(const A &a, uint64_t wave, uint64_t nwaves, uint64_t nspans)
+{
+   MmSpanCursor c;
+   c.round = 0; c.nwaves = nwaves; c.wave = wave; c.nspans = nspans;
+   c.ticket = nullptr; c.first = 0; c.end = 0;
+   if (a.span_tickets) {
+      const uint32_t k = blockIdx.x & (MM_CAND_LISTS - 1);
+      const uint64_t per = (nspans + MM_CAND_LISTS - 1) / MM_CAND_LISTS;
+      c.ticket = a.span_tickets + k * MM_LIST_STRIDE;
+      c.first = k * per;
+      c.end = c.first + per < nspans ? c.first + per : nspans;
+   }
+   return c;
+}
+
+// the next span of this wave (wave uniform), false when there is none left
+__device__ __forceinline__ bool mm_next_span(MmSpanCursor &c, uint64_t *span)
+{
+   if (c.ticket) {
+      unsigned long long t = 0;
+      if (__lane_id() == 0) {
+         t = atomicAdd(c.ticket, 1ull);
+      }
+      *span = c.first + mm_uniform64_k(t);
+      return *span < c.end;
+   }
+   for (; c.round * c.nwaves < c.nspans; c.round++) {
+      const uint64_t s = c.round * c.nwaves + (c.wave + c.round * 2731) % c.nwaves;
+      if (s < c.nspans) {
+         c.round++;
+         *span = s;
+         return true;
+      }
+   }
+   return false;
+}
+
 // bounds-checked version for the ragged end of the ROM (everything behind the last
 // whole 4 KiB group): one chunk per lane per iteration, look-back by a second load
 // (nblocks workgroups take part, this one is number `block` of them)
@@ -586,15 +652,10 @@ __device__ __forceinline__ void mm_stream_u8(const A &a)
    const uint4 *rom4 = reinterpret_cast<const uint4 *>(a.t.g.rom);
    const uint32_t *rom1 = reinterpret_cast<const uint32_t *>(a.t.g.rom);
 
-   // Round i hands span i*nwaves + ((wave + 2731 i) mod nwaves) to this wave: neighbouring waves
-   // still stream neighbouring spans, but anything periodic in the ROM (candidates at every
-   // 32 MiB, say) lands on a different wave every round instead of piling up on a few.
    const uint64_t nspans = (a.ngroups + gps - 1) / gps;
-   for (uint64_t round = 0; round * nwaves < nspans; round++) {
-      const uint64_t span = round * nwaves + (wave + round * 2731) % nwaves;
-      if (span >= nspans) {
-         continue;
-      }
+   MmSpanCursor cursor = mm_span_cursor(a, wave, nwaves, nspans);
+   uint64_t span;
+   while (mm_next_span(cursor, &span)) {
       const uint64_t g0 = span * gps;
       const uint64_t g1 = g0 + gps < a.ngroups ? g0 + gps : a.ngroups;
       uint32_t carry = g0 ? rom1[g0 * 1024 - 1] : 0u;          // dword in front of the span (wave uniform)
@@ -873,15 +934,10 @@ __device__ __forceinline__ void mm_stream_u16(const A &a)
    const uint4 *rom4 = reinterpret_cast<const uint4 *>(a.t.g.rom);
    const uint32_t *rom1 = reinterpret_cast<const uint32_t *>(a.t.g.rom);
 
-   // Round i hands span i*nwaves + ((wave + 2731 i) mod nwaves) to this wave: neighbouring waves
-   // still stream neighbouring spans, but anything periodic in the ROM (candidates at every
-   // 32 MiB, say) lands on a different wave every round instead of piling up on a few.
    const uint64_t nspans = (a.ngroups + gps - 1) / gps;
-   for (uint64_t round = 0; round * nwaves < nspans; round++) {
-      const uint64_t span = round * nwaves + (wave + round * 2731) % nwaves;
-      if (span >= nspans) {
-         continue;
-      }
+   MmSpanCursor cursor = mm_span_cursor(a, wave, nwaves, nspans);
+   uint64_t span;
+   while (mm_next_span(cursor, &span)) {
       const uint64_t g0 = span * gps;
       const uint64_t g1 = g0 + gps < a.ngroups ? g0 + gps : a.ngroups;
       // the three dwords in front of the span (wave uniform)
@@ -1208,6 +1264,16 @@ __global__ __launch_bounds__(256) void mm_gather(const uint8_t *rom, uint64_t nb
    }
 }
 
+// One wave that does nothing for `ticks` of the 100 MHz wall clock: holds the kernels behind it on its stream back
+// (mmh_scan_submit: the second scan of a burst starts half a streaming kernel behind the first, see there).
+__global__ __launch_bounds__(64) void mm_gate(unsigned long long ticks)
+{
+   const unsigned long long t0 = wall_clock64();
+   while (wall_clock64() - t0 < ticks) {
+      __builtin_amdgcn_s_sleep(64);
+   }
+}
+
 // --------------------------------------------------------------------------
 // launch wrappers (called from mm_capi.hip)
 // --------------------------------------------------------------------------
@@ -1230,7 +1296,9 @@ const Tuning &tuning()
       k.resolve_blocks = (unsigned)number("MMOORE_RESOLVE_BLOCKS", 4096);
       // (mm_arrive_last counts arrivals in MM_ARRIVE_LINES - 1 groups of MM_ARRIVE_FAN: more workgroups would spill into the next lines)
       k.tail_blocks = (unsigned)std::min<long>(number("MMOORE_TAIL_BLOCKS", 2048), (long)MM_ARRIVE_FAN * (MM_ARRIVE_LINES - 1));
-      k.lane_tail_blocks = (unsigned)std::min<long>(number("MMOORE_LANE_TAIL_BLOCKS", 2048), (long)MM_ARRIVE_FAN * (MM_ARRIVE_LINES - 1));
+      // (scans in flight: a small tail grid beside the next scan's streaming kernel -- 512 workgroups: 0.687-0.689 ms per 4 GiB
+      // scan in the steady state against 0.695-0.696 with 2048, profiles/r03_lane_gate_and_span_tickets.log)
+      k.lane_tail_blocks = (unsigned)std::min<long>(number("MMOORE_LANE_TAIL_BLOCKS", 512), (long)MM_ARRIVE_FAN * (MM_ARRIVE_LINES - 1));
       k.max_candidates = (uint32_t)number("MMOORE_MAX_CANDIDATES", 262144);
       return k;
    }();
@@ -1452,7 +1520,10 @@ static void fill_filter_args(A &a, const MmGeom &g, const mmh_plan_desc &pl, con
    }
    a.cand = cand; a.list_count = ctrl + MM_CTRL_LISTS; a.list_cap = cand_cap / MM_CAND_LISTS;
    a.dom_count = nullptr; a.skip_bits = nullptr;
-   a.bcand = nullptr; a.bcount = nullptr; a.bsuper = nullptr; a.boverflow = nullptr; a.bshift = 0;
+   a.bcand = nullptr; a.bcount = nullptr; a.boverflow = nullptr; a.bshift = 0;
+   static const uint32_t exp_bits = [] { const char *e = getenv("MMOORE_EXP"); return (uint32_t)(e && *e ? atol(e) : 0); }();
+   a.exp = exp_bits;
+   a.span_tickets = nullptr;
    // whole 4 KiB groups go to the span code, the ragged end to the bounds-checked one
    a.ngroups = g.nbytes / 4096;
    a.groups_per_span = groups_per_span;
@@ -1585,14 +1656,24 @@ BucketGeom bucket_geom(uint64_t nbytes)
    return b;
 }
 size_t bucket_cand_bytes() { return (size_t)MM_MAX_BUCKETS * MM_BUCKET_CAP * sizeof(uint64_t); }
-size_t bucket_count_bytes() { return (size_t)(MM_MAX_BUCKETS + MM_MAX_BUCKETS / MM_SUPER) * sizeof(unsigned int); }
+size_t bucket_count_bytes() { return (size_t)MM_MAX_BUCKETS * sizeof(unsigned int); }
 
 template <class A>
 static void fill_bucket_args(A &a, const MmGeom &g, const ResolveBuffers &rb)
 {
    const BucketGeom b = bucket_geom(g.nbytes);
-   a.bcand = rb.bcand; a.bcount = rb.bcount; a.bsuper = rb.bcount + MM_MAX_BUCKETS;
+   a.bcand = rb.bcand; a.bcount = rb.bcount;
    a.boverflow = rb.ctrl + MM_CTRL_BOVERFLOW; a.bshift = b.shift;
+}
+
+// MMOORE_SPAN_TICKETS=1: bucketed scans hand out spans through tickets (development knob).  Measured and NOT the
+// default: the ticket's round trip at every span boundary and the loss of "neighbouring waves stream neighbouring
+// spans" cost more than the balance gains -- streaming kernel alone 0.742 ms per 4 GiB against 0.705 static, scans in
+// flight 0.775 against 0.69 (profiles/r03_lane_gate_and_span_tickets.log).
+static bool span_tickets_enabled()
+{
+   static const bool on = [] { const char *e = getenv("MMOORE_SPAN_TICKETS"); return e && *e == '1'; }();
+   return on;
 }
 
 void launch_filter_buckets(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc, const ResolveBuffers &rb,
@@ -1605,6 +1686,8 @@ void launch_filter_buckets(hipStream_t st, const MmGeom &g, const mmh_plan_desc 
    }
    fill_filter_args(a, g, pl, fc, rb.cand, rb.ctrl, rb.cand_cap, gps);
    fill_bucket_args(a, g, rb);
+   // (the 64 list counters of the control block are idle in a bucketed scan: they hand out the spans)
+   a.span_tickets = span_tickets_enabled() ? rb.ctrl + MM_CTRL_LISTS : nullptr;
    with_shape(pl.elem_bytes, fc, [&](auto elem, auto shape) {
       constexpr int SHAPE = decltype(shape)::value;
       if constexpr (decltype(elem)::value == 1) {
@@ -1799,6 +1882,11 @@ void launch_rank_sort(hipStream_t st, const uint64_t *in, unsigned long long *ct
       hipLaunchKernelGGL(mm_rank_scatter, dim3(64), dim3(256), 0, st, in, ctrl, count_index, cap, max_n, partials,
                          host_result, dev_result, ctrl_words, keep);
    }
+}
+
+void launch_gate(hipStream_t st, double ms)
+{
+   hipLaunchKernelGGL(mm_gate, dim3(1), dim3(64), 0, st, (unsigned long long)(ms * 1e5));
 }
 
 void launch_synth(hipStream_t st, uint8_t *rom, uint64_t nbytes, uint64_t seed, uint64_t base_offset)

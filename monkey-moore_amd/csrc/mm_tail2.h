@@ -9,8 +9,8 @@
 // candidate into the bucket of its ROM neighbourhood, buckets are in offset order, and a wave needs three loads to
 // know a candidate and its place in the ascending list, whatever the number of candidates:
 //     the 64 member counts of the candidate's super-bucket   -> which bucket, which slot, candidates in front of the bucket
-//     the bucket's members (one per lane, <= 4 rounds)       -> the candidate itself and how many members are smaller
-// (the candidates in front of the super-bucket come from <= 256 super counters, scanned once per workgroup).
+//     the bucket's members (one per lane and round)          -> the candidate itself and how many members are smaller
+// (the candidates in front of the super-bucket: every workgroup sums the 4096 bucket counters once, 16 KiB from L2).
 // No workgroup-wide step is left inside the candidate loop: waves run on their own, with 20 .. 40 registers fewer
 // than mm_scan_tail -- the kernel fits beside the streaming kernel of the NEXT scan (scans in flight).
 //
@@ -38,30 +38,40 @@ __global__ __launch_bounds__(64 * MM_WAVES, OCC) void mm_scan_tail2(MmFusedArgs 
    __shared__ MmTail2Lds T;
    const int wave = (int)mm_uniform(threadIdx.x >> 6);
    const int lane = threadIdx.x & 63;
-   const uint32_t nsuper = (a.nbuckets + MM_SUPER - 1) / MM_SUPER;        // <= 256
+   constexpr uint32_t nsuper = MM_MAX_BUCKETS / MM_SUPER;                 // 64: one per lane
 
-   // ---- candidates in front of every super-bucket (wave 0; the plan goes to LDS meanwhile) --------------------------
-   if (threadIdx.x < 64) {
-      unsigned int carry = 0;
-      for (uint32_t s0 = 0; s0 < nsuper; s0 += 64) {
-         const uint32_t s = s0 + (uint32_t)lane;
-         const unsigned int n = s < nsuper ? a.bsuper[s] : 0u;
-         unsigned int incl = n;
+   // ---- candidates in front of every super-bucket ------------------------------------------------------------------
+   // Thread t sums 16 bucket counters (4 x 16 bytes, L2 resident: the streaming kernel's atomics left them there), four
+   // neighbouring threads make a super-bucket's sum, wave 0 scans the 64 sums while the plan goes to LDS.
+   static_assert(MM_MAX_BUCKETS == 64 * MM_SUPER && MM_SUPER == 64, "one super-bucket per lane, 16 counters per thread");
+   {
+      const uint4 *row = reinterpret_cast<const uint4 *>(a.bcount) + (uint64_t)threadIdx.x * 4;
+      unsigned int sum = 0;
 #pragma unroll
-         for (int d = 1; d < 64; d <<= 1) {
-            const unsigned int up = (unsigned int)__shfl_up((int)incl, d);
-            incl += lane >= d ? up : 0u;
-         }
-         if (s < nsuper) {
-            T.super_excl[s] = carry + incl - n;
-         }
-         carry += (unsigned int)__builtin_amdgcn_readlane((int)incl, 63);
+      for (int k = 0; k < 4; k++) {
+         const uint4 v = row[k];                                          // (buckets behind the ROM's last one were never touched: zero)
+         sum += v.x + v.y + v.z + v.w;
       }
-      if (lane == 0) {
-         T.super_excl[nsuper] = carry;
-         T.holes = 0;
-         T.walked = 0;
+      sum += (unsigned int)__shfl_xor((int)sum, 1);
+      sum += (unsigned int)__shfl_xor((int)sum, 2);
+      if ((threadIdx.x & 3) == 0) {
+         T.super_excl[(threadIdx.x >> 2) + 1] = sum;
       }
+   }
+   if (threadIdx.x == 0) {
+      T.super_excl[0] = 0;
+      T.holes = 0;
+      T.walked = 0;
+   }
+   __syncthreads();
+   if (threadIdx.x < 64) {
+      unsigned int incl = T.super_excl[lane + 1];
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+         const unsigned int up = (unsigned int)__shfl_up((int)incl, d);
+         incl += lane >= d ? up : 0u;
+      }
+      T.super_excl[lane + 1] = incl;                                      // candidates up to and including super-bucket `lane`
    }
    mm_plan_to_lds(P, a.t.plan);                                           // ends with a __syncthreads()
    const uint64_t ncand = T.super_excl[nsuper];
@@ -73,16 +83,8 @@ __global__ __launch_bounds__(64 * MM_WAVES, OCC) void mm_scan_tail2(MmFusedArgs 
    if (resolvable) {
       const uint64_t nwaves = (uint64_t)gridDim.x * MM_WAVES;
       for (uint64_t ci = (uint64_t)blockIdx.x * MM_WAVES + wave; ci < ncand; ci += nwaves) {
-         // which super-bucket: the last one whose first candidate is <= ci (lane l looks at entries l, l + 64, ...)
-         uint32_t s = 0;
-         for (uint32_t s0 = 0; s0 < nsuper; s0 += 64) {
-            const uint32_t k = s0 + (uint32_t)lane;
-            const unsigned long long le = __ballot(k < nsuper && T.super_excl[k] <= ci);
-            s = le ? s0 + 63u - (uint32_t)__builtin_clzll(le) : s;
-            if (le != ~0ull) {
-               break;
-            }
-         }
+         // which super-bucket: the last one whose first candidate is <= ci (one per lane)
+         const uint32_t s = 63u - (uint32_t)__builtin_clzll(__ballot(T.super_excl[lane] <= ci));
          const uint32_t in_super = (uint32_t)(ci - T.super_excl[s]);
          // which bucket of it: one counter per lane
          const uint32_t b_lane = s * MM_SUPER + (uint32_t)lane;
@@ -101,25 +103,15 @@ __global__ __launch_bounds__(64 * MM_WAVES, OCC) void mm_scan_tail2(MmFusedArgs 
          const uint32_t before = (uint32_t)T.super_excl[s] + (uint32_t)__shfl((int)excl, bl);   // candidates in front of the bucket
          const uint32_t members = (uint32_t)__shfl((int)n_lane, bl);
          const uint32_t slot = in_super - (uint32_t)__shfl((int)excl, bl);
-         // the bucket's members, one per lane and round: the candidate itself and how many of them lie in front of it
+         // the candidate itself, and how many of the bucket's members lie in front of it (64 members per round; one round
+         // unless the neighbourhood is crowded)
          const unsigned long long *mem = reinterpret_cast<const unsigned long long *>(a.bcand) + (uint64_t)bucket * MM_BUCKET_CAP;
-         unsigned long long m[MM_BUCKET_CAP / 64];
-#pragma unroll
-         for (int r = 0; r < (int)(MM_BUCKET_CAP / 64); r++) {
-            const uint32_t k = 64u * r + (uint32_t)lane;
-            m[r] = (64u * r < members && k < members) ? mem[k] : ~0ull;
-         }
-         uint64_t o = 0;
-#pragma unroll
-         for (int r = 0; r < (int)(MM_BUCKET_CAP / 64); r++) {
-            if ((slot >> 6) == (uint32_t)r) {
-               o = mm_uniform64(__shfl(m[r], (int)(slot & 63)));
-            }
-         }
+         const uint64_t o = mm_uniform64(mem[slot]);
          uint32_t rank = before;
-#pragma unroll
-         for (int r = 0; r < (int)(MM_BUCKET_CAP / 64); r++) {
-            rank += (uint32_t)__popcll(__ballot(m[r] < o));
+         for (uint32_t k0 = 0; k0 < members; k0 += 64) {
+            const uint32_t k = k0 + (uint32_t)lane;
+            const unsigned long long mk = k < members ? mem[k] : ~0ull;
+            rank += (uint32_t)__popcll(__ballot(mk < o));
          }
          int64_t hi = 0; uint32_t set = 0; uint64_t dom = 0;
          const int verdict = mm_resolve_candidate(a, P, Wv[wave], o, lane, &walked, &hi, &set, &dom);
@@ -213,9 +205,6 @@ __global__ __launch_bounds__(64 * MM_WAVES, OCC) void mm_scan_tail2(MmFusedArgs 
    }
    for (uint32_t k = threadIdx.x; k < a.nbuckets; k += blockDim.x) {
       a.bcount[k] = 0;
-   }
-   for (uint32_t k = threadIdx.x; k < nsuper; k += blockDim.x) {
-      a.bsuper[k] = 0;
    }
    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
    __syncthreads();

@@ -45,7 +45,8 @@ constexpr int MM_TILE = 2048;                 // positions per tile
 constexpr int MM_WAVES = 4;                   // waves per workgroup in the tile kernels
 constexpr int MM_MAXD = MM_RESOLVER_MAX_KEYWORD;   // bytes of a stored phase map in the per-candidate machinery: keywords of up to 32
                                               // symbols (D <= 31, phase sets in one 32-bit word); longer ones go to the forward engine
-constexpr int MM_FAST_STEPS = 2;              // look-back windows of mm_resolve: <= 256, then <= 512 positions
+constexpr int MM_FAST_STEPS = 3;              // look-back windows of the per-candidate resolver: 64 (128 for keywords beyond 16 symbols),
+                                              // then 256, then 512 positions
 constexpr int MM_MID_CHUNK = 512;             // mm_resolve2: a workgroup's waves map chunks of this many positions in parallel
 constexpr int MM_MID_CAP = 2048;              // candidates mm_resolve hands to mm_resolve2 per scan
 constexpr int MM_HARD_PARTS = 64;             // workgroups per hard candidate
@@ -510,12 +511,14 @@ __device__ __forceinline__ int mm_resolve_candidate(const A &a, const MmPlanLds 
       mm_step(a.t.plan, [&](int64_t k) { return mm_elem(a.t.g, start, k); }, 0, &matched);
       verdict = matched ? 1 : 0;
    }
-   // Look-back windows of <= 256, then <= 512 positions, ending on multiples of their size:
-   // a true match pulls every phase onto itself within a few keyword lengths (that is
-   // what the bad-character rule is for), so the first window usually settles it.
+   // Look-back windows of 64 (keywords beyond 16 symbols: 128), then 256, then 512 positions in front of the frontier:
+   // a true match pulls every phase onto itself within a few keyword lengths (that is what the bad-character
+   // rule is for), so the first, short window usually settles it -- one pass of the position-parallel jump loop
+   // instead of up to four (round 2 started with an aligned window of up to 256 positions: at 64 K candidates the
+   // tail kernel was bound by the instructions of that loop).
    for (int step = 0; step < MM_FAST_STEPS && hi > 0 && verdict < 0; step++) {
-      const int64_t gran = (int64_t)256 << step;
-      const int64_t lo = (hi - 1) & ~(gran - 1);
+      const int64_t size = step == 0 ? (a.t.plan.L <= 16 ? 64 : 128) : (int64_t)128 << step;
+      const int64_t lo = hi > size ? hi - size : 0;
       bool is_match = true;
       const uint32_t map = mm_tile_map(a.t, P, W, start, lo, (int)(hi - lo), mm_modd64(a.t, (uint64_t)lo), lane,
                                        step == 0 ? &is_match : nullptr);
