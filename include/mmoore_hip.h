@@ -216,8 +216,8 @@ int mmh_scan_multi(mmh_ctx *const *ctxs, int n, const mmh_plan_desc *plan, uint6
 /* Self-test hook (tests only): what mmh_gather_finish would deliver had an nranks-rank all-gather left
  * `records` -- nranks records of MMH_GATHER_RECORD_WORDS words as a scan publishes them: [0] slots,
  * [4] bit 0 = the slots have holes (~0), [6] = matches + 1, from word 8 the slots -- on the device.
- * Runs the packing kernel on them; *longest > 16384 means the second (padded) phase would follow and
- * nothing is delivered.  The development box has one GPU: this is how the merge of many ranks' lists
+ * Runs the packing kernel on them; *longest = the most a record would have to hold (a rank's list, or its
+ * slot count when the list has holes): > 16384 means the second (padded) phase would follow and nothing is delivered.  The development box has one GPU: this is how the merge of many ranks' lists
  * is tested there. */
 #define MMH_GATHER_RECORD_WORDS (8 + 16384)
 int mmh_selftest_gather_pack(mmh_ctx *ctx, const uint64_t *records, int nranks, uint64_t *out, uint64_t cap,

@@ -59,6 +59,7 @@ struct MmFusedArgs {
    uint32_t exp;
    unsigned long long *span_tickets;   // always null here (static span hand-out)
    uint32_t nbuckets;
+   uint32_t direct_limit;              // mm_scan_tail2: lists of up to this many slots are also stored straight into pinned host memory
    uint64_t ngroups;
    uint32_t groups_per_span;
    uint64_t edge_first;

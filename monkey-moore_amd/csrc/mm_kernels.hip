@@ -1708,8 +1708,10 @@ void launch_tail2(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, cons
    fill_tail_args(a, rb, base_offset, max_candidates, host_result, dev_result, MM_MAX_PUBLISH, seq);
    fill_bucket_args(a, g, rb);
    a.nbuckets = bucket_geom(g.nbytes).nb;
+   static const uint32_t direct_limit = [] { const char *e = getenv("MMOORE_DIRECT_PUBLISH"); return (uint32_t)(e && *e ? atol(e) : MM_DIRECT_PUBLISH); }();
+   a.direct_limit = direct_limit;
    a.has_edge = 0;
-   launch_timed(mm_scan_tail2<6>, dim3(tail_blocks ? tail_blocks : tuning().tail_blocks), dim3(64 * MM_WAVES), st, nullptr, stop, a);
+   launch_timed(mm_scan_tail2<8>, dim3(tail_blocks ? tail_blocks : tuning().tail_blocks), dim3(64 * MM_WAVES), st, nullptr, stop, a);
 }
 
 static MmTileArgs tile_args(const MmGeom &g, const mmh_plan_desc &pl)

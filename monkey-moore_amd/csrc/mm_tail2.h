@@ -77,18 +77,25 @@ __global__ __launch_bounds__(64 * MM_WAVES, OCC) void mm_scan_tail2(MmFusedArgs 
    const uint64_t ncand = T.super_excl[nsuper];
    const bool overflow = __hip_atomic_load(a.boverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
    const bool resolvable = !overflow && ncand <= a.out_cap && ncand <= a.max_candidates && ncand <= a.max_rank;
-   const bool direct = ncand <= MM_DIRECT_PUBLISH;                        // slots go to pinned host memory as well
+   const bool direct = ncand <= a.direct_limit;                           // slots go to pinned host memory as well
    unsigned long long walked = 0;
    unsigned int holes = 0;
    if (resolvable) {
       const uint64_t nwaves = (uint64_t)gridDim.x * MM_WAVES;
-      for (uint64_t ci = (uint64_t)blockIdx.x * MM_WAVES + wave; ci < ncand; ci += nwaves) {
-         // which super-bucket: the last one whose first candidate is <= ci (one per lane)
-         const uint32_t s = 63u - (uint32_t)__builtin_clzll(__ballot(T.super_excl[lane] <= ci));
+      // (the 64 bucket counters of the NEXT candidate's super-bucket are fetched while this one is resolved: one of the
+      // three dependent loads in front of a candidate off the critical path)
+      auto super_of = [&](uint64_t ci) { return 63u - (uint32_t)__builtin_clzll(__ballot(T.super_excl[lane] <= ci)); };
+      uint64_t ci = (uint64_t)blockIdx.x * MM_WAVES + wave;
+      uint32_t s = ci < ncand ? super_of(ci) : 0u;
+      unsigned int n_next = ci < ncand ? a.bcount[s * MM_SUPER + (uint32_t)lane] : 0u;
+      for (; ci < ncand; ci += nwaves) {
          const uint32_t in_super = (uint32_t)(ci - T.super_excl[s]);
-         // which bucket of it: one counter per lane
-         const uint32_t b_lane = s * MM_SUPER + (uint32_t)lane;
-         const unsigned int n_lane = b_lane < a.nbuckets ? a.bcount[b_lane] : 0u;
+         const uint32_t s_this = s;
+         const unsigned int n_lane = n_next;
+         if (ci + nwaves < ncand) {
+            s = super_of(ci + nwaves);
+            n_next = a.bcount[s * MM_SUPER + (uint32_t)lane];
+         }
          unsigned int incl = n_lane;
 #pragma unroll
          for (int d = 1; d < 64; d <<= 1) {
@@ -99,8 +106,8 @@ __global__ __launch_bounds__(64 * MM_WAVES, OCC) void mm_scan_tail2(MmFusedArgs 
          // (the last non-empty bucket that starts at or in front of the candidate; ci < ncand: there is one)
          const unsigned long long starts = __ballot(excl <= in_super && n_lane != 0);
          const int bl = starts ? 63 - __builtin_clzll(starts) : 0;
-         const uint32_t bucket = s * MM_SUPER + (uint32_t)bl;
-         const uint32_t before = (uint32_t)T.super_excl[s] + (uint32_t)__shfl((int)excl, bl);   // candidates in front of the bucket
+         const uint32_t bucket = s_this * MM_SUPER + (uint32_t)bl;
+         const uint32_t before = (uint32_t)T.super_excl[s_this] + (uint32_t)__shfl((int)excl, bl);   // candidates in front of the bucket
          const uint32_t members = (uint32_t)__shfl((int)n_lane, bl);
          const uint32_t slot = in_super - (uint32_t)__shfl((int)excl, bl);
          // the candidate itself, and how many of the bucket's members lie in front of it (64 members per round; one round

@@ -165,7 +165,7 @@ def test_packing_of_many_ranks_records(mm, comm_engine):
     for nranks in (1, 3, 8, 64):
         for trial in range(4):
             rec = rng.integers(0, 1 << 62, (nranks, W), dtype=np.uint64)        # garbage wherever nothing is defined
-            want = []
+            want, extents = [], []
             for r in range(nranks):
                 kind = int(rng.integers(0, 5)) if trial else 4
                 n = [0, 1, int(rng.integers(2, 5000)), 16384, int(rng.integers(2, 9000))][kind]
@@ -182,13 +182,15 @@ def test_packing_of_many_ranks_records(mm, comm_engine):
                     body[~hole] = offs
                     rec[r, 8:8 + slots] = body
                     rec[r, 0], rec[r, 4], rec[r, 6] = slots, 1, n + 1
+                    extents.append(slots)
                 else:
                     rec[r, 8:8 + n] = offs
                     rec[r, 0], rec[r, 4], rec[r, 6] = n + int(rng.integers(0, 3)), 0, n + 1   # (dense: word 0 may count dropped slots too)
+                    extents.append(n)
                 want.append(offs)
             got, longest = eng.selftest_gather_pack(rec)
             flat = np.concatenate(want)
-            assert longest == max(len(w) for w in want)
+            assert longest == max(extents)           # what a record has to hold: the list, or one slot per candidate when it has holes
             assert got.tolist() == flat.tolist(), (nranks, trial)
             assert (np.diff(got.astype(np.int64)) > 0).all() or got.size < 2
     # a rank with a list longer than a record: nothing is delivered, the second phase would follow

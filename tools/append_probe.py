@@ -26,12 +26,17 @@ eng.alloc(16 * PIECE)
 for k in range(16):
     eng.poke(k * PIECE, rom)
 plan = mm.plan_relative(1, "relativesrch")
-f, t = [], []
+import time
+f, t, wall = [], [], []
 for i in range(40):
+    t0 = time.perf_counter()
     offs = eng.scan(plan, block_bytes=524288, cap=1 << 20)
+    w = time.perf_counter() - t0
     tm = eng.timings()
     if i >= 15:
         f.append(tm["filter_ms"])
         t.append(tm["total_ms"])
-print("BUCKETS=%s EXP=%s plants/MiB %d: filter %.4f ms (min %.4f)  device %.4f ms  %s  results %d" % (
-    os.environ.get("MMOORE_BUCKETS", "1"), os.environ.get("MMOORE_EXP", "0"), per_mib, np.mean(f), np.min(f), np.mean(t), eng.counters(), len(offs)))
+        wall.append(w * 1e3)
+print("BUCKETS=%s EXP=%s DIRECT=%s plants/MiB %d: filter %.4f ms (min %.4f)  device %.4f ms  caller %.4f ms (min %.4f) = %.3f of peak  %s  results %d" % (
+    os.environ.get("MMOORE_BUCKETS", "1"), os.environ.get("MMOORE_EXP", "0"), os.environ.get("MMOORE_DIRECT_PUBLISH", "-"), per_mib, np.mean(f), np.min(f),
+    np.mean(t), np.mean(wall), np.min(wall), (4 << 30) / np.mean(wall) / 1e6 / 8000, eng.counters(), len(offs)))
