@@ -1812,6 +1812,7 @@ static void launch_forward(hipStream_t st, const MmGeom &g, const mmh_plan_desc 
    a.base_offset = base_offset;
    // the table-driven jump path: 8-bit elements, first compare against an element 1..4 to the left
    a.fast = 0; a.i1 = a.g1 = a.has2 = a.i2 = a.g2 = 0;
+
    int i1 = (int)pl.L - 1;
    while (i1 >= 0 && pl.cmp_mask[i1] == 0) {
       i1--;
