@@ -249,7 +249,7 @@ struct MmFilterArgs {
    unsigned int *bcount;             // [nb] members of every bucket
    unsigned long long *boverflow;    // appends that found their bucket full
    uint32_t bshift;                  // log2 of a bucket's width in bytes
-   uint32_t exp;                     // development: MMOORE_EXP bits (timing experiments, results are wrong when set)
+   uint32_t static_rounds;           // with span tickets: the first rounds stay static, the rest of the ROM is drawn
    // Dynamic span hand-out (bucketed scans; null: the static round-robin): MM_CAND_LISTS ticket counters, one 128-byte
    // line each.  Counter c hands out the spans of the c-th 64th of the ROM to the workgroups with blockIdx % 64 == c.
    unsigned long long *span_tickets;
@@ -343,12 +343,7 @@ __device__ __forceinline__ uint64_t *mm_bucket_reserve(const A &a, uint64_t piec
    const uint64_t b = piece0 >> a.bshift;
    unsigned int base = 0;
    if (__lane_id() == 0) {
-      if (a.exp & 4) {
-         __hip_atomic_fetch_add(a.bcount + b, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      else {
-         base = atomicAdd(a.bcount + b, total);
-      }
+      base = atomicAdd(a.bcount + b, total);
       // (no counter per super-bucket here: 256 of them are 8 cache lines, and 64 K fire-and-forget atomics on 8 lines
       // cost the streaming kernel 65 us -- mm_scan_tail2's workgroups sum the bucket counters instead)
       if (base + total > MM_BUCKET_CAP) {
@@ -479,13 +474,8 @@ __device__ __forceinline__ void mm_f8_survivors(const A &a, uint64_t chunk0, uin
       while (bits) {
          const int bit = __ffs((int)bits) - 1;
          bits &= bits - 1;
-         if (slot < room && !(a.exp & 2)) {
-            if (a.exp & 8) {
-               list[slot] = chunk0 + 4 * (bit & 3) + (bit >> 3) - a.iA;
-            }
-            else {
-               mm_store_shared(list + slot, chunk0 + 4 * (bit & 3) + (bit >> 3) - a.iA);
-            }
+         if (slot < room) {
+            mm_store_shared(list + slot, chunk0 + 4 * (bit & 3) + (bit >> 3) - a.iA);
          }
          slot++;
       }
@@ -561,6 +551,7 @@ __device__ __forceinline__ void mm_f8_survivors(const A &a, uint64_t chunk0, uin
 // the device ran 2 % below its streaming rate; with tickets whoever is running takes what is left.
 struct MmSpanCursor {
    uint64_t round, nwaves, wave, nspans;
+   uint64_t static_spans;                   // spans [0, static_spans) go round by round, the rest through tickets
    unsigned long long *ticket;
    uint64_t first, end;                     // dynamic: this counter's spans
 };
@@ -570,12 +561,16 @@ __device__ __forceinline__ MmSpanCursor mm_span_cursor(const A &a, uint64_t wave
 {
    MmSpanCursor c;
    c.round = 0; c.nwaves = nwaves; c.wave = wave; c.nspans = nspans;
-   c.ticket = nullptr; c.first = 0; c.end = 0;
+   c.ticket = nullptr; c.first = 0; c.end = 0; c.static_spans = nspans;
    if (a.span_tickets) {
+      // the first static_rounds rounds as ever; what is left of the ROM is cut into 64 shares, one ticket counter each
+      const uint64_t fixed = (uint64_t)a.static_rounds * nwaves;
+      c.static_spans = fixed < nspans ? fixed : nspans;
+      const uint64_t rest = nspans - c.static_spans;
       const uint32_t k = blockIdx.x & (MM_CAND_LISTS - 1);
-      const uint64_t per = (nspans + MM_CAND_LISTS - 1) / MM_CAND_LISTS;
+      const uint64_t per = (rest + MM_CAND_LISTS - 1) / MM_CAND_LISTS;
       c.ticket = a.span_tickets + k * MM_LIST_STRIDE;
-      c.first = k * per;
+      c.first = c.static_spans + k * per;
       c.end = c.first + per < nspans ? c.first + per : nspans;
    }
    return c;
@@ -584,6 +579,14 @@ __device__ __forceinline__ MmSpanCursor mm_span_cursor(const A &a, uint64_t wave
 // the next span of this wave (wave uniform), false when there is none left
 __device__ __forceinline__ bool mm_next_span(MmSpanCursor &c, uint64_t *span)
 {
+   for (; c.round * c.nwaves < c.static_spans; c.round++) {
+      const uint64_t s = c.round * c.nwaves + (c.wave + c.round * 2731) % c.nwaves;
+      if (s < c.static_spans) {
+         c.round++;
+         *span = s;
+         return true;
+      }
+   }
    if (c.ticket) {
       unsigned long long t = 0;
       if (__lane_id() == 0) {
@@ -591,14 +594,6 @@ __device__ __forceinline__ bool mm_next_span(MmSpanCursor &c, uint64_t *span)
       }
       *span = c.first + mm_uniform64_k(t);
       return *span < c.end;
-   }
-   for (; c.round * c.nwaves < c.nspans; c.round++) {
-      const uint64_t s = c.round * c.nwaves + (c.wave + c.round * 2731) % c.nwaves;
-      if (s < c.nspans) {
-         c.round++;
-         *span = s;
-         return true;
-      }
    }
    return false;
 }
@@ -1521,9 +1516,8 @@ static void fill_filter_args(A &a, const MmGeom &g, const mmh_plan_desc &pl, con
    a.cand = cand; a.list_count = ctrl + MM_CTRL_LISTS; a.list_cap = cand_cap / MM_CAND_LISTS;
    a.dom_count = nullptr; a.skip_bits = nullptr;
    a.bcand = nullptr; a.bcount = nullptr; a.boverflow = nullptr; a.bshift = 0;
-   static const uint32_t exp_bits = [] { const char *e = getenv("MMOORE_EXP"); return (uint32_t)(e && *e ? atol(e) : 0); }();
-   a.exp = exp_bits;
    a.span_tickets = nullptr;
+   a.static_rounds = 0;
    // whole 4 KiB groups go to the span code, the ragged end to the bounds-checked one
    a.ngroups = g.nbytes / 4096;
    a.groups_per_span = groups_per_span;
@@ -1666,14 +1660,15 @@ static void fill_bucket_args(A &a, const MmGeom &g, const ResolveBuffers &rb)
    a.boverflow = rb.ctrl + MM_CTRL_BOVERFLOW; a.bshift = b.shift;
 }
 
-// MMOORE_SPAN_TICKETS=1: bucketed scans hand out spans through tickets (development knob).  Measured and NOT the
-// default: the ticket's round trip at every span boundary and the loss of "neighbouring waves stream neighbouring
-// spans" cost more than the balance gains -- streaming kernel alone 0.742 ms per 4 GiB against 0.705 static, scans in
-// flight 0.775 against 0.69 (profiles/r03_lane_gate_and_span_tickets.log).
-static bool span_tickets_enabled()
+// MMOORE_SPAN_TICKETS=p: the last p percent of a bucketed scan's spans are drawn through tickets instead of being
+// dealt out round by round (development knob; 0 / unset = all static).  Tickets for ALL spans were measured and are
+// worse: the ticket's round trip at every span boundary and the loss of "neighbouring waves stream neighbouring spans"
+// cost more than the balance gains -- streaming kernel alone 0.742 ms per 4 GiB against 0.705 static, scans in flight
+// 0.775 against 0.69 (profiles/r03_lane_gate_and_span_tickets.log).
+static int span_ticket_percent()
 {
-   static const bool on = [] { const char *e = getenv("MMOORE_SPAN_TICKETS"); return e && *e == '1'; }();
-   return on;
+   static const int p = [] { const char *e = getenv("MMOORE_SPAN_TICKETS"); return e && *e ? std::min(100, std::max(0, atoi(e))) : 0; }();
+   return p;
 }
 
 void launch_filter_buckets(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc, const ResolveBuffers &rb,
@@ -1687,7 +1682,14 @@ void launch_filter_buckets(hipStream_t st, const MmGeom &g, const mmh_plan_desc 
    fill_filter_args(a, g, pl, fc, rb.cand, rb.ctrl, rb.cand_cap, gps);
    fill_bucket_args(a, g, rb);
    // (the 64 list counters of the control block are idle in a bucketed scan: they hand out the spans)
-   a.span_tickets = span_tickets_enabled() ? rb.ctrl + MM_CTRL_LISTS : nullptr;
+   if (span_ticket_percent() > 0) {
+      const uint64_t nspans = (a.ngroups + gps - 1) / gps;
+      uint64_t spans = (nspans + 3) / 4;
+      const uint64_t nwaves = std::min<uint64_t>(spans, filter_max_blocks()) * 4;
+      const uint64_t rounds = (nspans + nwaves - 1) / nwaves;
+      a.span_tickets = rb.ctrl + MM_CTRL_LISTS;
+      a.static_rounds = (uint32_t)(rounds * (100 - span_ticket_percent()) / 100);
+   }
    with_shape(pl.elem_bytes, fc, [&](auto elem, auto shape) {
       constexpr int SHAPE = decltype(shape)::value;
       if constexpr (decltype(elem)::value == 1) {

@@ -19,6 +19,12 @@ shutil.copy(os.path.join(out, "bench_n1.json"), os.path.join(dst, tag + "_bench_
 stats1 = glob.glob(os.path.join(out, "stats_depth1", "**", "*kernel_stats.csv"), recursive=True)
 if stats1:
     shutil.copy(stats1[0], os.path.join(dst, tag + "_kernel_stats_depth1.csv"))
+for cfg in ("C3", "C4", "C4BE"):
+    sc = glob.glob(os.path.join(out, "stats_depth1_" + cfg, "**", "*kernel_stats.csv"), recursive=True)
+    if sc:
+        shutil.copy(sc[0], os.path.join(dst, "%s_kernel_stats_depth1_%s.csv" % (tag, cfg)))
+if os.path.exists(os.path.join(out, "bench_n1_driver_shape.json")):
+    shutil.copy(os.path.join(out, "bench_n1_driver_shape.json"), os.path.join(dst, tag + "_bench_n1_driver_shape.json"))
 
 
 def by_phase():
@@ -101,8 +107,8 @@ summary = {
     # bench.py reports `roofline.traffic` from this file only while the library's sources are THESE
     "device_source_sha16": device_source_sha16(),
     "library_sha16": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16],
-    "command_fetch": "rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 3 --warmup 1 --depth 1 --no-cpu-baseline --no-other-depth --prewarm-s 0.05",
-    "command_write": "rocprofv3 --pmc WRITE_SIZE --output-format csv -- python3 bench.py --steps 3 --warmup 1 --depth 1 --no-cpu-baseline --no-other-depth --prewarm-s 0.05",
+    "command_fetch": "rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 3 --warmup 1 --depth 1 --no-cpu-baseline --no-other-depth --no-other-configs --prewarm-s 0.05",
+    "command_write": "rocprofv3 --pmc WRITE_SIZE --output-format csv -- python3 bench.py --steps 3 --warmup 1 --depth 1 --no-cpu-baseline --no-other-depth --no-other-configs --prewarm-s 0.05",
     "note": "separate --pmc passes; counters are in KiB; per MI355X_MICROARCH.md gfx950 FETCH_SIZE reports half of the bytes of a "
             "wide coalesced (16 B/lane) streaming read, so the read side is doubled; WRITE_SIZE is exact "
             "(calibration: mm_synth_fill writes the whole ROM and reports exactly its size)",
