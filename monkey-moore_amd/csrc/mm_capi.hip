@@ -671,10 +671,15 @@ int finish_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev, 
          oc->candidates = w.h_result[0];
          if ((flags & 4) && (w.h_result[5] & 0xFFFFFFFFu) == 0 && oc->candidates != 0) {
             // a long list: the slots were only written to the device-side copy of the block (a PCIe write per slot
-            // would take longer than the scan): one copy brings them over
+            // would take longer than the scan): one copy brings them over.  On the context's own stream, behind the
+            // tail kernel's end event (the flag word shows before the kernel has retired and its stores are visible to
+            // a copy engine) -- NOT on the scan's stream: with scans in flight the next scan's streaming kernel is
+            // already queued there, and waiting for the copy would mean waiting for that scan (measured: C4 / C5,
+            // 8.2 - 8.5 K candidates, ran one scan at a time with three tickets outstanding).
+            HIP_TRY(hipStreamWaitEvent(c->own_stream, ev[2], 0));
             HIP_TRY(hipMemcpyAsync(w.h_result + kHeaderWords, w.d_result[w.result_turn] + kHeaderWords, oc->candidates * sizeof(uint64_t),
-                                   hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
+                                   hipMemcpyDeviceToHost, c->own_stream));
+            HIP_TRY(hipStreamSynchronize(c->own_stream));
          }
          oc->listed = oc->candidates;
          oc->tiles = w.h_result[2];

@@ -947,8 +947,8 @@ __device__ __forceinline__ void mm_stream_u16(const A &a)
          const uint4 *p = rom4 + gg * 256 + lane;
          w[d][0] = p[0]; w[d][1] = p[64]; w[d][2] = p[128]; w[d][3] = p[192];
       }
+      uint32_t flagged = 0;                                     // bit 4*(g - g0) + u: piece u of group g has stage-1 hits
       for (uint64_t g = g0; g < g1; g += DEPTH + 1) {
-         uint32_t pending = 0;                                  // bit 4*s + u: piece u of group g+s has stage-1 hits
 #pragma unroll
          for (int s = 0; s <= DEPTH; s++) {
             constexpr int RING = DEPTH + 1;
@@ -957,6 +957,7 @@ __device__ __forceinline__ void mm_stream_u16(const A &a)
             const uint4 *pn = rom4 + gn * 256 + lane;
             w[slot_new][0] = pn[0]; w[slot_new][1] = pn[64]; w[slot_new][2] = pn[128]; w[slot_new][3] = pn[192];
             if (g + s < g1) {
+               const uint32_t first_bit = 4u * (uint32_t)(g + s - g0);
 #pragma unroll
                for (int u = 0; u < 4; u++) {
                   // dwords -3..-1 of this chunk: lane l-1's y, z, w; lane 0 keeps the carries
@@ -969,27 +970,32 @@ __device__ __forceinline__ void mm_stream_u16(const A &a)
                   r[2] = __builtin_amdgcn_update_dpp(k3, w[s][u].w, 0x138, 0xf, 0xf, false);
                   r[3] = w[s][u].x; r[4] = w[s][u].y; r[5] = w[s][u].z; r[6] = w[s][u].w;
                   const uint32_t any = mm_f16_chunk_any<SHAPE>(r, be, a.pat);
-                  pending |= __ballot(any != 0) != 0 ? 1u << (4 * s + u) : 0u;
+                  flagged |= __ballot(any != 0) != 0 ? 1u << (first_bit + u) : 0u;
                }
                c1 = __builtin_amdgcn_readlane(w[s][3].y, 63);
                c2 = __builtin_amdgcn_readlane(w[s][3].z, 63);
                c3 = __builtin_amdgcn_readlane(w[s][3].w, 63);
             }
          }
-         // rare: all conditions on the flagged pieces, from a re-read (see mm_filter_u8)
-         while (pending) {
-            const uint32_t bit = (uint32_t)__builtin_ctz(pending);
-            pending &= pending - 1;
-            const uint64_t c = (g + (bit >> 2)) * 256 + (uint64_t)(bit & 3) * 64 + lane;     // 16-byte chunk number
-            const uint4 wu = rom4[c];
-            uint32_t r[7] = {0, 0, 0, wu.x, wu.y, wu.z, wu.w};
-            if (c) {
-               r[0] = rom1[c * 4 - 3]; r[1] = rom1[c * 4 - 2]; r[2] = rom1[c * 4 - 1];
-            }
-            uint32_t he[4], ho[4];
-            if (__ballot(mm_f16_chunk<SHAPE>(r, be, a.pat, he, ho) != 0) != 0) {
-               mm_f16_survivors(a, c * 16, mm_f16_pack(he, ho));
-            }
+      }
+      // Rare (~1.6 % of the pieces on random bytes): all conditions on the flagged pieces, behind the SPAN -- the ring
+      // registers are dead by then, so this code costs the streaming loop no registers: 71 VGPRs = 7 waves per SIMD
+      // instead of 73 = 6 with the bucketed store's code inside the loop (the next scan's streaming kernel then
+      // finds no slot beside this one).  From a re-read of the piece, like mm_stream_u8, whose 69 VGPRs leave the code
+      // where it was: the later re-read misses L2 more often, which costs a scan with 64 K candidates 20 us.
+      // (A span has at most 8 groups: 32 flag bits.)
+      while (flagged) {
+         const uint32_t bit = (uint32_t)__builtin_ctz(flagged);
+         flagged &= flagged - 1;
+         const uint64_t c = (g0 + (bit >> 2)) * 256 + (uint64_t)(bit & 3) * 64 + lane;     // 16-byte chunk number
+         const uint4 wu = rom4[c];
+         uint32_t r[7] = {0, 0, 0, wu.x, wu.y, wu.z, wu.w};
+         if (c) {
+            r[0] = rom1[c * 4 - 3]; r[1] = rom1[c * 4 - 2]; r[2] = rom1[c * 4 - 1];
+         }
+         uint32_t he[4], ho[4];
+         if (__ballot(mm_f16_chunk<SHAPE>(r, be, a.pat, he, ho) != 0) != 0) {
+            mm_f16_survivors(a, c * 16, mm_f16_pack(he, ho));
          }
       }
    }
@@ -1002,7 +1008,7 @@ __global__ __launch_bounds__(256) void mm_filter_u8(MmFilterArgs a)
 }
 
 template <int SHAPE>
-__global__ __launch_bounds__(256, 7) void mm_filter_u16(MmFilterArgs a)
+__global__ __launch_bounds__(256) void mm_filter_u16(MmFilterArgs a)
 {
    mm_stream_u16<SHAPE>(a);
 }
@@ -1287,7 +1293,7 @@ const Tuning &tuning()
       Tuning k;
       k.filter_max_conditions = (int)number("MMOORE_FILTER_MAXCOND", 4);
       k.filter_blocks = (uint64_t)number("MMOORE_FILTER_BLOCKS", 256 * 6);
-      k.filter_groups_per_span = (uint32_t)number("MMOORE_FILTER_GPS", 7);
+      k.filter_groups_per_span = (uint32_t)std::min<long>(number("MMOORE_FILTER_GPS", 7), 8);   // (a span's flagged pieces are 32 bits)
       k.resolve_blocks = (unsigned)number("MMOORE_RESOLVE_BLOCKS", 4096);
       // (mm_arrive_last counts arrivals in MM_ARRIVE_LINES - 1 groups of MM_ARRIVE_FAN: more workgroups would spill into the next lines)
       k.tail_blocks = (unsigned)std::min<long>(number("MMOORE_TAIL_BLOCKS", 2048), (long)MM_ARRIVE_FAN * (MM_ARRIVE_LINES - 1));
