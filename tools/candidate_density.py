@@ -46,8 +46,9 @@ def text_like_piece(rng):
                                    "over know water than call first people may down side been now find").split()]
     at = 0
     while at < rom.size - (8 << 20):
-        kind = rng.integers(0, 10)
-        n = int(rng.integers(64 << 10, 2 << 20))
+        # ~3 % text (a few MiB of script in a 256 MiB piece), ~8 % pointer tables, ~16 % padding, the rest stays random
+        kind = int(rng.choice([0, 4, 6, 7, 9], p=[0.10, 0.20, 0.20, 0.20, 0.30]))
+        n = int(rng.integers(64 << 10, 1 << 20))
         if kind < 4:                                          # text: words + blanks, at a base other than ASCII half the time
             k = n // 5
             idx = rng.integers(0, len(words), k)
@@ -107,7 +108,7 @@ eng_bytes = NPIECES * PIECE
 eng.alloc(eng_bytes)
 rng = np.random.default_rng(2026)
 print("# candidate density probe: %d GiB ROM, 512 KiB blocks, engine semantics" % (eng_bytes >> 30))
-for per_mib in (1, 16, 256, 4096):
+for per_mib in (1, 4, 16, 64, 256, 4096):
     rom = random_piece(rng)
     n = plant(rom, rng, "relativesrch", per_mib)
     for k in range(NPIECES):
