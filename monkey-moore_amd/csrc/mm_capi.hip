@@ -1463,31 +1463,24 @@ extern "C" int mmh_scan_submit(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t b
          // (a streaming kernel reads ~6 TB/s)
          mm::launch_gate(lane_st, (double)g.nbytes / 6.0e9 * gate_percent / 100.0);
       }
-      // How scans in flight share the device (rocprofv3 kernel trace, tools/lane_trace.sh).  Scan t starts
-      // behind scan t-2 (same stream) and runs beside scan t-1.  The tail kernel of t-2 (96 VGPRs) finds
-      // registers only here and there beside the streaming kernel of t-1 (6 waves x 72 VGPRs per SIMD leave
-      // 80) and takes ~0.54 ms from dispatch to end instead of 0.03; the streaming kernel of t, which waits
-      // for it, then starts ~0.12 ms before that of t-1 ends (a seventh streaming wave per SIMD does fit) and
-      // takes over as its waves finish.  Net: 0.70 ms per scan, the duration of ONE streaming kernel run
-      // alone -- tail kernel, result hand-over and the gaps between kernels cost nothing.  Three lanes
-      // (workspaces, result blocks) on the two streams, although only two scans are ever at work on the
-      // device: the third is the one the host has ALREADY enqueued -- with two, scan t could only be
-      // submitted once t-2 had been collected, ~0.12 ms before its kernel was due, and a host that was late
-      // (a busy box: 0.80 ms per scan measured) left the device waiting.
-      // Tried and dropped: a scan's filter waiting for the previous scan's "filter done" event (766-913 us
-      // per scan); all streaming kernels on one stream and the tail kernels on the lanes' (strictly
-      // consecutive filters, tail beside the next filter from its start: the tail takes 390 us instead of 29
-      // under the memory load and the filter 786 instead of 697 -- 0.80 ms per scan); a tail kernel of 80
-      // VGPRs, which does fit beside six streaming waves (0.712-0.732 ms with 256 .. 2048 workgroups of it
-      // against 0.702-0.706: a tail that runs beside a streaming kernel costs more than one that waits for
-      // its drain).
-      // (From an empty pipeline the first two scans start together and the stagger builds up over some tens of
-      // scans: 0.76 ms per scan over 20, 0.73 over 50, 0.70 over 200.  Holding scan t back until the streaming
-      // kernel of t-1 is 60 .. 95 % through its rounds, or until its first workgroups have finished -- it counts
-      // in a word, a gate wave in front of scan t's kernel polls it -- was tried: 0.725-0.76 ms per scan in the
-      // steady state at every threshold against 0.698 without; so was making the second scan of a burst wait
-      // for the end of the first one's streaming kernel: no better over 5 .. 50 scans.)
-      // (scan t-2 was enqueued on this very stream: stream order is that wait)
+      // How scans in flight share the device (MMOORE_LANE_TRACE=1; rocprofv3 kernel trace, tools/lane_trace.sh).  Scan t
+      // starts behind scan t-2 (same stream) and runs beside scan t-1: its streaming kernel begins on the wave slots
+      // the streaming kernel of t-1 leaves free (6 of 7 per SIMD) and takes over as that one's workgroups finish;
+      // the tail kernel of t-2 in front of it waits for a slot beside the two streaming kernels (~0.45 ms from
+      // dispatch to end for 27 us of work) -- which is what staggers the scans.  Net: 0.69 ms per 4 GiB scan in
+      // the steady state, below the duration of ONE streaming kernel run alone -- tail kernel, result hand-over and
+      // the gaps between kernels cost nothing.  Three lanes (workspaces, result blocks) on the two streams, although
+      // only two scans are ever at work on the device: the third is the one the host has ALREADY enqueued -- with
+      // two, scan t could only be submitted once t-2 had been collected, ~0.12 ms before its kernel was due, and a
+      // host that was late (a busy box: 0.80 ms per scan measured) left the device waiting.
+      // Measured and dropped (profiles/r03_lane_stream_arrangements.log, r02 notes): every streaming kernel on ONE
+      // stream and the tail kernels on a second one behind their end events (0.75-0.79 ms per scan: back-to-back
+      // kernels of one stream leave ~17 us between them, and nothing overlaps a kernel's drain); streaming kernels
+      // alternating on two streams with the tails on a third (0.73-0.75); a scan's filter waiting for the previous
+      // scan's "filter done" event (0.77-0.91); holding scan t back until the streaming kernel of t-1 is 60 .. 95 %
+      // through its rounds (0.725-0.76).  What did help in round 3: a tail kernel that fits beside a streaming
+      // kernel (mm_scan_tail2, 61 VGPRs) on a small grid (512 workgroups), and the gate above for the second scan of
+      // a burst -- 0.711-0.724 ms per scan over the first 20 scans from an empty pipeline (round 2: 0.745-0.76).
       settle_lane_timing(c, lane);             // (before the lane's events are recorded again)
       for (auto &e : c->lane_ev[lane]) {
          if (!e) {
