@@ -501,6 +501,19 @@ def test_rom_from_file_and_gather(mm, gpu_engine, oracle, tmp_path):
         gpu_engine.load_file(str(tmp_path / "missing.bin"), 0, 16)
     with pytest.raises(mm.MMError):
         gpu_engine.load_file(str(path), data.size - 10, 100)  # runs off the end of the file: short read
+    # the watched load (mmh_rom_load_file_watched): bytes landed, and an abort word that is already up
+    import ctypes
+    done, stop = ctypes.c_uint64(123), ctypes.c_int32(0)
+    gpu_engine.load_file(str(path), 0, data.size, 4, abort_word=stop, bytes_done=done)
+    assert done.value == data.size
+    assert gpu_engine.scan(plan, block_bytes=524288).tolist() == got.tolist()
+    stop.value = 1
+    with pytest.raises(mm.MMError) as err:
+        gpu_engine.load_file(str(path), 0, data.size, 4, abort_word=stop, bytes_done=done)
+    assert err.value.code == mm.MMH_E_ABORTED and done.value < data.size
+    # ... after which the context loads and scans as before (copies the aborted load left in flight are drained first)
+    gpu_engine.load_file(str(path), 0, data.size)
+    assert gpu_engine.scan(plan, block_bytes=524288).tolist() == got.tolist()
 
 
 @pytest.mark.parametrize("depth", [2, 3])
