@@ -49,7 +49,7 @@ constexpr uint64_t MM_RESULT_HEADER_WORDS = 8;
 constexpr uint32_t MM_MAX_RANK_SORT = 16384;      // longest list the rank kernels / the single-launch kernel order (and a gather record holds)
 // slots the published block holds: the tail kernel behind the bucketed filter (mm_tail2.h) ranks a candidate with
 // two loads whatever their number, so it orders far longer lists than the count-the-smaller-ones kernels above
-constexpr uint32_t MM_MAX_PUBLISH = 131072;
+constexpr uint32_t MM_MAX_PUBLISH = 262144;
 // ... up to this many candidates every slot is also stored straight into pinned host memory (one PCIe write each: the
 // host has the list the moment the flag word changes); beyond, the slots only exist in the device-side copy and the
 // host fetches them with one DMA copy (a hundred thousand 8-byte PCIe writes would take longer than the scan)
@@ -67,7 +67,11 @@ constexpr uint64_t MM_RESULT_BLOCK_WORDS = MM_HDR_FLAG_WORD + 8;
 //     candidates in the buckets before its own  +  members of its own bucket with a smaller offset
 // -- a scan over the 64 super-bucket sums (once per workgroup), one over the 64 counters of its super-bucket and a ballot
 // over its bucket's members, instead of comparing it with every other candidate.
-constexpr uint32_t MM_BUCKET_CAP = 1024;          // candidates a bucket holds (more: the scan takes the list-based path)
+// candidates a bucket holds (more: the scan starts over with the list-based kernels).  Generous on purpose -- 128 MiB per
+// workspace: a common word in a ROM's script sits every few hundred bytes (profiles/r03_candidate_density.log: 'water',
+// 2000 per MiB of text), and ranking a candidate against a crowded bucket (members / 64 loads) is cheap next to a second
+// pass over the ROM
+constexpr uint32_t MM_BUCKET_CAP = 4096;
 constexpr uint32_t MM_MAX_BUCKETS = 4096;         // (every workgroup of mm_scan_tail2 sums all the counters: 16 KiB from L2)
 constexpr uint32_t MM_SUPER = 64;                 // buckets per super-bucket
 constexpr uint32_t MM_MIN_BUCKET_SHIFT = 12;

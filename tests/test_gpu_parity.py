@@ -243,9 +243,9 @@ def test_many_matches_stay_on_the_resolver_path(mm, gpu_engine, oracle):
 @pytest.mark.parametrize("nplants,elem", [(9000, 1), (70000, 1), (150000, 1), (50000, 2)])
 def test_bucketed_store_list_lengths(mm, gpu_engine, oracle, nplants, elem):
     """Big ROMs drop candidates into buckets of their ROM neighbourhood and mm_scan_tail2 ranks them from there
-    (csrc/mm_tail2.h): lists of up to 8192 slots are written straight into pinned memory, longer ones (up to 131072) are
-    fetched from the device-side copy, beyond that the list-based kernels take over -- through mmh_scan, through the
-    submit lanes, and one chain over the whole buffer; a few plants wrap around (candidates that are no matches: holes)."""
+    (csrc/mm_tail2.h): lists of up to 8192 slots are written straight into pinned memory, longer ones (up to 262144) are
+    fetched from the device-side copy -- through mmh_scan, through the submit lanes, and one chain over the whole
+    buffer; a few plants wrap around (candidates that are no matches: holes)."""
     rng = np.random.default_rng(nplants)
     kw = "bucket"
     rom = _random_rom_with_plants(rng, 64 << 20, elem, [ord(c) for c in kw], False, nplants=nplants)
@@ -266,6 +266,30 @@ def test_bucketed_store_list_lengths(mm, gpu_engine, oracle, nplants, elem):
     data = rom if elem == 1 else rom.view("<u2")
     assert gpu_engine.scan(plan, cap=1 << 18).tolist() == oracle.search(oplan, data).tolist()
     assert gpu_engine.scan(plan, block_bytes=524288, cap=100).tolist() == want.tolist()      # MMH_E_CAPACITY, retried bigger
+
+
+def test_crowded_bucket_takes_the_list_based_kernels(mm, gpu_engine, oracle):
+    """More candidates in one ROM neighbourhood than a bucket holds (4096 per 128 KiB of a 512 MiB ROM: a 3-symbol keyword
+    planted every 16 bytes over 256 KiB): mm_scan_tail2 resolves nothing, the scan starts over with the list-based
+    kernels and still reports exactly the reference's offsets -- through mmh_scan and through the submit lanes."""
+    from _oracle import oracle_engine_parallel
+    rng = np.random.default_rng(4096)
+    n = 512 << 20
+    rom = rng.integers(0, 256, n, dtype=np.uint8)
+    at = (300 << 20) + 776          # (even: with this keyword every jump of the reference's chain is 2 -- odd positions are never visited)
+    for k in range(16384):
+        base = int(rng.integers(0, 200))
+        rom[at + 16 * k: at + 16 * k + 3] = [base + 10, base + 11, base + 12]          # 'klm' shifted: deltas +1, +1
+    kw = "klm"
+    gpu_engine.upload(rom)
+    plan, oplan = mm.plan_relative(1, kw), oracle.plan(1, kw)
+    want = oracle_engine_parallel(oracle, oplan, rom, 524288)
+    got = gpu_engine.scan(plan, block_bytes=524288, cap=1 << 17)
+    ctr = gpu_engine.counters()
+    assert got.tolist() == want.tolist() and len(want) > 16384
+    assert ctr["path"] in (0, 2, 4, 5), ctr
+    t = gpu_engine.submit(plan, block_bytes=524288)
+    assert gpu_engine.collect(t, cap=1 << 17).tolist() == want.tolist()
 
 
 def test_low_entropy_alphabets(mm, gpu_engine, oracle):
