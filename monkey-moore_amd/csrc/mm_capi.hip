@@ -1424,12 +1424,14 @@ extern "C" int mmh_scan_submit(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t b
    if (!c->lane_fence) {
       HIP_TRY(hipEventCreateWithFlags(&c->lane_fence, hipEventDisableTiming));
    }
-   // Scans in flight share the device best half a streaming kernel apart: the tail kernel of one runs while the other
-   // streams.  From an empty pipeline the first two scans would start together, END together -- both tail kernels then run
-   // with nothing streaming beside them -- and their successors start together again: the pairs only drift apart over
-   // some tens of scans (0.74 ms per 4 GiB scan over the first 20, 0.70 in the steady state).  So the second scan of
-   // a burst is held back by a gate (one sleeping wave in front of its streaming kernel) for MMOORE_LANE_GATE percent
-   // (default 50) of the time a streaming kernel takes: the stagger is there from the start.
+   // Scans in flight share the device best a good part of a streaming kernel apart: the tail kernel of one runs while
+   // the other streams.  From an empty pipeline the first two scans start together; MMOORE_LANE_GATE=p (development
+   // knob) holds the second scan of a burst back by a gate -- one sleeping wave in front of its streaming kernel -- for
+   // p percent of the time a streaming kernel takes.  Measured with round 3's lean tail kernel over five runs per
+   // setting (profiles/r03_lane_gate_repeats.log): 0 / 35 / 50 / 65 / 80 / 100 percent give 0.725-0.735 ms per scan
+   // over the first 20 scans on a box whose steady state is 0.70 -- no difference that shows through the +-1 % run-to-run
+   // spread (the lean tail lets the stagger form within two or three scans by itself).  Default: off -- a burst of
+   // two scans would only finish later for it.
    int others = 0;
    bool behind_first = false;
    for (const MmPending &q : c->pending) {
@@ -1458,7 +1460,7 @@ extern "C" int mmh_scan_submit(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t b
       // the ROM may still be in the making on the context's stream (upload, synth, poke)
       HIP_TRY(hipEventRecord(c->lane_fence, c->stream));
       HIP_TRY(hipStreamWaitEvent(lane_st, c->lane_fence, 0));
-      static const int gate_percent = [] { const char *e = getenv("MMOORE_LANE_GATE"); return e && *e ? atoi(e) : 50; }();
+      static const int gate_percent = [] { const char *e = getenv("MMOORE_LANE_GATE"); return e && *e ? atoi(e) : 0; }();
       if (gated && gate_percent > 0) {
          // (a streaming kernel reads ~6 TB/s)
          mm::launch_gate(lane_st, (double)g.nbytes / 6.0e9 * gate_percent / 100.0);
@@ -1478,9 +1480,10 @@ extern "C" int mmh_scan_submit(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t b
       // kernels of one stream leave ~17 us between them, and nothing overlaps a kernel's drain); streaming kernels
       // alternating on two streams with the tails on a third (0.73-0.75); a scan's filter waiting for the previous
       // scan's "filter done" event (0.77-0.91); holding scan t back until the streaming kernel of t-1 is 60 .. 95 %
-      // through its rounds (0.725-0.76).  What did help in round 3: a tail kernel that fits beside a streaming
-      // kernel (mm_scan_tail2, 61 VGPRs) on a small grid (512 workgroups), and the gate above for the second scan of
-      // a burst -- 0.711-0.724 ms per scan over the first 20 scans from an empty pipeline (round 2: 0.745-0.76).
+      // through its rounds (0.725-0.76); a gate in front of the second scan of a burst (above: no measurable difference).
+      // What did help in round 3: a tail kernel that fits beside a streaming kernel (mm_scan_tail2, 61 VGPRs) on a
+      // small grid (512 workgroups) -- 0.71-0.735 ms per scan over the first 20 scans from an empty pipeline over
+      // boxes and runs (round 2: 0.745-0.76).
       settle_lane_timing(c, lane);             // (before the lane's events are recorded again)
       for (auto &e : c->lane_ev[lane]) {
          if (!e) {
