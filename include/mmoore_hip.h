@@ -113,11 +113,15 @@ int mmh_rom_load_file(mmh_ctx *ctx, const char *path, uint64_t file_offset, uint
 /* The same load, watched from another thread -- the reference's dispatcher polls its abort flag between blocks and
  * reports progress per block while the workers read (src/core/search_engine.cpp:161-187); here the bulk of a
  * file search's time is this ingest, so it is what has to be interruptible and observable:
- *   abort_word  (may be NULL) is read before every 4 MiB piece; once it is non-zero the readers stop, the copies
- *               already queued are drained and the call returns MMH_E_ABORTED (the ROM's contents are then undefined);
- *   bytes_done  (may be NULL) is set to 0 at the start and raised by the size of every piece whose read has finished
- *               and whose host-to-device copy has been queued (monotone; nbytes once a load has succeeded).
- * Both words are accessed with relaxed atomic loads / adds; the caller polls bytes_done from its own thread. */
+ *   abort_word  (may be NULL) is read every 0.1 ms by the calling thread, which then only supervises the readers; once
+ *               it is non-zero the readers are told to stop and the call returns MMH_E_ABORTED at once (measured:
+ *               0.1-0.5 ms after the word went up) -- without waiting for readers that sit inside a blocking call or
+ *               for copies already queued; those are waited for before the ROM or the staging buffers are used again
+ *               (the next load, scan, or mmh_destroy), and that wait is itself called off by the next load's abort
+ *               word.  The ROM's contents are undefined after an abort.  Neither word is touched once the call is back;
+ *   bytes_done  (may be NULL) is set to 0 at the start and follows the bytes whose read has finished and whose
+ *               host-to-device copy has been queued (monotone; nbytes once a load has succeeded).
+ * Both words are accessed with relaxed atomic loads / stores; the caller polls bytes_done from its own thread. */
 int mmh_rom_load_file_watched(mmh_ctx *ctx, const char *path, uint64_t file_offset, uint64_t nbytes, int threads,
                               const volatile int32_t *abort_word, volatile uint64_t *bytes_done);
 /* wall time, size and reader count of the last mmh_rom_load_file */

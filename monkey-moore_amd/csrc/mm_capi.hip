@@ -1167,7 +1167,9 @@ MmGeom scan_geometry(const mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block
 // Lists beyond kMaxRankSort entries are ordered by the radix sort of mm_sort.hip.
 uint32_t candidate_limit(const MmWorkspace &w)
 {
-   return (uint32_t)std::min<uint64_t>(mm::tuning().max_candidates, w.cand_cap / 2);
+   // (round 3: what the bucketed path takes -- one result slot per candidate; the list-based kernels notice by themselves
+   // when one of their 64 lists overflows, which sends the scan on to the flood / forward paths)
+   return (uint32_t)std::min<uint64_t>(mm::tuning().max_candidates, w.out_cap);
 }
 
 } // namespace

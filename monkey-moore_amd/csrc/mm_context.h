@@ -7,6 +7,9 @@
 
 #include <stdint.h>
 
+#include <atomic>
+#include <memory>
+#include <thread>
 #include <vector>
 
 #include "mmoore_hip.h"
@@ -18,6 +21,8 @@ struct MmIngest {
    std::vector<hipEvent_t> events;
    std::vector<hipStream_t> streams;
    bool undrained = false;           // an aborted load left copies in flight on `streams` (mm_ingest_drain)
+   std::vector<std::thread> stragglers;   // ... and possibly readers inside a blocking call (joined by mm_ingest_drain)
+   std::shared_ptr<std::atomic<int>> straggling;   // how many of them are still at it
    double last_seconds = 0;
    uint64_t last_bytes = 0;
    int last_threads = 0;

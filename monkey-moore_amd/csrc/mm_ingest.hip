@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -68,23 +69,139 @@ bool ingest_resources(mmh_ctx *c, int threads, std::string *err)
 
 } // namespace
 
-// copies an aborted load left in flight: wait for them before the ROM or the staging buffers are used again
-int mm_ingest_drain(mmh_ctx *c)
-{
-   if (c && c->ingest.undrained) {
-      c->ingest.undrained = false;
-      if (hipSetDevice(c->device) != hipSuccess) {
-         return MMH_E_DEVICE;
-      }
-      for (hipStream_t s : c->ingest.streams) {
-         if (hipStreamSynchronize(s) != hipSuccess) {
-            mmh_set_error("draining an aborted file load failed");
-            return MMH_E_DEVICE;
-         }
+// One load: what its readers share.  It lives on the heap and the readers hold it by shared_ptr, because an aborted
+// load returns to its caller while readers may still sit inside a blocking call (measured on the MI355X box: a
+// reader's first hipMemcpyAsync of a load occasionally blocks for 9-33 ms); such stragglers finish against this
+// block -- never against the caller's abort word or byte counter, which may be gone by then.
+struct LoadJob {
+   mmh_ctx *c = nullptr;
+   std::string path;
+   uint64_t file_offset = 0, nbytes = 0, npieces = 0;
+   std::atomic<uint64_t> next{0}, bytes_done{0};
+   std::atomic<int> running{0};
+   std::atomic<bool> failed{false}, stop{false};
+   std::mutex err_lock;
+   std::string err;
+
+   void give_up(const std::string &why)
+   {
+      std::lock_guard<std::mutex> hold(err_lock);
+      if (!failed.exchange(true)) {
+         err = why;
       }
    }
+};
+
+static void read_pieces(std::shared_ptr<LoadJob> job, int t)
+{
+   LoadJob &j = *job;
+   MmIngest &in = j.c->ingest;
+   struct Leave {
+      LoadJob &j;
+      ~Leave() { j.running--; }
+   } leave{j};
+   if (hipSetDevice(j.c->device) != hipSuccess) {
+      return j.give_up("hipSetDevice failed in a reader thread");
+   }
+   const int fd = open(j.path.c_str(), O_RDONLY);
+   if (fd < 0) {
+      return j.give_up(std::string("cannot open ") + j.path + ": " + strerror(errno));
+   }
+   const uint64_t piece = MmIngest::kPiece;
+   bool used[2] = {false, false};
+   for (unsigned turn = 0; !j.failed && !j.stop; turn++) {
+      const uint64_t k = j.next.fetch_add(1);
+      if (k >= j.npieces) {
+         break;
+      }
+      const int slot = 2 * t + (int)(turn & 1);
+      if (used[turn & 1] && hipEventSynchronize(in.events[slot]) != hipSuccess) {
+         j.give_up("hipEventSynchronize failed");
+         break;
+      }
+      const uint64_t at = k * piece;
+      const uint64_t len = std::min(piece, j.nbytes - at);
+      uint8_t *dst = static_cast<uint8_t *>(in.staging[slot]);
+      uint64_t got = 0;
+      while (got < len && !j.stop) {
+         // (1 MiB per call: a reader is never more than ~0.3 ms of reading away from seeing the stop flag)
+         const ssize_t r = pread(fd, dst + got, std::min<uint64_t>(len - got, 1u << 20), (off_t)(j.file_offset + at + got));
+         if (r < 0 && errno == EINTR) {
+            continue;
+         }
+         if (r <= 0) {
+            j.give_up(r == 0 ? std::string("short read from ") + j.path : std::string("read error on ") + j.path + ": " + strerror(errno));
+            break;
+         }
+         got += (uint64_t)r;
+      }
+      if (got < len) {
+         break;
+      }
+      if (hipMemcpyAsync(j.c->rom + at, dst, len, hipMemcpyHostToDevice, in.streams[t]) != hipSuccess ||
+          hipEventRecord(in.events[slot], in.streams[t]) != hipSuccess) {
+         j.give_up("host-to-device copy failed");
+         break;
+      }
+      used[turn & 1] = true;
+      j.bytes_done += len;
+   }
+   // A stopped load does not wait for the copies it has queued (up to two pieces per reader): the caller wants its
+   // thread back now.  They are drained before the staging buffers or the ROM are touched again (mm_ingest_drain).
+   if (!j.stop && hipStreamSynchronize(in.streams[t]) != hipSuccess) {
+      j.give_up("hipStreamSynchronize failed in a reader thread");
+   }
+   close(fd);
+}
+
+// what an aborted load left behind: readers still inside a blocking call, copies in flight -- wait for both before the
+// ROM or the staging buffers are used again.  With an abort word the wait itself can be called off (MMH_E_ABORTED,
+// everything still undrained): the next load of a search that was aborted a moment ago is aborted just as promptly.
+static int drain_watched(mmh_ctx *c, const volatile int32_t *abort_word)
+{
+   if (!c || !c->ingest.undrained) {
+      return MMH_OK;
+   }
+   MmIngest &in = c->ingest;
+   auto called_off = [&]() {
+      if (abort_word && __atomic_load_n(abort_word, __ATOMIC_RELAXED) != 0) {
+         mmh_set_error("mmh_rom_load_file: aborted by the caller");
+         return true;
+      }
+      return false;
+   };
+   while (abort_word && in.straggling && in.straggling->load() > 0) {
+      if (called_off()) {
+         return MMH_E_ABORTED;
+      }
+      std::this_thread::sleep_for(std::chrono::microseconds(100));
+   }
+   for (auto &th : in.stragglers) {
+      th.join();
+   }
+   in.stragglers.clear();
+   in.straggling.reset();
+   if (hipSetDevice(c->device) != hipSuccess) {
+      return MMH_E_DEVICE;
+   }
+   for (hipStream_t s : in.streams) {
+      hipError_t e;
+      while (abort_word && (e = hipStreamQuery(s)) == hipErrorNotReady) {
+         if (called_off()) {
+            return MMH_E_ABORTED;
+         }
+         std::this_thread::sleep_for(std::chrono::microseconds(50));
+      }
+      if (hipStreamSynchronize(s) != hipSuccess) {
+         mmh_set_error("draining an aborted file load failed");
+         return MMH_E_DEVICE;
+      }
+   }
+   in.undrained = false;
    return MMH_OK;
 }
+
+int mm_ingest_drain(mmh_ctx *c) { return drain_watched(c, nullptr); }
 
 extern "C" int mmh_rom_load_file(mmh_ctx *c, const char *path, uint64_t file_offset, uint64_t nbytes, int threads)
 {
@@ -102,7 +219,7 @@ extern "C" int mmh_rom_load_file_watched(mmh_ctx *c, const char *path, uint64_t 
       __atomic_store_n(bytes_done, (uint64_t)0, __ATOMIC_RELAXED);
    }
    const auto t0 = std::chrono::steady_clock::now();
-   int rc = mm_ingest_drain(c);
+   int rc = drain_watched(c, abort_word);
    if (rc != MMH_OK) {
       return rc;
    }
@@ -134,100 +251,78 @@ extern "C" int mmh_rom_load_file_watched(mmh_ctx *c, const char *path, uint64_t 
    }
    close(probe);
 
-   std::atomic<uint64_t> next{0};
-   std::atomic<bool> failed{false}, aborted{false};
-   std::mutex err_lock;
+   auto job = std::make_shared<LoadJob>();
+   job->c = c;
+   job->path = path;
+   job->file_offset = file_offset;
+   job->nbytes = nbytes;
+   job->npieces = npieces;
+   job->running = threads;
    MmIngest &in = c->ingest;
-   auto reader = [&](int t) {
-      auto give_up = [&](const std::string &why) {
-         std::lock_guard<std::mutex> hold(err_lock);
-         if (!failed.exchange(true)) {
-            err = why;
+   // The calling thread reads pieces too unless it has an abort word to watch: then it only supervises -- it carries
+   // the caller's word in and the byte count out every 0.1 ms and leaves the moment the word is up.
+   const bool supervise = abort_word != nullptr;
+   std::vector<std::thread> pool;
+   for (int t = supervise ? 0 : 1; t < threads; t++) {
+      pool.emplace_back(read_pieces, job, t);
+   }
+   bool aborted = false;
+   if (!supervise) {
+      read_pieces(job, 0);
+      if (bytes_done) {
+         __atomic_store_n(bytes_done, job->bytes_done.load(), __ATOMIC_RELAXED);
+      }
+   }
+   else {
+      const auto poll_start = std::chrono::steady_clock::now();
+      for (;;) {
+         if (bytes_done) {
+            __atomic_store_n(bytes_done, job->bytes_done.load(), __ATOMIC_RELAXED);
          }
-      };
-      if (hipSetDevice(c->device) != hipSuccess) {
-         return give_up("hipSetDevice failed in a reader thread");
-      }
-      const int fd = open(path, O_RDONLY);
-      if (fd < 0) {
-         return give_up(std::string("cannot open ") + path + ": " + strerror(errno));
-      }
-      bool used[2] = {false, false};
-      for (unsigned turn = 0; !failed && !aborted; turn++) {
-         // the caller's abort word, once per piece (a piece is ~1 ms of reading)
-         if (abort_word && __atomic_load_n(abort_word, __ATOMIC_RELAXED) != 0) {
+         if (job->running == 0) {
+            break;
+         }
+         if (__atomic_load_n(abort_word, __ATOMIC_RELAXED) != 0) {
+            job->stop = true;
             aborted = true;
             break;
          }
-         const uint64_t k = next.fetch_add(1);
-         if (k >= npieces) {
-            break;
+         // (small files are in HBM within microseconds: spin first, sleep once the load turns out to take a while)
+         if (std::chrono::steady_clock::now() - poll_start < std::chrono::microseconds(300)) {
+            std::this_thread::yield();
          }
-         const int slot = 2 * t + (int)(turn & 1);
-         if (used[turn & 1] && hipEventSynchronize(in.events[slot]) != hipSuccess) {
-            give_up("hipEventSynchronize failed");
-            break;
-         }
-         const uint64_t at = k * piece;
-         const uint64_t len = std::min(piece, nbytes - at);
-         uint8_t *dst = static_cast<uint8_t *>(in.staging[slot]);
-         uint64_t got = 0;
-         while (got < len) {
-            const ssize_t r = pread(fd, dst + got, len - got, (off_t)(file_offset + at + got));
-            if (r < 0 && errno == EINTR) {
-               continue;
-            }
-            if (r <= 0) {
-               give_up(r == 0 ? std::string("short read from ") + path : std::string("read error on ") + path + ": " + strerror(errno));
-               break;
-            }
-            got += (uint64_t)r;
-         }
-         if (got < len) {
-            break;
-         }
-         if (hipMemcpyAsync(c->rom + at, dst, len, hipMemcpyHostToDevice, in.streams[t]) != hipSuccess ||
-             hipEventRecord(in.events[slot], in.streams[t]) != hipSuccess) {
-            give_up("host-to-device copy failed");
-            break;
-         }
-         used[turn & 1] = true;
-         if (bytes_done) {
-            __atomic_fetch_add(bytes_done, len, __ATOMIC_RELAXED);
+         else {
+            std::this_thread::sleep_for(std::chrono::microseconds(100));
          }
       }
-      // An aborted load does not wait for the copies it has queued (up to two pieces per reader): the caller wants
-      // its thread back now.  They are drained before the staging buffers or the ROM are touched again (mm_ingest_drain).
-      if (!aborted && hipStreamSynchronize(in.streams[t]) != hipSuccess) {
-         give_up("hipStreamSynchronize failed in a reader thread");
-      }
-      close(fd);
-   };
-   std::vector<std::thread> pool;
-   for (int t = 1; t < threads; t++) {
-      pool.emplace_back(reader, t);
    }
-   reader(0);
-   for (auto &th : pool) {
-      th.join();
+   if (aborted) {
+      for (auto &th : pool) {
+         in.stragglers.push_back(std::move(th));
+      }
+      in.straggling = std::shared_ptr<std::atomic<int>>(job, &job->running);
+      in.undrained = true;
+   }
+   else {
+      for (auto &th : pool) {
+         th.join();
+      }
    }
    in.last_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
    in.last_bytes = nbytes;
    in.last_threads = threads;
    if (aborted) {
-      in.undrained = true;
       static const bool trace = getenv("MMOORE_INGEST_TRACE") != nullptr;
       if (trace) {
-         fprintf(stderr, "mmh_rom_load_file: aborted after %.2f ms, %d readers joined\n", in.last_seconds * 1e3, threads);
+         fprintf(stderr, "mmh_rom_load_file: aborted after %.2f ms, %d of %d readers still busy\n", in.last_seconds * 1e3,
+                 job->running.load(), threads);
       }
-   }
-   if (aborted && !failed) {
       mmh_set_error("mmh_rom_load_file: aborted by the caller");
       return MMH_E_ABORTED;
    }
-   if (failed) {
-      mmh_set_error("mmh_rom_load_file: %s", err.c_str());
-      return err.find("short read") != std::string::npos || err.find("cannot open") != std::string::npos ? MMH_E_ARG : MMH_E_DEVICE;
+   if (job->failed) {
+      mmh_set_error("mmh_rom_load_file: %s", job->err.c_str());
+      return job->err.find("short read") != std::string::npos || job->err.find("cannot open") != std::string::npos ? MMH_E_ARG : MMH_E_DEVICE;
    }
    return MMH_OK;
 }

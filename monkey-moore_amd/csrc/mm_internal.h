@@ -49,7 +49,7 @@ constexpr uint64_t MM_RESULT_HEADER_WORDS = 8;
 constexpr uint32_t MM_MAX_RANK_SORT = 16384;      // longest list the rank kernels / the single-launch kernel order (and a gather record holds)
 // slots the published block holds: the tail kernel behind the bucketed filter (mm_tail2.h) ranks a candidate with
 // two loads whatever their number, so it orders far longer lists than the count-the-smaller-ones kernels above
-constexpr uint32_t MM_MAX_PUBLISH = 262144;
+constexpr uint32_t MM_MAX_PUBLISH = 1048576;
 // ... up to this many candidates every slot is also stored straight into pinned host memory (one PCIe write each: the
 // host has the list the moment the flag word changes); beyond, the slots only exist in the device-side copy and the
 // host fetches them with one DMA copy (a hundred thousand 8-byte PCIe writes would take longer than the scan)

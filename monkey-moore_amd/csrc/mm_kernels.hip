@@ -1300,7 +1300,7 @@ const Tuning &tuning()
       // (scans in flight: a small tail grid beside the next scan's streaming kernel -- 512 workgroups: 0.687-0.689 ms per 4 GiB
       // scan in the steady state against 0.695-0.696 with 2048, profiles/r03_lane_gate_and_span_tickets.log)
       k.lane_tail_blocks = (unsigned)std::min<long>(number("MMOORE_LANE_TAIL_BLOCKS", 512), (long)MM_ARRIVE_FAN * (MM_ARRIVE_LINES - 1));
-      k.max_candidates = (uint32_t)number("MMOORE_MAX_CANDIDATES", 262144);
+      k.max_candidates = (uint32_t)number("MMOORE_MAX_CANDIDATES", 1048576);
       return k;
    }();
    return t;

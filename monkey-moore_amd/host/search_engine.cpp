@@ -270,7 +270,8 @@ std::vector<mmoore::SearchResult<DataType>> mmoore::SearchEngine<DataType>::run(
       // threads of their own, this thread polls what has landed -- one progress tick per reference block whose bytes
       // are in HBM, like the reference's workers tick as they finish blocks (search_engine.cpp:161-165) -- and
       // raises the loaders' abort word as soon as the caller's flag is up (:177-187: polled every 5 ms there;
-      // here every 0.2 ms, and the readers look at the word before every 4 MiB piece).
+      // here every 0.2 ms; the library's supervising thread looks at the word every 0.1 ms and returns without
+      // waiting for readers inside a blocking call -- measured 0.1-0.5 ms from flag to return on a 4 GiB file).
       std::vector<std::string> load_error(ctxs.size());
       std::vector<int> load_rc(ctxs.size(), MMH_OK);
       std::vector<uint64_t> landed(ctxs.size(), 0);           // raised by the library (relaxed atomics)

@@ -192,48 +192,60 @@ def test_fuzz_long_keywords(mm, gpu_engine, oracle, seed):
         assert gpu_engine.scan(plan, cap=1 << 12).tolist() == oracle.search(oplan, data).tolist(), (seed, case, L, kw, "whole")
 
 
+def _path_report():
+    return {"%s,%d" % k: n for k, n in sorted(PATH_HITS.items())}
+
+
 def test_fuzz_reached_every_engine_path():
     """Over the default seeds every engine path must have been taken often enough to mean something: 0 filter + resolver,
-    2 + hard resolver, 3 forward engine on everything, 4 forward engine on flagged domains, 5 candidate floods -- through
-    the single-launch kernel, through streaming + tail kernel, and through the submit lanes (whose collect rescans
-    synchronously whatever the lanes do not run themselves: their counters then report that scan's path)."""
+    2 + hard resolver, 3 forward engine on everything, 4 forward engine on flagged domains -- through the single-launch
+    kernel, through streaming + tail kernel, and through the submit lanes (whose collect rescans synchronously whatever
+    the lanes do not run themselves: their counters then report that scan's path).  Path 5 (candidate floods) needs more
+    than a million candidates since round 3, which ROMs of these sizes do not hold: see the next test."""
     print("engine paths taken (route, path): scans --", dict(sorted(PATH_HITS.items())))
+    report = os.environ.get("MM_FUZZ_REPORT")
+    if report:
+        import json
+        with open(report, "w") as f:
+            json.dump(_path_report(), f)
     if SEEDS < 400 or MEDIUM < 32:
         pytest.skip("fewer seeds than the default: no counts to hold")
     by_path = collections.Counter()
     for (route, path), n in PATH_HITS.items():
         by_path[path] += n
-    # (measured with the default seeds: 22898 / 858 / 162 / 114 / 16 scans; the seeds are fixed, so these only move with the code)
-    floor = {0: 10000, 2: 400, 3: 100, 4: 60, 5: 10}
+    # (measured with the default seeds: 23010 / 830 / 94 / 114 scans; the seeds are fixed, so these only move with the code)
+    floor = {0: 10000, 2: 400, 3: 60, 4: 60}
     for path, least in floor.items():
         assert by_path[path] >= least, (path, by_path[path], least, dict(PATH_HITS))
     for route in ("fused", "plain", "lanes"):
         assert PATH_HITS[(route, 0)] >= 20, (route, dict(PATH_HITS))
     # the rare paths through more than one route
     assert sum(1 for route in ("fused", "plain", "lanes") if PATH_HITS[(route, 3)] > 0) >= 2, dict(PATH_HITS)
-    assert sum(1 for route in ("fused", "plain", "lanes") if PATH_HITS[(route, 5)] + PATH_HITS[(route, 4)] > 0) >= 2, dict(PATH_HITS)
+    assert sum(1 for route in ("fused", "plain", "lanes") if PATH_HITS[(route, 4)] > 0) >= 2, dict(PATH_HITS)
 
 
-VALUE_CASES = int(os.environ.get("MM_FUZZ_VALUES", "12"))   # raise for a soak
-
-
-def test_fuzz_value_scan(mm, gpu_engine, oracle):
-    rng = np.random.default_rng(99)
-    for case in range(VALUE_CASES):
-        elem = int(rng.choice([1, 2]))
-        vals = [int(v) for v in rng.integers(-40, 41, int(rng.integers(2, 9)))]
-        oplan, plan = oracle.plan_values(elem, vals), mm.plan_value_scan(elem, vals)
-        n = int(rng.choice([5000, 300000])) // elem
-        hi = 256 if elem == 1 else 65536
-        d = rng.integers(0, int(rng.choice([4, 64, hi])), n).astype(np.int64) + 60
-        for _ in range(30):
-            pos = int(rng.integers(0, n - len(vals) - 1))
-            x = int(rng.integers(60, 150))
-            for j, v in enumerate([0] + vals):
-                d[pos + j] = x = x + v if j else x
-        rom = d.astype(np.uint8 if elem == 1 else "<u2").view(np.uint8)
-        gpu_engine.upload(rom)
-        got = gpu_engine.scan(plan, block_bytes=65536)
-        assert got.tolist() == oracle.engine(oplan, rom, 65536).tolist(), (case, vals, elem)
-        data = rom if elem == 1 else rom[: (rom.size // 2) * 2].view("<u2")
-        assert gpu_engine.scan(plan).tolist() == oracle.search(oplan, data).tolist(), (case, vals, elem, "whole")
+def test_fuzz_with_a_small_candidate_limit(tmp_path):
+    """The same fuzz in a process of its own whose per-candidate path gives up at 16384 candidates (MMOORE_MAX_CANDIDATES is
+    read once per process): what lies beyond the limit -- the candidate-flood path (5), the flagged domains (4), the
+    forward engine on everything (3) -- is reached by ROMs of a few MiB again, as it was before the limit went to 2^20."""
+    import json
+    import subprocess
+    import sys
+    report = tmp_path / "paths.json"
+    env = dict(os.environ, MMOORE_MAX_CANDIDATES="16384", MM_FUZZ_SEEDS="48", MM_FUZZ_MEDIUM="32", MM_FUZZ_LONG="1",
+               MM_FUZZ_REPORT=str(report))
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_fuzz.py"), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
+                        "-k", "against_oracle or medium_roms or reached_every"], env=env, capture_output=True, text=True, timeout=1500,
+                       cwd=os.path.dirname(here))
+    print(r.stdout[-2000:])
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+    hits = json.loads(report.read_text())
+    by_path = collections.Counter()
+    for key, n in hits.items():
+        by_path[int(key.split(",")[1])] += n
+    print("engine paths with the small limit:", hits)
+    # (measured: 2754 / 94 / 90 / 22 / 44 scans on paths 0 / 2 / 3 / 4 / 5)
+    floor = {0: 1000, 3: 40, 4: 12, 5: 25}
+    for path, least in floor.items():
+        assert by_path[path] >= least, (path, by_path[path], least, hits)

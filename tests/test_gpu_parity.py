@@ -240,10 +240,10 @@ def test_many_matches_stay_on_the_resolver_path(mm, gpu_engine, oracle):
     assert gpu_engine.scan(plan, block_bytes=524288, cap=1000).tolist() == want.tolist()   # MMH_E_CAPACITY, retried bigger
 
 
-@pytest.mark.parametrize("nplants,elem", [(9000, 1), (70000, 1), (150000, 1), (50000, 2)])
+@pytest.mark.parametrize("nplants,elem", [(9000, 1), (70000, 1), (150000, 1), (50000, 2), (700000, 1)])
 def test_bucketed_store_list_lengths(mm, gpu_engine, oracle, nplants, elem):
     """Big ROMs drop candidates into buckets of their ROM neighbourhood and mm_scan_tail2 ranks them from there
-    (csrc/mm_tail2.h): lists of up to 8192 slots are written straight into pinned memory, longer ones (up to 262144) are
+    (csrc/mm_tail2.h): lists of up to 8192 slots are written straight into pinned memory, longer ones (up to 2^20) are
     fetched from the device-side copy -- through mmh_scan, through the submit lanes, and one chain over the whole
     buffer; a few plants wrap around (candidates that are no matches: holes)."""
     rng = np.random.default_rng(nplants)
@@ -256,15 +256,15 @@ def test_bucketed_store_list_lengths(mm, gpu_engine, oracle, nplants, elem):
     gpu_engine.upload(rom)
     plan, oplan = mm.plan_relative(elem, kw), oracle.plan(elem, kw)
     want = oracle.engine(oplan, rom, 524288)
-    got = gpu_engine.scan(plan, block_bytes=524288, cap=1 << 18)
+    got = gpu_engine.scan(plan, block_bytes=524288, cap=1 << 20)
     ctr = gpu_engine.counters()
     assert got.tolist() == want.tolist() and len(want) > 0.8 * nplants
     assert ctr["path"] in (0, 2) and ctr["candidates"] >= len(want), ctr
     tickets = [gpu_engine.submit(plan, block_bytes=524288) for _ in range(3)]
     for t in tickets:
-        assert gpu_engine.collect(t, cap=1 << 18).tolist() == want.tolist()
+        assert gpu_engine.collect(t, cap=1 << 20).tolist() == want.tolist()
     data = rom if elem == 1 else rom.view("<u2")
-    assert gpu_engine.scan(plan, cap=1 << 18).tolist() == oracle.search(oplan, data).tolist()
+    assert gpu_engine.scan(plan, cap=1 << 20).tolist() == oracle.search(oplan, data).tolist()
     assert gpu_engine.scan(plan, block_bytes=524288, cap=100).tolist() == want.tolist()      # MMH_E_CAPACITY, retried bigger
 
 
