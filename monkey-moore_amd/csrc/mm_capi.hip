@@ -446,6 +446,7 @@ struct Outcome {
    uint32_t hard = 0;
    bool hard_overflow = false;
    bool sorted_on_device = false;
+   uint32_t limit = 0;              // the candidate limit of the kernels that ran (bucketed store: 2^20, list-based kernels: 2^18)
 };
 
 // enqueue [zero counters] -> engine kernels -> ordering into pinned host memory; `ev` = the
@@ -490,6 +491,11 @@ int wait_for_gather_reading(mmh_ctx *c, const uint64_t *buffer)
    return MMH_OK;
 }
 
+uint32_t list_candidate_limit(const MmWorkspace &w, uint32_t max_candidates)
+{
+   return (uint32_t)std::min<uint64_t>(std::min<uint32_t>(max_candidates, mm::tuning().list_candidates), w.cand_cap / 2);
+}
+
 int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev, const MmGeom &g, const mmh_plan_desc &pl,
                      const mm::FilterChoice &fc, bool sequential, uint64_t base_offset, uint32_t max_candidates,
                      const uint32_t *skip_bits = nullptr, bool allow_polled = false, bool allow_single_launch = false,
@@ -499,6 +505,12 @@ int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev,
    const bool polled = allow_polled && !sequential && !skip_bits && fused_enabled();
    const bool single_launch = polled && allow_single_launch && c->fused_ok && mm::fused_applies(g);
    const bool bucketed = polled && !single_launch && buckets_enabled();
+   // Only the bucketed store takes the full limit: the list-based kernels keep round 2's (their lists share d_cand, and the
+   // callers read "more candidates than this" as "a flood: take it apart domain by domain").
+   if (!bucketed) {
+      max_candidates = list_candidate_limit(w, max_candidates);
+   }
+   w.limit = max_candidates;
    if (bucketed) {
       const int rc = ensure_buckets(c, w, st);
       if (rc != MMH_OK) {
@@ -636,6 +648,7 @@ int wait_fused(MmWorkspace &w, hipEvent_t done)
 int finish_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev, const MmGeom &g, const mmh_plan_desc &pl,
                     uint64_t base_offset, uint32_t max_candidates, bool sequential, Outcome *oc)
 {
+   max_candidates = oc->limit = w.limit;        // (what enqueue_pipeline settled on)
    if (w.polled) {
       w.polled = false;
       const bool was_fused = w.fused;
@@ -712,6 +725,7 @@ int finish_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev, 
          if (again != MMH_OK) {
             return again;
          }
+         max_candidates = oc->limit = w.limit;
          HIP_TRY(hipEventSynchronize(ev[2]));
          read_outcome(w, sequential, oc);
       }
@@ -1213,7 +1227,8 @@ int scan_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int b
    // (keywords beyond 32 symbols: the resolvers' phase sets do not hold their D > 31 phases)
    const bool narrow = plan->L <= MM_RESOLVER_MAX_KEYWORD;
    enum { FAST, SEQUENTIAL, DENSE } mode = c->engine == 1 ? SEQUENTIAL : (c->engine == 2 || !have_filter || !narrow) ? DENSE : FAST;
-   const uint32_t max_candidates = candidate_limit(c->ws[0]);
+   const uint32_t scan_limit = candidate_limit(c->ws[0]);
+   uint32_t max_candidates = scan_limit;
 
    Outcome oc;
    std::vector<uint64_t> long_list;
@@ -1235,10 +1250,11 @@ int scan_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int b
          settled = true;
          break;
       }
-      rc = run_pipeline(c, g, *plan, fc, mode == SEQUENTIAL, base_offset, max_candidates, &oc);
+      rc = run_pipeline(c, g, *plan, fc, mode == SEQUENTIAL, base_offset, scan_limit, &oc);
       if (rc != MMH_OK) {
          return rc;
       }
+      max_candidates = oc.limit;                  // (the list-based kernels' limit if those ran, see enqueue_pipeline)
       if (mode == FAST && oc.hard_overflow && !g.whole && oc.candidates <= c->ws[0].out_cap && oc.candidates <= max_candidates) {
          // more left-overs than mm_resolve2 / mm_hard_resolve take: forward engine on their domains only
          bool handled = false;
@@ -1533,7 +1549,7 @@ extern "C" int mmh_scan_collect(mmh_ctx *c, int ticket, uint64_t *out, uint64_t 
          p.active = false;
          return rc;
       }
-      rescan = oc.candidates > w.out_cap || oc.candidates > p.max_candidates || oc.hard_overflow || !oc.sorted_on_device;
+      rescan = oc.candidates > w.out_cap || oc.candidates > oc.limit || oc.hard_overflow || !oc.sorted_on_device;
       static const bool lane_trace = getenv("MMOORE_LANE_TRACE") != nullptr;     // development: where the lanes' kernels lie in time
       if (lane_trace) {
          static hipEvent_t base = nullptr;

@@ -35,6 +35,7 @@ struct MmWorkspace {
    uint64_t cand_cap = 0;
    uint64_t *d_out = nullptr;       // unordered matches
    uint64_t out_cap = 0;
+   uint32_t limit = 0;              // candidate limit of the scan enqueued last (enqueue_pipeline)
    unsigned long long *d_ctrl = nullptr;   // counters + arrival tickets, zeroed per scan (mm::ResolveBuffers)
    uint64_t *d_mid_off = nullptr;   // hand-over list mm_resolve -> mm_resolve2
    uint64_t *d_mid_hi = nullptr;

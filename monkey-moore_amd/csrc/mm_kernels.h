@@ -16,7 +16,8 @@ struct Tuning {
    unsigned resolve_blocks;          // MMOORE_RESOLVE_BLOCKS   (4096 workgroups)
    unsigned tail_blocks;             // MMOORE_TAIL_BLOCKS      (2048 workgroups of mm_scan_tail / mm_scan_tail2)
    unsigned lane_tail_blocks;        // MMOORE_LANE_TAIL_BLOCKS (workgroups of mm_scan_tail2 behind a scan of the submit lanes)
-   uint32_t max_candidates;          // MMOORE_MAX_CANDIDATES   (1048576 per scan)
+   uint32_t max_candidates;          // MMOORE_MAX_CANDIDATES   (1048576 per scan: the bucketed store, csrc/mm_tail2.h)
+   uint32_t list_candidates;         // MMOORE_LIST_CANDIDATES  (262144 per scan: the list-based kernels)
 };
 const Tuning &tuning();
 

@@ -1301,6 +1301,7 @@ const Tuning &tuning()
       // scan in the steady state against 0.695-0.696 with 2048, profiles/r03_lane_gate_and_span_tickets.log)
       k.lane_tail_blocks = (unsigned)std::min<long>(number("MMOORE_LANE_TAIL_BLOCKS", 512), (long)MM_ARRIVE_FAN * (MM_ARRIVE_LINES - 1));
       k.max_candidates = (uint32_t)number("MMOORE_MAX_CANDIDATES", 1048576);
+      k.list_candidates = (uint32_t)number("MMOORE_LIST_CANDIDATES", 262144);
       return k;
    }();
    return t;
