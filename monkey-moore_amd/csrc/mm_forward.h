@@ -27,8 +27,9 @@
 //   * keywords of up to MMH_MAX_KEYWORD = 128 symbols (D <= 127): maps are byte arrays handled by
 //     lane e and lane e + 64 (template parameter MAXD); the per-candidate resolvers keep D <= 31,
 //     longer keywords always come here.
-// Batches are handed out through one ticket per workgroup and four batches, so a waiting wave
-// only ever waits for batches that running waves own: no residency assumption, no deadlock.
+// Batches are handed out through tickets in order (blocks of 16 per workgroup, its waves taking them
+// one by one): a waiting wave only ever waits for batches that running waves own or will take next:
+// no residency assumption, no deadlock.
 #ifndef MM_FORWARD_H
 #define MM_FORWARD_H
 
@@ -74,6 +75,12 @@ struct MmForwardArgs {
    uint32_t fast;
    uint32_t i1, g1;          // keyword position of the first compare and the distance to its partner
    uint32_t has2, i2, g2;    // the same for the next compare down, when it qualifies
+   // quiet batches (mm_fwd_quiet): the streaming filter's first two SWAR conditions (FilterChoice, mm_kernels.h); 0: no such path
+   uint32_t quiet_shape;     // MM_F8_* shape with run-time shifts: 0x100 | MASK2 << 4 | number of conditions (1 or 2)
+   uint32_t quiet_iA;        // keyword position of condition 0
+   uint32_t quiet_pat[2];    // expected deltas, replicated over the bytes of a dword
+   uint32_t quiet_sh1;       // v_alignbit amount of condition 1
+   uint32_t chunk;           // consecutive batches per ticket (a workgroup's block)
 };
 
 struct MmFwdTables {
@@ -392,6 +399,86 @@ __device__ __forceinline__ void mm_fwd_emit(const MmForwardArgs &a, WL &W, int s
    mm_wave_sync();
 }
 
+// Does NO position of [lo0, lo1) of the domain pass the reference's whole compare loop?  The streaming filter's test
+// (mm_f8_chunk: up to two SWAR conditions, a superset of the compare loop's first steps) on the positions' bytes straight
+// from global memory, 16 bytes per lane and 1 KiB per wave and step; what passes (2^-16 of random positions) runs the
+// compare loop itself.  8-bit elements only.  Wave uniform.
+template <int SHAPE>
+__device__ __forceinline__ bool mm_fwd_quiet_t(const MmForwardArgs &a, uint64_t start, int64_t lo0, int64_t lo1, int lane)
+{
+   const MmGeom &g = a.t.g;
+   const uint64_t first = start + (uint64_t)lo0 + a.quiet_iA;            // the anchor byte of position lo0 ...
+   const uint64_t last = start + (uint64_t)(lo1 - 1) + a.quiet_iA;       // ... and of the last position
+   const uint32_t pat[4] = {a.quiet_pat[0], a.quiet_pat[1], 0u, 0u};
+   const uint32_t sh[4] = {0u, a.quiet_sh1, 0u, 0u};
+   // 4 KiB per wave and step, 64 consecutive bytes per lane: four loads in flight per lane, and the dword in front of
+   // a chunk is the previous chunk's last one
+   for (uint64_t piece = first & ~(uint64_t)15; piece <= last; piece += 4096) {
+      const uint64_t byte0 = piece + 64u * (uint32_t)lane;
+      uint4 w[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+         w[k] = mm_load_chunk(g.rom, g.nbytes, byte0 + 16u * k);
+      }
+      const uint32_t back0 = byte0 >= 4 && byte0 <= g.nbytes ? *reinterpret_cast<const uint32_t *>(g.rom + byte0 - 4) : 0u;
+      uint32_t some = 0;
+      {
+         uint32_t back = back0;
+#pragma unroll
+         for (int k = 0; k < 4; k++) {
+            uint32_t h[4];
+            some |= mm_f8_chunk<SHAPE>(w[k], back, pat, sh, h);
+            back = w[k].w;
+         }
+      }
+      if (__ballot(some != 0) != 0) {
+         bool found = false;
+         if (some) {
+            // (rare -- 2^-16 of random positions: the flags again, chunk by chunk, from bytes loaded again: keeping the
+            // four chunks alive through this branch costs the kernel a wave per SIMD)
+            uint32_t back = back0;
+#pragma unroll 1
+            for (int k = 0; k < 4; k++) {
+               const uint4 wk = mm_load_chunk(g.rom, g.nbytes, byte0 + 16u * (uint32_t)k);
+               uint32_t h[4];
+               mm_f8_chunk<SHAPE>(wk, back, pat, sh, h);
+               back = wk.w;
+               uint32_t bits = mm_f8_pack(h);                            // bit 8 b + d: byte b of dword d
+               while (bits) {
+                  const int bit = __ffs((int)bits) - 1;
+                  bits &= bits - 1;
+                  const uint64_t t = byte0 + (uint64_t)(16 * k + 4 * (bit & 7) + (bit >> 3));
+                  if (t >= first && t <= last) {
+                     bool matched = false;
+                     mm_step(a.t.plan, [&](int64_t e) { return mm_elem(g, start, e); }, (int64_t)(t - a.quiet_iA - start), &matched);
+                     found = found || matched;
+                  }
+               }
+            }
+         }
+         if (__ballot(found) != 0) {
+            return false;
+         }
+      }
+   }
+   return true;
+}
+
+__device__ __forceinline__ bool mm_fwd_quiet(const MmForwardArgs &a, uint64_t start, int64_t lo0, int64_t lo1, int lane)
+{
+   if (lo1 <= lo0) {
+      return true;
+   }
+   switch (a.quiet_shape) {                                               // (wave uniform)
+   case 0x101: return mm_fwd_quiet_t<0x101>(a, start, lo0, lo1, lane);
+   case 0x111: return mm_fwd_quiet_t<0x111>(a, start, lo0, lo1, lane);
+   case 0x102: return mm_fwd_quiet_t<0x102>(a, start, lo0, lo1, lane);
+   case 0x112: return mm_fwd_quiet_t<0x112>(a, start, lo0, lo1, lane);
+   case 0x122: return mm_fwd_quiet_t<0x122>(a, start, lo0, lo1, lane);
+   default: return mm_fwd_quiet_t<0x132>(a, start, lo0, lo1, lane);
+   }
+}
+
 // the look-back word of batch b, once it is non-zero (wave uniform)
 __device__ __forceinline__ unsigned long long mm_fwd_wait(const unsigned long long *status, uint64_t b, int lane)
 {
@@ -416,8 +503,11 @@ __global__ __launch_bounds__(64 * MM_WAVES) void mm_forward(MmForwardArgs a)
    __shared__ WL Wv[MM_WAVES];
    __shared__ uint8_t tilemap[MM_WAVES][MM_FWD_BATCH][MAXD];
    __shared__ uint8_t lookback[MM_WAVES][MAXD];
-   __shared__ uint8_t superx[MM_WAVES][MM_TILE / 256 + 1][MAXD + 4];
-   __shared__ unsigned long long next_batch;
+   // (the super-group tables of mm_fwd_map overlay the tile's jumps: those have served their purpose once the exit
+   // tables exist, and the 1.3 KiB this saves is what keeps six workgroups on a CU)
+   static_assert(sizeof(uint8_t[MM_TILE / 256 + 1][MAXD + 4]) <= sizeof(WL::jump), "super-group tables overlay the jumps");
+   __shared__ unsigned int q_taken, q_ready[2], q_readers[2];
+   __shared__ unsigned long long q_base[2];
    mm_plan_to_lds(P, a.t.plan);
    mm_fwd_tables(T, P, a);
 
@@ -427,18 +517,51 @@ __global__ __launch_bounds__(64 * MM_WAVES) void mm_forward(MmForwardArgs a)
    WL &W = Wv[wave];
    const uint64_t nbatches = a.ndom * a.bpd;
 
+   // Hand-out (round 3; before: one ticket per workgroup and four batches, its four waves in step -- with quiet
+   // batches a tenth of the batches takes five times as long as the rest, and a workgroup whose waves wait for each
+   // other spends a third of its rounds at the slow one's pace).  Now the workgroup draws BLOCKS of a.chunk consecutive
+   // batches from the global ticket and its waves take batches out of the current block one by one through a counter
+   // in LDS, nobody waiting for anybody: taken = batches the workgroup's waves have taken so far; the wave that takes
+   // the first batch of block j draws the block's ticket and announces it in slot j % 2 (base, ready = j + 1), the
+   // takers of the block's other batches spin on that word; the slot is reused by block j + 2, whose drawer first
+   // waits until all of block j's takers have read it (readers).  The four waves of a workgroup so work on
+   // neighbouring batches, as they did with the old hand-out.  (One ticket per wave and batch: 32 K atomics per GiB on
+   // one address, and the waves of a CU spread over the ROM: 0.93 instead of 0.72 ms per GiB.)
+   // No deadlock: tickets are drawn in order and a workgroup's batches are taken in order by waves that only ever wait
+   // for smaller batches, so the smallest unfinished batch is always in the hands of a wave that can run, or will be
+   // taken by the next wave of its workgroup that finishes.
+   if (threadIdx.x == 0) {
+      q_taken = 0;
+      q_ready[0] = q_ready[1] = 0;
+      q_readers[0] = q_readers[1] = 0;
+   }
+   __syncthreads();
    for (;;) {
-      __syncthreads();
-      if (threadIdx.x == 0) {
-         next_batch = atomicAdd(a.ticket, (unsigned long long)MM_WAVES);
+      unsigned long long mine = 0;
+      if (lane == 0) {
+         const uint32_t i = atomicAdd(&q_taken, 1u);
+         const uint32_t j = i / a.chunk, o = i - j * a.chunk, slot = j & 1u;
+         if (o == 0) {
+            if (j >= 2) {
+               while (__hip_atomic_load(&q_readers[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != a.chunk) {
+                  __builtin_amdgcn_s_sleep(1);
+               }
+               __hip_atomic_store(&q_readers[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            q_base[slot] = atomicAdd(a.ticket, (unsigned long long)a.chunk);
+            __hip_atomic_store(&q_ready[slot], j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+         }
+         else {
+            while (__hip_atomic_load(&q_ready[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != j + 1) {
+               __builtin_amdgcn_s_sleep(1);
+            }
+         }
+         mine = q_base[slot] + o;
+         __hip_atomic_fetch_add(&q_readers[slot], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
-      __syncthreads();
-      const uint64_t item = next_batch + (uint64_t)wave;
-      if (next_batch >= nbatches) {
-         break;
-      }
+      const uint64_t item = mm_uniform64(mine);
       if (item >= nbatches) {
-         continue;
+         break;
       }
       const uint64_t dom = item / a.bpd;
       const uint32_t b = (uint32_t)(item % a.bpd);
@@ -455,26 +578,108 @@ __global__ __launch_bounds__(64 * MM_WAVES) void mm_forward(MmForwardArgs a)
          bm[h] = (uint32_t)lane + 64u * h;
       }
       uint32_t flagged = 0;                         // tiles with a position that passed the whole compare loop
-      for (uint32_t t = t0; t < t1; t++) {
-         const int64_t lo = (int64_t)t * MM_FWD_TILE;
-         uint32_t map[NH];
+      // ---- the quiet batch.  The batch's map is the map of its last tiles alone once THAT is constant: whatever phase
+      // the chain enters the batch in, it leaves those tiles -- and so the batch -- in the same one.  Tiles are therefore
+      // mapped from the batch's end backwards, composing suf = (map of the tiles behind) o (this tile's map), until suf is
+      // constant (wildcard keywords: one tile -- their capped skips mix the phases quickly; plain keywords: a few -- most
+      // of their jumps are L - 1, which keeps a chain in its phase).  If then no position of the tiles in front passes
+      // the compare loop (mm_fwd_quiet: the streaming filter's test on their bytes) there is nothing to report from the
+      // batch either: it is done with a few tiles mapped and the others only read.  A tile with a position that passes
+      // ends the attempt -- the chain's entry phase is needed, i.e. every map -- and nothing is lost: the maps made so
+      // far stay in tilemap[] for pass 1 below.
+      uint32_t have = 0;                            // tiles whose maps already sit in tilemap[wave]
+      if (ELEM == 1 && a.quiet_shape != 0 && nv > (int64_t)t0 * MM_FWD_TILE) {
+         uint8_t *suf = lookback[wave];
 #pragma unroll
          for (int h = 0; h < NH; h++) {
-            map[h] = (uint32_t)lane + 64u * h;      // tiles past the domain's end: identity
+            if (lane + 64 * h < MAXD) {
+               suf[lane + 64 * h] = (uint8_t)(lane + 64 * h);
+            }
          }
-         if (lo < nv) {
+         mm_wave_sync();
+         const uint32_t tlast = (uint32_t)((nv - 1) / MM_FWD_TILE);
+         bool done = false;
+         for (uint32_t t = tlast < t1 - 1 ? tlast : t1 - 1;; t--) {
+            const int64_t lo = (int64_t)t * MM_FWD_TILE;
             const int npos = (int)(nv - lo < MM_FWD_TILE ? nv - lo : MM_FWD_TILE);
+            uint32_t map[NH];
             bool any = false;
             const uint8_t *tile;
             int shift;
             mm_fwd_jumps(a, P, T, W, start, lo, npos, lane, &any, &tile, &shift);
-            mm_fwd_map<NH, MAXD>(a.t, W, superx[wave], shift, npos, mm_modd64(a.t, (uint64_t)lo), lane, map);
-            flagged |= any ? 1u << (t - t0) : 0u;
-         }
+            mm_fwd_map<NH, MAXD>(a.t, W, (*reinterpret_cast<uint8_t (*)[MM_TILE / 256 + 1][MAXD + 4]>(W.jump)), shift, npos, mm_modd64(a.t, (uint64_t)lo), lane, map);
+            uint32_t sn[NH];
 #pragma unroll
-         for (int h = 0; h < NH; h++) {
-            if (lane + 64 * h < MAXD) {
-               tilemap[wave][t - t0][lane + 64 * h] = (uint8_t)map[h];
+            for (int h = 0; h < NH; h++) {
+               sn[h] = 0;
+               if (lane + 64 * h < MAXD) {
+                  tilemap[wave][t - t0][lane + 64 * h] = (uint8_t)map[h];
+               }
+               if ((uint32_t)lane + 64u * h < D) {
+                  sn[h] = suf[map[h]];
+               }
+            }
+            have |= 1u << (t - t0);
+            mm_wave_sync();
+            if (any) {
+               flagged |= 1u << (t - t0);
+               break;
+            }
+            const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sn[0]);
+            bool differs = false;
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+               if ((uint32_t)lane + 64u * h < D) {
+                  suf[lane + 64 * h] = (uint8_t)sn[h];
+                  differs = differs || sn[h] != s0;
+               }
+            }
+            mm_wave_sync();
+            if (__ballot(differs) == 0) {
+               if (mm_fwd_quiet(a, start, (int64_t)t0 * MM_FWD_TILE, lo, lane)) {
+                  if (lane == 0) {
+                     __hip_atomic_store(a.status + item, MM_FWD_INCLUSIVE | ((unsigned long long)s0 << 8), __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_AGENT);
+                  }
+                  done = true;
+               }
+               break;
+            }
+            if (t == t0) {
+               break;
+            }
+         }
+#ifdef MM_FWD_DEBUG
+         if (lane == 0 && item % 1499 == 0) {
+            printf("batch %llu: maps made %d, flagged %x, done %d\n", (unsigned long long)item, __popc(have), flagged, (int)done);
+         }
+#endif
+         if (done) {
+            continue;
+         }
+      }
+      for (uint32_t t = t0; t < t1; t++) {
+         const int64_t lo = (int64_t)t * MM_FWD_TILE;
+         if (((have >> (t - t0)) & 1u) == 0) {
+            uint32_t map[NH];
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+               map[h] = (uint32_t)lane + 64u * h;   // tiles past the domain's end: identity
+            }
+            if (lo < nv) {
+               const int npos = (int)(nv - lo < MM_FWD_TILE ? nv - lo : MM_FWD_TILE);
+               bool any = false;
+               const uint8_t *tile;
+               int shift;
+               mm_fwd_jumps(a, P, T, W, start, lo, npos, lane, &any, &tile, &shift);
+               mm_fwd_map<NH, MAXD>(a.t, W, (*reinterpret_cast<uint8_t (*)[MM_TILE / 256 + 1][MAXD + 4]>(W.jump)), shift, npos, mm_modd64(a.t, (uint64_t)lo), lane, map);
+               flagged |= any ? 1u << (t - t0) : 0u;
+            }
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+               if (lane + 64 * h < MAXD) {
+                  tilemap[wave][t - t0][lane + 64 * h] = (uint8_t)map[h];
+               }
             }
          }
          mm_wave_sync();

@@ -1837,6 +1837,26 @@ static void launch_forward(hipStream_t st, const MmGeom &g, const mmh_plan_desc 
          a.has2 = 1; a.i2 = (uint32_t)i2; a.g2 = (uint32_t)(-pl.bridge[i2]);
       }
    }
+   // quiet batches (mm_fwd_quiet): only beside the table-driven jump path (8-bit elements), with the streaming filter's conditions
+   a.quiet_shape = 0; a.quiet_iA = 0; a.quiet_pat[0] = a.quiet_pat[1] = 0; a.quiet_sh1 = 0;
+   FilterChoice fc;
+   if (a.fast && choose_filter(pl, &fc) && !(getenv("MMOORE_FORWARD_QUIET") && *getenv("MMOORE_FORWARD_QUIET") == '0')) {
+      const uint32_t nc = fc.ncond < 2 ? fc.ncond : 2;
+      uint32_t mask2 = fc.gap[0] == 2 ? 1u : 0u;
+      if (nc == 2) {
+         mask2 |= fc.gap[1] == 2 ? 2u : 0u;
+         a.quiet_pat[1] = fc.pat[1];
+         a.quiet_sh1 = 32u - 8u * fc.shift[1];
+      }
+      a.quiet_shape = 0x100u | (mask2 << 4) | nc;
+      a.quiet_iA = fc.iA;
+      a.quiet_pat[0] = fc.pat[0];
+   }
+   {
+      // a workgroup's block of batches (mm_forward.h): 16 on big jobs, 4 -- one batch per wave -- where that leaves workgroups without work
+      const char *e = getenv("MMOORE_FWD_CHUNK");
+      a.chunk = e && atoi(e) >= 4 ? (uint32_t)atoi(e) : (nbatches >= 16ull * 256 * 6 ? 16u : 4u);
+   }
    (void)hipMemsetAsync(db.maps, 0, dg.status_bytes, st);
    int device = 0, cus = 256;
    (void)hipGetDevice(&device);
