@@ -33,6 +33,7 @@
 #ifndef MM_FORWARD_H
 #define MM_FORWARD_H
 
+
 constexpr int MM_FWD_BATCH = 16;               // tiles per batch (one wave): 32 Ki positions
 // positions per tile: a tile's positions sit in up to 3 slots further on (MmFwdLds), and 64 lanes own
 // 64 groups of 32 slots -- 2044 + 3 slots still fit them
@@ -75,11 +76,15 @@ struct MmForwardArgs {
    uint32_t fast;
    uint32_t i1, g1;          // keyword position of the first compare and the distance to its partner
    uint32_t has2, i2, g2;    // the same for the next compare down, when it qualifies
-   // quiet batches (mm_fwd_quiet): the streaming filter's first two SWAR conditions (FilterChoice, mm_kernels.h); 0: no such path
-   uint32_t quiet_shape;     // MM_F8_* shape with run-time shifts: 0x100 | MASK2 << 4 | number of conditions (1 or 2)
-   uint32_t quiet_iA;        // keyword position of condition 0
-   uint32_t quiet_pat[2];    // expected deltas, replicated over the bytes of a dword
-   uint32_t quiet_sh1;       // v_alignbit amount of condition 1
+   // the pre-pass's tile bitmap (launch_loud: the streaming filter over the ROM before this kernel): bit dom * tpd + t set when
+   // a position of tile t of domain dom may pass the compare loop; null: no pre-pass (listed domains, keywords without a SWAR test)
+   const uint32_t *loud;
+   // 8-bit elements find the loud tiles of a batch themselves (mm_fwd_loud_mask: the kernel waits on LDS most of the time, the
+   // memory system is idle): the streaming filter's first two SWAR conditions (FilterChoice, mm_kernels.h); 0: no such test
+   uint32_t loud_shape;      // MM_F8_* shape with run-time shifts: 0x100 | MASK2 << 4 | number of conditions (1 or 2)
+   uint32_t loud_iA;         // keyword position of condition 0
+   uint32_t loud_pat[2];     // expected deltas, replicated over the bytes of a dword
+   uint32_t loud_sh1;        // v_alignbit amount of condition 1
    uint32_t chunk;           // consecutive batches per ticket (a workgroup's block)
 };
 
@@ -399,20 +404,21 @@ __device__ __forceinline__ void mm_fwd_emit(const MmForwardArgs &a, WL &W, int s
    mm_wave_sync();
 }
 
-// Does NO position of [lo0, lo1) of the domain pass the reference's whole compare loop?  The streaming filter's test
-// (mm_f8_chunk: up to two SWAR conditions, a superset of the compare loop's first steps) on the positions' bytes straight
-// from global memory, 16 bytes per lane and 1 KiB per wave and step; what passes (2^-16 of random positions) runs the
-// compare loop itself.  8-bit elements only.  Wave uniform.
+// The loud tiles among tiles [t0, t0 + ntiles) of the domain (positions [t0 TILE, lo1)): bit k set when a position of tile t0 + k
+// passes the reference's whole compare loop.  The streaming filter's test (mm_f8_chunk: up to two SWAR conditions, a
+// superset of the compare loop's first steps) on the positions' bytes straight from global memory, 4 KiB per wave and
+// step -- 64 consecutive bytes per lane: four loads in flight per lane, and the dword in front of a chunk is the previous
+// chunk's last one; what passes (2^-16 of random positions) runs the compare loop itself, unless its tile is known to be
+// loud already (floods: every position passes).  8-bit elements only.  Wave uniform.
 template <int SHAPE>
-__device__ __forceinline__ bool mm_fwd_quiet_t(const MmForwardArgs &a, uint64_t start, int64_t lo0, int64_t lo1, int lane)
+__device__ __forceinline__ uint32_t mm_fwd_loud_t(const MmForwardArgs &a, uint64_t start, int64_t lo0, int64_t lo1, int lane)
 {
    const MmGeom &g = a.t.g;
-   const uint64_t first = start + (uint64_t)lo0 + a.quiet_iA;            // the anchor byte of position lo0 ...
-   const uint64_t last = start + (uint64_t)(lo1 - 1) + a.quiet_iA;       // ... and of the last position
-   const uint32_t pat[4] = {a.quiet_pat[0], a.quiet_pat[1], 0u, 0u};
-   const uint32_t sh[4] = {0u, a.quiet_sh1, 0u, 0u};
-   // 4 KiB per wave and step, 64 consecutive bytes per lane: four loads in flight per lane, and the dword in front of
-   // a chunk is the previous chunk's last one
+   const uint64_t first = start + (uint64_t)lo0 + a.loud_iA;             // the anchor byte of position lo0 ...
+   const uint64_t last = start + (uint64_t)(lo1 - 1) + a.loud_iA;        // ... and of the last position
+   const uint32_t pat[4] = {a.loud_pat[0], a.loud_pat[1], 0u, 0u};
+   const uint32_t sh[4] = {0u, a.loud_sh1, 0u, 0u};
+   uint32_t mask = 0;
    for (uint64_t piece = first & ~(uint64_t)15; piece <= last; piece += 4096) {
       const uint64_t byte0 = piece + 64u * (uint32_t)lane;
       uint4 w[4];
@@ -432,10 +438,10 @@ __device__ __forceinline__ bool mm_fwd_quiet_t(const MmForwardArgs &a, uint64_t 
          }
       }
       if (__ballot(some != 0) != 0) {
-         bool found = false;
+         uint32_t mine = 0;
          if (some) {
-            // (rare -- 2^-16 of random positions: the flags again, chunk by chunk, from bytes loaded again: keeping the
-            // four chunks alive through this branch costs the kernel a wave per SIMD)
+            // (rare: the flags again, chunk by chunk, from bytes loaded again: keeping the four chunks alive through
+            // this branch costs the kernel a wave per SIMD)
             uint32_t back = back0;
 #pragma unroll 1
             for (int k = 0; k < 4; k++) {
@@ -449,33 +455,37 @@ __device__ __forceinline__ bool mm_fwd_quiet_t(const MmForwardArgs &a, uint64_t 
                   bits &= bits - 1;
                   const uint64_t t = byte0 + (uint64_t)(16 * k + 4 * (bit & 7) + (bit >> 3));
                   if (t >= first && t <= last) {
-                     bool matched = false;
-                     mm_step(a.t.plan, [&](int64_t e) { return mm_elem(g, start, e); }, (int64_t)(t - a.quiet_iA - start), &matched);
-                     found = found || matched;
+                     const uint32_t tbit = 1u << ((uint32_t)(t - first) / MM_FWD_TILE);
+                     if (((mask | mine) & tbit) == 0) {
+                        bool matched = false;
+                        mm_step(a.t.plan, [&](int64_t e) { return mm_elem(g, start, e); }, (int64_t)(t - a.loud_iA - start), &matched);
+                        mine |= matched ? tbit : 0u;
+                     }
                   }
                }
             }
          }
-         if (__ballot(found) != 0) {
-            return false;
+         if (__ballot(mine != 0) != 0) {
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+               mine |= (uint32_t)__shfl_xor((int)mine, d);
+            }
+            mask |= (uint32_t)__builtin_amdgcn_readfirstlane((int)mine);
          }
       }
    }
-   return true;
+   return mask;
 }
 
-__device__ __forceinline__ bool mm_fwd_quiet(const MmForwardArgs &a, uint64_t start, int64_t lo0, int64_t lo1, int lane)
+__device__ __forceinline__ uint32_t mm_fwd_loud_mask(const MmForwardArgs &a, uint64_t start, int64_t lo0, int64_t lo1, int lane)
 {
-   if (lo1 <= lo0) {
-      return true;
-   }
-   switch (a.quiet_shape) {                                               // (wave uniform)
-   case 0x101: return mm_fwd_quiet_t<0x101>(a, start, lo0, lo1, lane);
-   case 0x111: return mm_fwd_quiet_t<0x111>(a, start, lo0, lo1, lane);
-   case 0x102: return mm_fwd_quiet_t<0x102>(a, start, lo0, lo1, lane);
-   case 0x112: return mm_fwd_quiet_t<0x112>(a, start, lo0, lo1, lane);
-   case 0x122: return mm_fwd_quiet_t<0x122>(a, start, lo0, lo1, lane);
-   default: return mm_fwd_quiet_t<0x132>(a, start, lo0, lo1, lane);
+   switch (a.loud_shape) {                                                // (wave uniform)
+   case 0x101: return mm_fwd_loud_t<0x101>(a, start, lo0, lo1, lane);
+   case 0x111: return mm_fwd_loud_t<0x111>(a, start, lo0, lo1, lane);
+   case 0x102: return mm_fwd_loud_t<0x102>(a, start, lo0, lo1, lane);
+   case 0x112: return mm_fwd_loud_t<0x112>(a, start, lo0, lo1, lane);
+   case 0x122: return mm_fwd_loud_t<0x122>(a, start, lo0, lo1, lane);
+   default: return mm_fwd_loud_t<0x132>(a, start, lo0, lo1, lane);
    }
 }
 
@@ -494,7 +504,7 @@ __device__ __forceinline__ unsigned long long mm_fwd_wait(const unsigned long lo
 // ELEM: element bytes the tile buffers are sized for (1: 8-bit searches, 6 workgroups per CU instead of 4);
 // MAXD: 32 for keywords of up to 32 symbols, 128 beyond (phase maps handled by lane e and lane e + 64)
 template <int ELEM, int MAXD>
-__global__ __launch_bounds__(64 * MM_WAVES) void mm_forward(MmForwardArgs a)
+__global__ __launch_bounds__(64 * MM_WAVES) __attribute__((amdgpu_waves_per_eu(ELEM == 1 && MAXD == 32 ? 6 : 4))) void mm_forward(MmForwardArgs a)
 {
    using WL = MmFwdLds<ELEM>;
    constexpr int NH = (MAXD + 63) / 64;
@@ -503,6 +513,8 @@ __global__ __launch_bounds__(64 * MM_WAVES) void mm_forward(MmForwardArgs a)
    __shared__ WL Wv[MM_WAVES];
    __shared__ uint8_t tilemap[MM_WAVES][MM_FWD_BATCH][MAXD];
    __shared__ uint8_t lookback[MM_WAVES][MAXD];
+   __shared__ uint8_t lookback2[MM_WAVES][MAXD];      // the sweep's second composition (lookback: its first)
+   __shared__ uint8_t centry[MM_WAVES][MM_FWD_BATCH]; // ... and the entry phases it finds
    // (the super-group tables of mm_fwd_map overlay the tile's jumps: those have served their purpose once the exit
    // tables exist, and the 1.3 KiB this saves is what keeps six workgroups on a CU)
    static_assert(sizeof(uint8_t[MM_TILE / 256 + 1][MAXD + 4]) <= sizeof(WL::jump), "super-group tables overlay the jumps");
@@ -571,118 +583,189 @@ __global__ __launch_bounds__(64 * MM_WAVES) void mm_forward(MmForwardArgs a)
       const uint32_t t0 = b * MM_FWD_BATCH;
       const uint32_t t1 = t0 + MM_FWD_BATCH < a.tpd ? t0 + MM_FWD_BATCH : a.tpd;
 
-      // ---- pass 1: the map of every tile of the batch, composed into the batch's map ----------
-      uint32_t bm[NH];                              // bm[h]: where entry phase lane + 64 h leaves the batch so far
+      // ---- pass 1: tile maps.  Two ways through the batch's tiles, one loop (the mapping code exists once):
+      //
+      // SWEEP (with the pre-pass's bitmap).  Two observations make most of a batch's tiles unnecessary to map:
+      //  * the batch's map is the map of its LAST tiles alone once that is constant: whatever phase the chain enters
+      //    the batch in, it leaves those tiles -- and so the batch -- in the same one.  Likewise the phase in which
+      //    the chain enters a tile f is known once the map of the tiles right in front of f is constant.  (Wildcard
+      //    keywords: one tile is enough -- their capped skips mix the phases quickly; plain keywords: 1 - 4 -- most
+      //    of their jumps are L - 1, which keeps a chain in its phase);
+      //  * a tile none of whose positions passes the compare loop has nothing to report, and which tiles those are
+      //    the streaming filter has found out at its own speed before this kernel started (a.loud).
+      // So the tiles are swept from the batch's end backwards.  While something still asks for maps -- ex: the batch's
+      // exit phase, tg: the entry phase of the lowest loud tile met so far -- tiles are mapped and composed into
+      // ex / tg; once nothing does, the sweep jumps to the next loud tile down or ends.  The entry phases found
+      // (centry) and the maps made (tilemap) are then all pass 2 needs: a tile's entry phase is either in centry or
+      // follows from the tile below through that one's map.
+      //
+      // FILL.  A sweep that arrives at the batch's first tile still asking (floods, low-entropy data: the chains do not
+      // merge) has mapped every tile from where the question came up; nothing is lost: the tiles without a map are
+      // mapped as well, bottom up, the batch's map is composed from all of them and the look-back over the batches in
+      // front does the asking (round 2's way, which scans without the bitmap take from the start).
+      uint32_t flagged = 0;                         // tiles to report from: loud ones (sweep), or with a position that passed the compare loop
+      uint32_t have = 0;                            // tiles whose maps sit in tilemap[wave]
+      uint32_t known = 0;                           // tiles whose entry phase sits in centry[wave]
+      const int tl = nv > (int64_t)t0 * MM_FWD_TILE                      // the batch's last tile inside the domain (t0 - 1: none)
+                        ? (int)((uint64_t)(nv - 1) / MM_FWD_TILE < t1 - 1 ? (uint64_t)(nv - 1) / MM_FWD_TILE : t1 - 1)
+                        : (int)t0 - 1;
+      bool sweep = (a.loud != nullptr || (ELEM == 1 && a.loud_shape != 0)) && tl >= (int)t0;
+      uint32_t loud = 0;
+      if (ELEM == 1 && sweep && a.loud == nullptr) {
+         const int64_t lo1 = (int64_t)(tl + 1) * MM_FWD_TILE;
+         loud = mm_fwd_loud_mask(a, start, (int64_t)t0 * MM_FWD_TILE, lo1 < nv ? lo1 : nv, lane);
+      }
+      else if (sweep) {
+         const uint64_t bit0 = dom * a.tpd + t0;
+         const uint64_t two = (uint64_t)a.loud[bit0 >> 5] | ((uint64_t)a.loud[(bit0 >> 5) + 1] << 32);
+         loud = (uint32_t)(two >> (bit0 & 31)) & ((2u << (tl - (int)t0)) - 1u);
+         loud = (uint32_t)__builtin_amdgcn_readfirstlane((int)loud);
+      }
+      bool need_ex = sweep, need_tg = false;
+      uint32_t target = 0;
+      uint8_t *ex = lookback[wave], *tg = lookback2[wave];
+      if (sweep) {
+#pragma unroll
+         for (int h = 0; h < NH; h++) {
+            if (lane + 64 * h < MAXD) {
+               ex[lane + 64 * h] = (uint8_t)(lane + 64 * h);
+            }
+         }
+         mm_wave_sync();
+      }
+      for (int t = sweep ? tl : (int)t0;;) {
+         bool mapped = false, any = false;
+         if (sweep) {
+            if (t < (int)t0) {
+               if (!need_ex && !need_tg) {
+                  break;                               // swept: every question answered
+               }
+               sweep = false;                          // still asking at the batch's first tile: fill
+               flagged = 0;                            // (filled batches report from the tiles mm_fwd_jumps names)
+               t = (int)t0;
+               continue;
+            }
+            if (!need_ex && !need_tg) {
+               // nothing asks for maps: on to the next loud tile down
+               const uint32_t below = loud & ((2u << (t - (int)t0)) - 1u);
+               if (below == 0) {
+                  break;
+               }
+               t = (int)t0 + 31 - __clz((int)below);
+            }
+            else {
+               mapped = true;
+            }
+            any = ((loud >> (t - (int)t0)) & 1u) != 0;
+         }
+         else {
+            while (t <= tl && ((have >> (t - (int)t0)) & 1u) != 0) {
+               // (a map the sweep made: only the tile's flag is missing)
+               flagged |= loud & (1u << (t - (int)t0));
+               t++;
+            }
+            if (t > tl) {
+               break;
+            }
+            mapped = true;
+         }
+         if (mapped) {
+            const int64_t lo = (int64_t)t * MM_FWD_TILE;
+            const int npos = (int)(nv - lo < MM_FWD_TILE ? nv - lo : MM_FWD_TILE);
+            uint32_t map[NH];
+            const uint8_t *tile;
+            int shift;
+            bool passed = false;
+            mm_fwd_jumps(a, P, T, W, start, lo, npos, lane, &passed, &tile, &shift);
+            mm_fwd_map<NH, MAXD>(a.t, W, (*reinterpret_cast<uint8_t (*)[MM_TILE / 256 + 1][MAXD + 4]>(W.jump)), shift, npos,
+                                 mm_modd64(a.t, (uint64_t)lo), lane, map);
+            any = sweep ? any : passed;
+            uint32_t en[NH], gn[NH];
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+               en[h] = gn[h] = 0;
+               if (lane + 64 * h < MAXD) {
+                  tilemap[wave][t - (int)t0][lane + 64 * h] = (uint8_t)map[h];
+               }
+               if (sweep && (uint32_t)lane + 64u * h < D) {
+                  en[h] = need_ex ? ex[map[h]] : 0u;
+                  gn[h] = need_tg ? tg[map[h]] : 0u;
+               }
+            }
+            have |= 1u << (t - (int)t0);
+            mm_wave_sync();
+            if (sweep) {
+               const uint32_t e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)en[0]);
+               const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)gn[0]);
+               bool evaries = false, gvaries = false;
+#pragma unroll
+               for (int h = 0; h < NH; h++) {
+                  if ((uint32_t)lane + 64u * h < D) {
+                     if (need_ex) {
+                        ex[lane + 64 * h] = (uint8_t)en[h];
+                     }
+                     if (need_tg) {
+                        tg[lane + 64 * h] = (uint8_t)gn[h];
+                     }
+                     evaries = evaries || en[h] != e0;
+                     gvaries = gvaries || gn[h] != g0;
+                  }
+               }
+               mm_wave_sync();
+               if (need_ex && __ballot(evaries) == 0) {
+                  // the tiles from here to the batch's end take every phase to e0: tell the batches behind us at once
+                  if (lane == 0) {
+                     __hip_atomic_store(a.status + item, MM_FWD_INCLUSIVE | ((unsigned long long)e0 << 8), __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_AGENT);
+                  }
+                  need_ex = false;
+               }
+               if (need_tg && __ballot(gvaries) == 0) {
+                  if (lane == 0) {
+                     centry[wave][target - t0] = (uint8_t)g0;
+                  }
+                  known |= 1u << (target - t0);
+                  need_tg = false;
+               }
+            }
+         }
+         if (any) {
+            flagged |= 1u << (t - (int)t0);
+            if (sweep) {
+               // the lowest tile that reports so far: the ones above get their entry phases through the maps in between
+               // (all made: the question never went away)
+               target = (uint32_t)t;
+               need_tg = true;
+#pragma unroll
+               for (int h = 0; h < NH; h++) {
+                  if (lane + 64 * h < MAXD) {
+                     tg[lane + 64 * h] = (uint8_t)(lane + 64 * h);
+                  }
+               }
+               mm_wave_sync();
+            }
+         }
+         t += sweep ? -1 : 1;
+      }
+      const bool swept = sweep;
+      uint32_t entry = 0;                           // first batch of a domain: the chain starts at its first position
+      if (!swept) {
+      // (tiles past the domain's end: identity)
+      for (int t = tl + 1; t < (int)t1; t++) {
+#pragma unroll
+         for (int h = 0; h < NH; h++) {
+            if (lane + 64 * h < MAXD) {
+               tilemap[wave][t - (int)t0][lane + 64 * h] = (uint8_t)(lane + 64 * h);
+            }
+         }
+      }
+      mm_wave_sync();
+      uint32_t bm[NH];                              // bm[h]: where entry phase lane + 64 h leaves the batch
 #pragma unroll
       for (int h = 0; h < NH; h++) {
          bm[h] = (uint32_t)lane + 64u * h;
       }
-      uint32_t flagged = 0;                         // tiles with a position that passed the whole compare loop
-      // ---- the quiet batch.  The batch's map is the map of its last tiles alone once THAT is constant: whatever phase
-      // the chain enters the batch in, it leaves those tiles -- and so the batch -- in the same one.  Tiles are therefore
-      // mapped from the batch's end backwards, composing suf = (map of the tiles behind) o (this tile's map), until suf is
-      // constant (wildcard keywords: one tile -- their capped skips mix the phases quickly; plain keywords: a few -- most
-      // of their jumps are L - 1, which keeps a chain in its phase).  If then no position of the tiles in front passes
-      // the compare loop (mm_fwd_quiet: the streaming filter's test on their bytes) there is nothing to report from the
-      // batch either: it is done with a few tiles mapped and the others only read.  A tile with a position that passes
-      // ends the attempt -- the chain's entry phase is needed, i.e. every map -- and nothing is lost: the maps made so
-      // far stay in tilemap[] for pass 1 below.
-      uint32_t have = 0;                            // tiles whose maps already sit in tilemap[wave]
-      if (ELEM == 1 && a.quiet_shape != 0 && nv > (int64_t)t0 * MM_FWD_TILE) {
-         uint8_t *suf = lookback[wave];
-#pragma unroll
-         for (int h = 0; h < NH; h++) {
-            if (lane + 64 * h < MAXD) {
-               suf[lane + 64 * h] = (uint8_t)(lane + 64 * h);
-            }
-         }
-         mm_wave_sync();
-         const uint32_t tlast = (uint32_t)((nv - 1) / MM_FWD_TILE);
-         bool done = false;
-         for (uint32_t t = tlast < t1 - 1 ? tlast : t1 - 1;; t--) {
-            const int64_t lo = (int64_t)t * MM_FWD_TILE;
-            const int npos = (int)(nv - lo < MM_FWD_TILE ? nv - lo : MM_FWD_TILE);
-            uint32_t map[NH];
-            bool any = false;
-            const uint8_t *tile;
-            int shift;
-            mm_fwd_jumps(a, P, T, W, start, lo, npos, lane, &any, &tile, &shift);
-            mm_fwd_map<NH, MAXD>(a.t, W, (*reinterpret_cast<uint8_t (*)[MM_TILE / 256 + 1][MAXD + 4]>(W.jump)), shift, npos, mm_modd64(a.t, (uint64_t)lo), lane, map);
-            uint32_t sn[NH];
-#pragma unroll
-            for (int h = 0; h < NH; h++) {
-               sn[h] = 0;
-               if (lane + 64 * h < MAXD) {
-                  tilemap[wave][t - t0][lane + 64 * h] = (uint8_t)map[h];
-               }
-               if ((uint32_t)lane + 64u * h < D) {
-                  sn[h] = suf[map[h]];
-               }
-            }
-            have |= 1u << (t - t0);
-            mm_wave_sync();
-            if (any) {
-               flagged |= 1u << (t - t0);
-               break;
-            }
-            const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sn[0]);
-            bool differs = false;
-#pragma unroll
-            for (int h = 0; h < NH; h++) {
-               if ((uint32_t)lane + 64u * h < D) {
-                  suf[lane + 64 * h] = (uint8_t)sn[h];
-                  differs = differs || sn[h] != s0;
-               }
-            }
-            mm_wave_sync();
-            if (__ballot(differs) == 0) {
-               if (mm_fwd_quiet(a, start, (int64_t)t0 * MM_FWD_TILE, lo, lane)) {
-                  if (lane == 0) {
-                     __hip_atomic_store(a.status + item, MM_FWD_INCLUSIVE | ((unsigned long long)s0 << 8), __ATOMIC_RELAXED,
-                                        __HIP_MEMORY_SCOPE_AGENT);
-                  }
-                  done = true;
-               }
-               break;
-            }
-            if (t == t0) {
-               break;
-            }
-         }
-#ifdef MM_FWD_DEBUG
-         if (lane == 0 && item % 1499 == 0) {
-            printf("batch %llu: maps made %d, flagged %x, done %d\n", (unsigned long long)item, __popc(have), flagged, (int)done);
-         }
-#endif
-         if (done) {
-            continue;
-         }
-      }
       for (uint32_t t = t0; t < t1; t++) {
-         const int64_t lo = (int64_t)t * MM_FWD_TILE;
-         if (((have >> (t - t0)) & 1u) == 0) {
-            uint32_t map[NH];
-#pragma unroll
-            for (int h = 0; h < NH; h++) {
-               map[h] = (uint32_t)lane + 64u * h;   // tiles past the domain's end: identity
-            }
-            if (lo < nv) {
-               const int npos = (int)(nv - lo < MM_FWD_TILE ? nv - lo : MM_FWD_TILE);
-               bool any = false;
-               const uint8_t *tile;
-               int shift;
-               mm_fwd_jumps(a, P, T, W, start, lo, npos, lane, &any, &tile, &shift);
-               mm_fwd_map<NH, MAXD>(a.t, W, (*reinterpret_cast<uint8_t (*)[MM_TILE / 256 + 1][MAXD + 4]>(W.jump)), shift, npos, mm_modd64(a.t, (uint64_t)lo), lane, map);
-               flagged |= any ? 1u << (t - t0) : 0u;
-            }
-#pragma unroll
-            for (int h = 0; h < NH; h++) {
-               if (lane + 64 * h < MAXD) {
-                  tilemap[wave][t - t0][lane + 64 * h] = (uint8_t)map[h];
-               }
-            }
-         }
-         mm_wave_sync();
 #pragma unroll
          for (int h = 0; h < NH; h++) {
             if ((uint32_t)lane + 64u * h < D) {
@@ -698,7 +781,6 @@ __global__ __launch_bounds__(64 * MM_WAVES) void mm_forward(MmForwardArgs a)
          differs = differs || ((uint32_t)lane + 64u * h < D && bm[h] != bm0);
       }
       const bool constant = __ballot(differs) == 0;
-      uint32_t entry = 0;                           // first batch of a domain: the chain starts at its first position
       if (b == 0 || constant) {
          // (b == 0: the chain enters in phase 0, and lane 0 is the first lane)
          if (lane == 0) {
@@ -773,11 +855,20 @@ __global__ __launch_bounds__(64 * MM_WAVES) void mm_forward(MmForwardArgs a)
                                __HIP_MEMORY_SCOPE_AGENT);
          }
       }
-      // ---- pass 2 (rare): the tiles that hold a full match, walked with their true entry phase --
+      }
+      // ---- pass 2 (rare): the tiles to report from, walked with their true entry phase: the batch's entry phase
+      // carried through every tile's map (filled batches), or what the sweep found (centry) carried on through the
+      // maps it made
       if (flagged) {
          uint32_t ph = entry;
-         for (uint32_t t = t0; t < t1; t++) {
-            if ((flagged >> (t - t0)) & 1u) {
+         bool ph_known = !swept;
+         for (uint32_t t = t0; (int)t <= tl && (flagged >> (t - t0)) != 0; t++) {
+            const uint32_t bit = 1u << (t - t0);
+            if (known & bit) {
+               ph = centry[wave][t - t0];
+               ph_known = true;
+            }
+            if (flagged & bit) {
                const int64_t lo = (int64_t)t * MM_FWD_TILE;
                const int npos = (int)(nv - lo < MM_FWD_TILE ? nv - lo : MM_FWD_TILE);
                bool any = false;
@@ -786,7 +877,10 @@ __global__ __launch_bounds__(64 * MM_WAVES) void mm_forward(MmForwardArgs a)
                mm_fwd_jumps(a, P, T, W, start, lo, npos, lane, &any, &tile, &shift);
                mm_fwd_emit(a, W, shift, start, lo, npos, ph, lane);
             }
-            ph = tilemap[wave][t - t0][ph];
+            ph_known = ph_known && (have & bit) != 0;
+            if (ph_known) {
+               ph = tilemap[wave][t - t0][ph];
+            }
          }
       }
    }

@@ -52,6 +52,8 @@ struct MmFusedArgs {
    uint64_t list_cap;
    unsigned int *dom_count;            // always null here
    const uint32_t *skip_bits;          // always null here
+   uint32_t *loud_bits;                // always null here
+   uint32_t loud_tpd, loud_tile;
    uint64_t *bcand;                    // bucketed store (mm_tail2.h); null in the single-launch kernel
    unsigned int *bcount;
    unsigned long long *boverflow;

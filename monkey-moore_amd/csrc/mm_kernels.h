@@ -109,6 +109,7 @@ struct DenseGeom {
    uint32_t tpd;             // tiles per domain
    uint32_t bpd;             // batches (of MM_FWD_BATCH tiles) per domain
    size_t status_bytes;      // ticket + look-back words, at the start of `maps`
+   size_t loud_bytes;        // ... followed by the pre-pass's tile bitmap (0 with listed domains)
    size_t maps_bytes;        // ... followed by one published map per batch
 };
 struct DenseBuffers {

@@ -244,6 +244,10 @@ struct MmFilterArgs {
    // candidate floods (engine mode, see run_candidate_floods in mm_capi.hip); both null in a normal scan
    unsigned int *dom_count;          // count pass: candidates per domain instead of the lists
    const uint32_t *skip_bits;        // filtered pass: candidates of flagged domains are dropped
+   // the forward engine's pre-pass (mm_forward.h): no lists at all -- every survivor sets the bit of its forward-engine tile
+   // (tile (b S + p) loud_tpd + j / loud_tile of the bitmap: "a position of this tile may pass the compare loop"); else null
+   uint32_t *loud_bits;
+   uint32_t loud_tpd, loud_tile;
    // bucketed store (mm_internal.h MM_BUCKET_*; null: the lists above): big ROMs, read by mm_scan_tail2
    uint64_t *bcand;                  // [nb][MM_BUCKET_CAP] candidate byte offsets
    unsigned int *bcount;             // [nb] members of every bucket
@@ -272,6 +276,14 @@ __device__ __forceinline__ void mm_cand_append(const A &a, bool want, uint64_t o
 template <class A>
 __device__ __forceinline__ void mm_cand_emit(const A &a, bool want, uint64_t off)
 {
+   if (a.loud_bits) {                                      // wave uniform
+      uint64_t b = 0; uint32_t p = 0; int64_t j = 0;
+      if (want && mm_locate(a.t.g, off, &b, &p, &j)) {
+         const uint64_t tile = (a.t.g.whole ? 0 : (b * a.t.g.S + p) * a.loud_tpd) + (uint64_t)j / a.loud_tile;
+         atomicOr(a.loud_bits + (tile >> 5), 1u << (tile & 31));
+      }
+      return;
+   }
    if (a.dom_count || a.skip_bits) {                       // wave uniform
       uint64_t b = 0; uint32_t p = 0; int64_t j = 0;
       const bool located = want && mm_locate(a.t.g, off, &b, &p, &j);
@@ -481,8 +493,8 @@ __device__ __forceinline__ void mm_f8_survivors(const A &a, uint64_t chunk0, uin
       }
       return;
    }
-   bool batch = !a.verify && !a.dom_count && !a.skip_bits && !head;
-   if (!a.verify && !head && !batch && !a.t.g.whole) {
+   bool batch = !a.verify && !a.dom_count && !a.skip_bits && !a.loud_bits && !head;
+   if (!a.verify && !head && !batch && !a.t.g.whole && !a.loud_bits) {
       // Flood handling passes, 8-bit: a piece lies in ONE block (= domain) nearly always.  Then
       // the count pass adds the piece's survivors with one atomic and the filtered pass drops
       // or keeps them wholesale, instead of locating every survivor on its own.
@@ -850,7 +862,7 @@ __device__ __forceinline__ void mm_f16_survivors(const A &a, uint64_t chunk0, ui
       }
       return;
    }
-   if (!a.verify && !a.dom_count && !a.skip_bits && __ballot(bits != 0 && chunk0 < 2 * MMH_MAX_KEYWORD + 2) == 0) {
+   if (!a.verify && !a.dom_count && !a.skip_bits && !a.loud_bits && __ballot(bits != 0 && chunk0 < 2 * MMH_MAX_KEYWORD + 2) == 0) {
       uint32_t slot, room;
       uint64_t *list = mm_cand_reserve(a, (uint32_t)__popc(bits), &slot, &room);
       while (bits) {
@@ -1522,6 +1534,7 @@ static void fill_filter_args(A &a, const MmGeom &g, const mmh_plan_desc &pl, con
    }
    a.cand = cand; a.list_count = ctrl + MM_CTRL_LISTS; a.list_cap = cand_cap / MM_CAND_LISTS;
    a.dom_count = nullptr; a.skip_bits = nullptr;
+   a.loud_bits = nullptr; a.loud_tpd = 0; a.loud_tile = 1;
    a.bcand = nullptr; a.bcount = nullptr; a.boverflow = nullptr; a.bshift = 0;
    a.span_tickets = nullptr;
    a.static_rounds = 0;
@@ -1551,6 +1564,24 @@ void launch_filter(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, con
       }
       else {
          launch_filter_pair(mm_filter_u16<SHAPE>, mm_filter_u16_edge<SHAPE>, st, a, g, start, stop);
+      }
+   });
+}
+
+// the forward engine's pre-pass: the streaming filter over the whole ROM, survivors into the tile bitmap (zeroed by the caller)
+static void launch_loud(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc, unsigned long long *ctrl,
+                        uint32_t *bits, uint32_t tpd, uint32_t tile)
+{
+   MmFilterArgs a;
+   fill_filter_args(a, g, pl, fc, nullptr, ctrl, 0, filter_groups_per_span());
+   a.loud_bits = bits; a.loud_tpd = tpd; a.loud_tile = tile;
+   with_shape(pl.elem_bytes, fc, [&](auto elem, auto shape) {
+      constexpr int SHAPE = decltype(shape)::value;
+      if constexpr (decltype(elem)::value == 1) {
+         launch_filter_pair(mm_filter_u8<SHAPE>, mm_filter_u8_edge<SHAPE>, st, a, g, nullptr, nullptr);
+      }
+      else {
+         launch_filter_pair(mm_filter_u16<SHAPE>, mm_filter_u16_edge<SHAPE>, st, a, g, nullptr, nullptr);
       }
    });
 }
@@ -1802,7 +1833,9 @@ DenseGeom dense_geom(const MmGeom &g, uint64_t listed_domains)
    d.bpd = (d.tpd + MM_FWD_BATCH - 1) / MM_FWD_BATCH;
    // [ticket, pad][one look-back word per batch], then one map per batch
    d.status_bytes = (((size_t)d.ndom * d.bpd + 2) * sizeof(unsigned long long) + 255) & ~(size_t)255;
-   d.maps_bytes = d.status_bytes + (size_t)d.ndom * d.bpd * (g.L > MM_MAXD ? MMH_MAX_KEYWORD : MM_MAXD);
+   // ... the pre-pass's tile bitmap (whole-ROM passes only; two words of slack: a batch's bits are read as two words) ...
+   d.loud_bytes = listed_domains ? 0 : ((((size_t)d.ndom * d.tpd + 31) / 32 + 2) * sizeof(uint32_t) + 255) & ~(size_t)255;
+   d.maps_bytes = d.status_bytes + d.loud_bytes + (size_t)d.ndom * d.bpd * (g.L > MM_MAXD ? MMH_MAX_KEYWORD : MM_MAXD);
    return d;
 }
 
@@ -1816,7 +1849,7 @@ static void launch_forward(hipStream_t st, const MmGeom &g, const mmh_plan_desc 
    const uint64_t nbatches = dg.ndom * dg.bpd;
    a.ticket = reinterpret_cast<unsigned long long *>(db.maps);
    a.status = a.ticket + 2;
-   a.agg = db.maps + dg.status_bytes;                 // [batches][MM_MAXD or MMH_MAX_KEYWORD] (dense_geom sized it)
+   a.agg = db.maps + dg.status_bytes + dg.loud_bytes; // [batches][MM_MAXD or MMH_MAX_KEYWORD] (dense_geom sized it)
    a.out = db.out; a.list_count = db.ctrl + MM_CTRL_LISTS; a.list_cap = db.out_cap / MM_CAND_LISTS;
    a.base_offset = base_offset;
    // the table-driven jump path: 8-bit elements, first compare against an element 1..4 to the left
@@ -1837,27 +1870,40 @@ static void launch_forward(hipStream_t st, const MmGeom &g, const mmh_plan_desc 
          a.has2 = 1; a.i2 = (uint32_t)i2; a.g2 = (uint32_t)(-pl.bridge[i2]);
       }
    }
-   // quiet batches (mm_fwd_quiet): only beside the table-driven jump path (8-bit elements), with the streaming filter's conditions
-   a.quiet_shape = 0; a.quiet_iA = 0; a.quiet_pat[0] = a.quiet_pat[1] = 0; a.quiet_sh1 = 0;
+   // Which tiles have something to report (the sweep of mm_forward.h): 8-bit searches on the table path find out themselves, batch
+   // by batch, with the streaming filter's first two conditions; 16-bit searches get a bitmap from the streaming filter itself,
+   // run over the whole ROM before the forward kernel (whole-ROM passes only).  Keywords without a SWAR test: no sweep.
+   a.loud = nullptr;
+   a.loud_shape = 0; a.loud_iA = 0; a.loud_pat[0] = a.loud_pat[1] = 0; a.loud_sh1 = 0;
    FilterChoice fc;
-   if (a.fast && choose_filter(pl, &fc) && !(getenv("MMOORE_FORWARD_QUIET") && *getenv("MMOORE_FORWARD_QUIET") == '0')) {
+   const bool sweeps = choose_filter(pl, &fc) && !(getenv("MMOORE_FORWARD_SWEEP") && *getenv("MMOORE_FORWARD_SWEEP") == '0');
+   if (sweeps && a.fast) {
       const uint32_t nc = fc.ncond < 2 ? fc.ncond : 2;
       uint32_t mask2 = fc.gap[0] == 2 ? 1u : 0u;
       if (nc == 2) {
          mask2 |= fc.gap[1] == 2 ? 2u : 0u;
-         a.quiet_pat[1] = fc.pat[1];
-         a.quiet_sh1 = 32u - 8u * fc.shift[1];
+         a.loud_pat[1] = fc.pat[1];
+         a.loud_sh1 = 32u - 8u * fc.shift[1];
       }
-      a.quiet_shape = 0x100u | (mask2 << 4) | nc;
-      a.quiet_iA = fc.iA;
-      a.quiet_pat[0] = fc.pat[0];
+      a.loud_shape = 0x100u | (mask2 << 4) | nc;
+      a.loud_iA = fc.iA;
+      a.loud_pat[0] = fc.pat[0];
    }
+   const bool prepass = sweeps && !a.fast && !dom_list && dg.loud_bytes != 0;
    {
-      // a workgroup's block of batches (mm_forward.h): 16 on big jobs, 4 -- one batch per wave -- where that leaves workgroups without work
+      // A workgroup's block of batches (mm_forward.h): four -- one per wave, as round 2 handed them out.  Bigger blocks are
+      // slower, and badly so (1 GiB, wildcard keyword: 4 / 8 / 16 / 32 batches -> 0.31 / 0.67 / 0.94 / 1.19 ms): the
+      // workgroups then work 4 x 32 KiB at a time out of regions 8 x ... 32 x 32 KiB apart, and at any moment the reads of
+      // the whole grid land on a fraction of the memory channels.  (MMOORE_FWD_CHUNK: that experiment.)
       const char *e = getenv("MMOORE_FWD_CHUNK");
-      a.chunk = e && atoi(e) >= 4 ? (uint32_t)atoi(e) : (nbatches >= 16ull * 256 * 6 ? 16u : 4u);
+      a.chunk = e && atoi(e) >= 4 ? (uint32_t)atoi(e) : 4u;
    }
-   (void)hipMemsetAsync(db.maps, 0, dg.status_bytes, st);
+   (void)hipMemsetAsync(db.maps, 0, dg.status_bytes + (prepass ? dg.loud_bytes : 0), st);
+   if (prepass) {
+      uint32_t *bits = reinterpret_cast<uint32_t *>(db.maps + dg.status_bytes);
+      launch_loud(st, g, pl, fc, db.ctrl, bits, dg.tpd, (uint32_t)MM_FWD_TILE);
+      a.loud = bits;
+   }
    int device = 0, cus = 256;
    (void)hipGetDevice(&device);
    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
