@@ -1889,7 +1889,15 @@ static void launch_forward(hipStream_t st, const MmGeom &g, const mmh_plan_desc 
       a.loud_iA = fc.iA;
       a.loud_pat[0] = fc.pat[0];
    }
-   const bool prepass = sweeps && !a.fast && !dom_list && dg.loud_bytes != 0;
+   // (the sweep lives on chains that merge.  8-bit: one delta in 25 is in the skip table and moves its chain to another phase;
+   // 16-bit: practically none is, every jump is the default one and the phases never mix -- unless the wildcard loop caps the
+   // jumps (wst): measured on 1 GiB, 16-bit: wildcard keyword 4.98 -> 1.04 ms, plain keyword 5.79 -> 6.45 with a pre-pass that
+   // bought nothing.  So: only with capped jumps.)
+   bool capped = false;
+   for (uint32_t i = 0; i < pl.L; i++) {
+      capped = capped || pl.wst[i] != 255;
+   }
+   const bool prepass = sweeps && !a.fast && capped && !dom_list && dg.loud_bytes != 0;
    {
       // A workgroup's block of batches (mm_forward.h): four -- one per wave, as round 2 handed them out.  Bigger blocks are
       // slower, and badly so (1 GiB, wildcard keyword: 4 / 8 / 16 / 32 batches -> 0.31 / 0.67 / 0.94 / 1.19 ms): the
