@@ -437,7 +437,19 @@ __device__ __forceinline__ uint32_t mm_fwd_loud_t(const MmForwardArgs &a, uint64
             back = w[k].w;
          }
       }
-      if (__ballot(some != 0) != 0) {
+      const unsigned long long crowd = __ballot(some != 0);
+      if (__popcll(crowd) > 4) {
+         // hits all over the step (a flood: padding, low-entropy data): its tiles are loud, no questions asked -- loud may
+         // say so of a tile too many (pass 2 then walks a tile that reports nothing), and running the compare loop from
+         // global memory for every lane of every step cost floods a quarter more time than the whole engine without the sweep
+         const uint64_t b0 = piece > first ? piece : first, b1 = piece + 4095 < last ? piece + 4095 : last;
+         const uint32_t k0 = (uint32_t)(b0 - first) / MM_FWD_TILE, k1 = (uint32_t)(b1 - first) / MM_FWD_TILE;
+         mask |= (2u << k1) - (1u << k0);
+         if (mask == (2u << ((uint32_t)(last - first) / MM_FWD_TILE)) - 1u) {
+            break;                                                         // every tile is loud already
+         }
+      }
+      else if (crowd != 0) {
          uint32_t mine = 0;
          if (some) {
             // (rare: the flags again, chunk by chunk, from bytes loaded again: keeping the four chunks alive through

@@ -692,3 +692,57 @@ def test_candidate_flood_in_a_padding_run(mm, gpu_engine, oracle, kw, elem, hard
     gpu_engine.set_engine(0)
     t = gpu_engine.submit(plan, block_bytes=block)
     assert gpu_engine.collect(t, cap=1 << 21).tolist() == want.tolist()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MM_SWEEP_SEEDS", "8"))))       # raise for a soak
+def test_forward_engine_sweep_on_mixed_roms(mm, gpu_engine, oracle, seed):
+    """The forward engine forced (mmh_set_engine 2) on ROMs that make its sparse sweep take every turn (csrc/mm_forward.h,
+    pass 1): random stretches (maps constant after 1 - 4 tiles: swept batches), sparse and clustered plants (loud tiles
+    next to each other, at a batch's first and last tile), low-entropy stretches and padding (chains that never merge:
+    sweep -> fill, look-back over many batches), 8-bit plain / wildcard keywords (loud tiles found in the kernel), 16-bit
+    wildcard keywords (the bitmap pre-pass) and 16-bit plain ones (no sweep) -- blocks of 512 KiB, 64 KiB, 8191 bytes and
+    one chain over the whole buffer, against the oracle."""
+    rng = np.random.default_rng(31000 + seed)
+    elem = 1 if seed % 4 != 3 else 2
+    be = elem == 2 and seed % 8 == 7
+    kw, wc = [("relative", 0), ("re*at*ve", ord("*")), ("abcab", 0), ("te*ts*h", ord("*"))][seed % 4]
+    n = (20 << 20) + int(rng.integers(0, 5000)) * elem
+    hi = 256 if elem == 1 else 65536
+    d = rng.integers(0, hi, n // elem).astype(np.int64)
+    vals = [None if (wc and ord(c) == wc) else ord(c) for c in kw]
+    lits = [v for v in vals if v is not None]
+
+    def plant(pos):
+        sh = int(rng.integers(-min(lits), hi - max(lits)))
+        for j, v in enumerate(vals):
+            if v is not None and pos + j < d.size:
+                d[pos + j] = v + sh
+    for _ in range(300):                                      # sparse
+        plant(int(rng.integers(0, d.size - 16)))
+    for c in range(12):                                       # clusters: neighbouring tiles, tile and batch edges
+        at = int(rng.integers(0, d.size - 40000))
+        at -= at % 2044 if c % 3 == 0 else (at % 32704 if c % 3 == 1 else 0)
+        for k in range(int(rng.integers(2, 30))):
+            plant(max(0, at + int(rng.integers(-20, 6200))))
+    for _ in range(5):                                        # low entropy / padding: chains that do not merge
+        at = int(rng.integers(0, d.size - (1 << 20)))
+        ln = int(rng.integers(3000, 600000))
+        alpha = int(rng.choice([1, 2, 3, 5]))
+        d[at:at + ln] = rng.integers(0, alpha, ln) + int(rng.integers(0, hi - 8))
+    if seed % 2:
+        a = int(rng.integers(0, d.size - 70000))
+        d[a:a + 66000] = np.arange(66000) % 251               # a ramp: 'abc..'-like keywords match it wholesale
+    rom = d.astype(np.uint8 if elem == 1 else (">u2" if be else "<u2")).view(np.uint8)
+    gpu_engine.upload(rom)
+    plan, oplan = mm.plan_relative(elem, kw, wc), oracle.plan(elem, kw, wc)
+    gpu_engine.set_engine(2)
+    try:
+        for block in (524288, 65536, 8191):
+            got = gpu_engine.scan(plan, block_bytes=block, big_endian=be, cap=1 << 21)
+            assert gpu_engine.counters()["path"] == 3
+            assert got.tolist() == oracle.engine(oplan, rom, block, be).tolist(), (seed, kw, block)
+        if not be:
+            data = rom if elem == 1 else rom[: (rom.size // 2) * 2].view("<u2")
+            assert gpu_engine.scan(plan, cap=1 << 21).tolist() == oracle.search(oplan, data).tolist(), (seed, kw, "whole")
+    finally:
+        gpu_engine.set_engine(0)
