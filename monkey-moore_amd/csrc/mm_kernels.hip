@@ -226,6 +226,8 @@ struct MmTileArgs {
    uint32_t inv_d32;        // floor(2^32 / D) + 1: quotient estimate for 32-bit x, at most one too big
    uint32_t block_shift;    // log2(block_bytes) when that is a power of two, else ~0
    uint64_t skip_bloom;     // bit (d & 63) set for every listed bad-character diff
+   uint64_t skip_bloom2;    // ... bit ((d >> 6) & 63) ...
+   uint64_t skip_bloom3;    // ... and bit ((d >> 12) & 63): a 16-bit delta that is in none of the lists passes all three once in ~1000
 };
 
 // Arguments of the streaming code.  The span / edge kernels take this struct; the fused scan kernel
@@ -1765,9 +1767,12 @@ static MmTileArgs tile_args(const MmGeom &g, const mmh_plan_desc &pl)
    if (g.block_bytes && (g.block_bytes & (g.block_bytes - 1)) == 0) {
       t.block_shift = (uint32_t)__builtin_ctzll(g.block_bytes);
    }
-   t.skip_bloom = 0;
+   t.skip_bloom = t.skip_bloom2 = t.skip_bloom3 = 0;
    for (uint32_t k = 0; k < pl.n_skip; k++) {
-      t.skip_bloom |= 1ull << ((uint32_t)pl.skip_diff[k] & 63);
+      const uint32_t d = (uint32_t)pl.skip_diff[k];
+      t.skip_bloom |= 1ull << (d & 63);
+      t.skip_bloom2 |= 1ull << ((d >> 6) & 63);
+      t.skip_bloom3 |= 1ull << ((d >> 12) & 63);
    }
    return t;
 }

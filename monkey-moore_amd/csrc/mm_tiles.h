@@ -175,7 +175,9 @@ __device__ __forceinline__ int mm_tile_skip(const MmTileArgs &a, const MmPlanLds
    }
    int s = a.plan.default_skip;
    s = s < 1 ? 1 : s;
-   if ((a.skip_bloom >> (d & 63)) & 1) {
+   // (three 64-bit filters on bits 0-5, 6-11 and 12-17 of the delta: with one, a tenth of the lanes passed and every wave
+   // ran the list below for every position -- 16-bit searches on the forward engine spent most of their time here)
+   if ((a.skip_bloom >> (d & 63)) & (a.skip_bloom2 >> (((uint32_t)d >> 6) & 63)) & (a.skip_bloom3 >> (((uint32_t)d >> 12) & 63)) & 1) {
       const int n = (int)a.plan.n_skip;
       for (int k = 0; k < n; k++) {
          s = P.skip_diff[k] == d ? P.skip_val[k] : s;
