@@ -547,7 +547,7 @@ __global__ __launch_bounds__(64 * MM_WAVES) __attribute__((amdgpu_waves_per_eu(E
    WL &W = Wv[wave];
    const uint64_t nbatches = a.ndom * a.bpd;
 
-   // Hand-out (round 3; before: one ticket per workgroup and four batches, its four waves in step -- with quiet
+   // Hand-out (round 3; before: one ticket per workgroup and four batches, its four waves in step -- with swept
    // batches a tenth of the batches takes five times as long as the rest, and a workgroup whose waves wait for each
    // other spends a third of its rounds at the slow one's pace).  Now the workgroup draws BLOCKS of a.chunk consecutive
    // batches from the global ticket and its waves take batches out of the current block one by one through a counter

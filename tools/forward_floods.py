@@ -1,3 +1,8 @@
+# SPDX-License-Identifier: GPL-3.0-or-later
+"""Dev probe: the forward engine forced (mmh_set_engine(ctx, 2)) on 1 GiB of data where nearly every tile has something to
+report -- 4096 plants per MiB, alphabets of 3 / 16 symbols -- and on the same data with a keyword that never matches:
+what the sparse sweep's reading costs where it cannot save anything, what it saves on low-entropy data.  Run it again
+with MMOORE_FORWARD_SWEEP=0 for the engine without the sweep.  -> profiles/rNN_forward_floods.log"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from __graft_entry__ import load_package
