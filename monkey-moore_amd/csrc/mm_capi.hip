@@ -863,6 +863,12 @@ int run_dense(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, uint64_t bas
    db.maps = c->d_dense;
    db.out = c->ws[0].d_out; db.out_cap = c->ws[0].out_cap; db.ctrl = c->ws[0].d_ctrl;
 
+   {
+      const int rc = grow(&c->d_sort_in, &c->sort_in_cap, c->ws[0].out_cap);     // (the lists together never hold more)
+      if (rc != MMH_OK) {
+         return rc;
+      }
+   }
    HIP_TRY(hipMemsetAsync(c->ws[0].d_ctrl, 0, mm::ctrl_bytes(), st));
    c->ws[0].ctrl_clean = false;
    begin_scan_events(c, false);
@@ -871,12 +877,16 @@ int run_dense(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, uint64_t bas
    mm::launch_dense(st, g, pl, dg, db, base_offset, dom_list);
    HIP_TRY(hipGetLastError());
    HIP_TRY(hipEventRecord(c->ev[2], st));
+   // the lists one behind the other, for the ordering: one launch right behind the engine (it was a copy per list after
+   // the counters had come back: 0.15 ms of enqueueing for a thousand matches)
+   const uint64_t list_cap = c->ws[0].out_cap / MM_CAND_LISTS;
+   mm::launch_pack_lists(st, c->ws[0].d_out, list_cap, c->ws[0].d_ctrl + MM_CTRL_LISTS, c->d_sort_in);
+   HIP_TRY(hipGetLastError());
    std::vector<unsigned long long> ctrl(mm::ctrl_bytes() / sizeof(unsigned long long));
    HIP_TRY(hipMemcpyAsync(ctrl.data(), c->ws[0].d_ctrl, mm::ctrl_bytes(), hipMemcpyDeviceToHost, st));
    HIP_TRY(hipStreamSynchronize(st));
    c->scans_recorded++;
 
-   const uint64_t list_cap = c->ws[0].out_cap / MM_CAND_LISTS;
    uint64_t most = 0, total = 0;
    for (int l = 0; l < MM_CAND_LISTS; l++) {
       const uint64_t n = ctrl[MM_CTRL_LISTS + l * MM_LIST_STRIDE];
@@ -892,19 +902,7 @@ int run_dense(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, uint64_t bas
       *grew = true;
       return MMH_OK;
    }
-   // pack the lists, then order them the way search_engine.cpp:193-197 does -- on the device
-   int rc = grow(&c->d_sort_in, &c->sort_in_cap, total);
-   if (rc != MMH_OK) {
-      return rc;
-   }
-   uint64_t at = 0;
-   for (int l = 0; l < MM_CAND_LISTS; l++) {
-      const uint64_t n = ctrl[MM_CTRL_LISTS + l * MM_LIST_STRIDE];
-      if (n) {
-         HIP_TRY(hipMemcpyAsync(c->d_sort_in + at, c->ws[0].d_out + (uint64_t)l * list_cap, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
-         at += n;
-      }
-   }
+   // order them the way search_engine.cpp:193-197 does -- on the device
    return sort_to_host(c, c->d_sort_in, total, found);
 }
 

@@ -122,6 +122,8 @@ struct DenseBuffers {
 DenseGeom dense_geom(const MmGeom &g, uint64_t listed_domains = 0);
 void launch_dense(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const DenseGeom &dg, const DenseBuffers &db,
                   uint64_t base_offset, const uint32_t *dom_list = nullptr);
+// the MM_CAND_LISTS lists of `lists` (list_cap entries each, counters MM_LIST_STRIDE words apart) one behind the other in `packed`
+void launch_pack_lists(hipStream_t st, const uint64_t *lists, uint64_t list_cap, const unsigned long long *list_count, uint64_t *packed);
 void launch_chain_seq(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, uint64_t *out,
                       unsigned long long *out_count, uint64_t out_cap, uint64_t base_offset);
 // orders the ctrl[count_index] keys of `in` into host_result[8..] (pinned host memory) and

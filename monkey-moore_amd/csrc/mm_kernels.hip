@@ -1985,6 +1985,28 @@ void launch_synth(hipStream_t st, uint8_t *rom, uint64_t nbytes, uint64_t seed, 
    hipLaunchKernelGGL(mm_synth_fill, dim3(2048), dim3(256), 0, st, rom, nbytes, seed, base_offset);
 }
 
+// The forward engine's MM_CAND_LISTS output lists, one behind the other in `packed` (what the ordering takes): block (l, part)
+// copies its share of list l to where the lists in front of it end.  One launch instead of a copy per list.
+__global__ __launch_bounds__(256) void mm_pack_lists(const uint64_t *lists, uint64_t list_cap, const unsigned long long *count, uint64_t *packed)
+{
+   const uint32_t l = blockIdx.x;
+   uint64_t before = 0;
+   for (uint32_t k = 0; k < l; k++) {
+      const uint64_t n = count[k * MM_LIST_STRIDE];
+      before += n < list_cap ? n : list_cap;
+   }
+   uint64_t n = count[l * MM_LIST_STRIDE];
+   n = n < list_cap ? n : list_cap;                 // (an overflowed list: the caller sizes the lists anew and scans again)
+   for (uint64_t i = (uint64_t)blockIdx.y * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.y * 256) {
+      packed[before + i] = lists[(uint64_t)l * list_cap + i];
+   }
+}
+
+void launch_pack_lists(hipStream_t st, const uint64_t *lists, uint64_t list_cap, const unsigned long long *list_count, uint64_t *packed)
+{
+   hipLaunchKernelGGL(mm_pack_lists, dim3(MM_CAND_LISTS, 16), dim3(256), 0, st, lists, list_cap, list_count, packed);
+}
+
 void launch_gather(hipStream_t st, const uint8_t *rom, uint64_t nbytes, const uint64_t *offsets, uint64_t n, uint32_t each,
                    uint8_t *out)
 {
