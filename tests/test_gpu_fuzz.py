@@ -65,7 +65,10 @@ def _rom(rng, nbytes, elem, be, kw, wc, seq, alphabet):
     return np.concatenate([arr, tail])
 
 
-@pytest.mark.parametrize("seed", range(SEEDS))
+FIRST = int(os.environ.get("MM_FUZZ_FIRST", "0"))         # a soak's failing neighbourhood again: MM_FUZZ_FIRST=290 MM_FUZZ_SEEDS=30
+
+
+@pytest.mark.parametrize("seed", range(FIRST, FIRST + SEEDS))
 def test_fuzz_against_oracle(mm, gpu_engine, oracle, seed):
     rng = np.random.default_rng(7000 + seed)
     for case in range(24):
