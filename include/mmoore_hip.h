@@ -247,6 +247,55 @@ int mmh_timing_history(mmh_ctx *ctx, float *filter_ms, float *total_ms, int cap,
  * dense engine on the domains that hold most candidates, filter + resolver on the rest -- [2] is
  * the number of flooded domains). */
 int mmh_last_counters(mmh_ctx *ctx, uint64_t *c4);
+/* ---- route health ------------------------------------------------------------------------------
+ * The fast routes of a scan -- zero-copy upload of small buffers (the kernels read pinned host memory over PCIe), the
+ * single-launch kernel with its grid barrier, the bucketed candidate store, results announced through a polled word
+ * in pinned memory instead of a HIP event -- are cross-checked three ways:
+ *   * the first mmh_create on a device runs a known-answer scan (mmh_selftest_kat) through the fast routes, through
+ *     the plain event-synchronised kernels and through the sequential chain kernel; a fast route that returns
+ *     anything else is switched off for the process, loudly (stderr), and mmh_create fails when even the plain
+ *     kernels disagree with the known answer (MMOORE_SELFTEST=0 skips the test);
+ *   * every block a polled scan publishes is validated before it is trusted (flag bits, counts against capacities,
+ *     no slot still holding the poison the host left there, offsets strictly ascending and inside the ROM); a
+ *     violation reruns the scan through the plain kernels and is remembered (sticky) -- never a wrong list in silence;
+ *   * mmh_set_route switches routes off at run time, so that a caller (tests/test_gpu_fuzz.py on a mismatch,
+ *     tools/soak_fuzz.sh) can scan the same ROM every way in one process and see which routes disagree.
+ * MonkeyMoore<Ty>::search at the reference benchmark's sizes (benchmarks/bench_search.cpp:67-105 -> src/core/
+ * monkey_moore.cpp:41-49) takes exactly these routes. */
+enum {
+   MMH_ROUTE_NO_SINGLE_LAUNCH = 1,   /* ROMs of <= 4 MiB: streaming kernel + tail kernel instead of mm_scan_fused */
+   MMH_ROUTE_NO_ZERO_COPY = 2,       /* uploads of <= 512 KiB are copied to HBM like any other */
+   MMH_ROUTE_NO_BUCKETS = 4,         /* the 64 candidate lists + mm_scan_tail instead of the bucketed store + mm_scan_tail2 */
+   MMH_ROUTE_NO_POLLED = 8           /* mm_resolve + rank kernels, the scan's end waited for on a HIP event */
+};
+enum {
+   MMH_FB_NONE = 0,
+   MMH_FB_HEADER = 1,                /* flag bits / counters of the published header contradict each other or the scan */
+   MMH_FB_CAPACITY = 2,              /* more slots or matches announced than the block or the scan's limits allow */
+   MMH_FB_STALE_SLOT = 3,            /* a slot still held the host's poison 2 ms after the flag word showed */
+   MMH_FB_ORDER = 4,                 /* the list is not strictly ascending, or its length is not the announced one */
+   MMH_FB_RANGE = 5,                 /* an offset outside the ROM */
+   MMH_FB_SELFTEST = 6               /* (process-wide) the first-use self-test switched a route off */
+};
+/* mask: MMH_ROUTE_* bits to switch OFF on this context from the next upload / scan on (0: all routes on). */
+int mmh_set_route(mmh_ctx *ctx, uint32_t mask);
+/* h[0] first violation seen on this context (MMH_FB_*, sticky; 0 = none), [1] scans rerun through the plain kernels
+ * because of one, [2] result slots that showed after the flag word and were waited for (not a violation), [3] the
+ * most recent violation, [4] routes off in effect (context | process), [5] routes the self-test switched off for the
+ * process, [6] self-test state of the context's device (0 not run, 1 passed, 2 passed with routes off, 3 failed),
+ * [7] scans validated; [8..15] header words 0..7 of the block the last synchronous scan published. */
+int mmh_health(mmh_ctx *ctx, uint64_t *h16);
+/* The self-test's known answer (host only): a 4133-byte ROM, the keyword "abcde" (8-bit, no wildcards), blocks of
+ * 1024 bytes; expected = what the reference's engine reports (tests/test_oracle.py checks that against the oracle). */
+int mmh_selftest_kat(uint8_t *rom, uint64_t rom_cap, uint64_t *rom_bytes, uint64_t *expected, uint64_t expected_cap,
+                     uint64_t *expected_count);
+/* Runs the self-test again on this context's device (a context of its own); *routes_off = what it would switch off;
+ * MMH_E_DEVICE when the plain kernels fail it. */
+int mmh_selftest_run(int device, uint32_t *routes_off);
+/* Tests only: damage the block the next polled scan of this context publishes, on the host, before it is validated --
+ * 1 flag bits, 2 a slot left at the poison, 3 two slots swapped, 4 a slot outside the ROM, 5 the announced count. */
+int mmh_debug_inject(mmh_ctx *ctx, uint32_t kind);
+
 /* How the streaming filter keys on a plan (host only, no device needed; tests and tuning):
  * info[0] number of SWAR conditions (0 = none: the dense engine runs), [1] anchor keyword
  * position, [2] kernel shape id, [3] 1 when survivors are verified inside the filter kernel,

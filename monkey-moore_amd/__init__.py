@@ -31,7 +31,10 @@ EXPORTS = [
     "mmh_scan_submit", "mmh_scan_collect", "mmh_rom_load_file_watched",
     "mmh_partition", "mmh_comm_unique_id", "mmh_comm_init_rank", "mmh_comm_init_all", "mmh_comm_info", "mmh_comm_destroy",
     "mmh_gather_start", "mmh_gather_finish", "mmh_last_gather_timings", "mmh_scan_multi", "mmh_selftest_gather_pack",
+    "mmh_set_route", "mmh_health", "mmh_selftest_kat", "mmh_selftest_run", "mmh_debug_inject",
 ]
+ROUTE_NO_SINGLE_LAUNCH, ROUTE_NO_ZERO_COPY, ROUTE_NO_BUCKETS, ROUTE_NO_POLLED = 1, 2, 4, 8
+FB_NONE, FB_HEADER, FB_CAPACITY, FB_STALE_SLOT, FB_ORDER, FB_RANGE, FB_SELFTEST = range(7)
 MMH_GATHER_RECORD_WORDS = 8 + 16384
 MMH_MAX_IN_FLIGHT = 3
 MMH_COMM_ID_BYTES = 128
@@ -126,6 +129,11 @@ def lib():
         L.mmh_last_gather_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.mmh_selftest_gather_pack.argtypes = [C.c_void_p, u64p, C.c_int, u64p, C.c_uint64, u64p, u64p]
         L.mmh_scan_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(PlanDesc), C.c_uint64, C.c_int, u64p, u64p, C.c_uint64, u64p]
+        L.mmh_set_route.argtypes = [C.c_void_p, C.c_uint32]
+        L.mmh_health.argtypes = [C.c_void_p, u64p]
+        L.mmh_selftest_kat.argtypes = [C.POINTER(C.c_uint8), C.c_uint64, u64p, u64p, C.c_uint64, u64p]
+        L.mmh_selftest_run.argtypes = [C.c_int, u32p]
+        L.mmh_debug_inject.argtypes = [C.c_void_p, C.c_uint32]
         _lib = L
     return _lib
 
@@ -207,6 +215,22 @@ def scan_multi(engines, plan, block_bytes, base_offsets, big_endian=False, cap=1
             continue
         _check(rc)
         return out[: count.value].copy()
+
+
+def selftest_kat():
+    """(rom bytes, keyword, block_bytes, expected offsets) of the library's first-use self-test (host only)."""
+    rom = np.zeros(8192, np.uint8)
+    exp = np.zeros(64, np.uint64)
+    nb, ne = C.c_uint64(0), C.c_uint64(0)
+    _check(lib().mmh_selftest_kat(rom.ctypes.data_as(C.POINTER(C.c_uint8)), rom.size, C.byref(nb), _p(exp, C.c_uint64), exp.size, C.byref(ne)))
+    return rom[: nb.value].copy(), "abcde", 1024, exp[: ne.value].copy()
+
+
+def selftest_run(device=0):
+    """Runs the known-answer self-test on a device; returns the MMH_ROUTE_* mask it would switch off (0: all routes fine)."""
+    off = C.c_uint32(0)
+    _check(lib().mmh_selftest_run(device, C.byref(off)))
+    return off.value
 
 
 def device_count():
@@ -403,6 +427,20 @@ class Engine:
         f, t, k = (C.c_float * n)(), (C.c_float * n)(), C.c_int(0)
         _check(lib().mmh_timing_history(self._h, f, t, n, C.byref(k)))
         return np.array(f[: k.value]), np.array(t[: k.value])
+
+    def set_route(self, mask):
+        """Switch fast routes off on this context (ROUTE_* bits; 0 = all on)."""
+        _check(lib().mmh_set_route(self._h, mask))
+
+    def inject(self, kind):
+        """Tests: damage the next polled scan's published block on the host (mmh_debug_inject)."""
+        _check(lib().mmh_debug_inject(self._h, kind))
+
+    def health(self):
+        h = (C.c_uint64 * 16)()
+        _check(lib().mmh_health(self._h, h))
+        return dict(fallback_reason=int(h[0]), fallbacks=int(h[1]), late_slots=int(h[2]), last_reason=int(h[3]), routes_off=int(h[4]),
+                    process_routes_off=int(h[5]), selftest=int(h[6]), validated=int(h[7]), header=[int(v) for v in h[8:16]])
 
     def counters(self):
         c = (C.c_uint64 * 4)()

@@ -37,10 +37,29 @@ def _run(cmd):
     return r.stdout
 
 
+def _stamp_matches(target, digest):
+    """The built library next to a stamp file holding the hash of the sources it was built from: nothing to do.
+    (File times do not survive the copy to the GPU box, and lib/obj/ does not travel at all: without the stamp every
+    process there rebuilt the library -- two minutes of hipcc per pytest run.)"""
+    try:
+        with open(target + ".stamp") as f:
+            return os.path.exists(target) and f.read().strip() == digest
+    except OSError:
+        return False
+
+
+def _write_stamp(target, digest):
+    with open(target + ".stamp", "w") as f:
+        f.write(digest + "\n")
+
+
 def build_capi(force=False):
     """libmmoore_hip.so: every csrc translation unit to its own object (in parallel), then one link."""
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIB_DIR, exist_ok=True)
+    digest = device_source_sha16()
+    if not force and _stamp_matches(CAPI_SO, digest):
+        return CAPI_SO
     obj_dir = os.path.join(LIB_DIR, "obj")
     os.makedirs(obj_dir, exist_ok=True)
     units = ("mm_kernels.hip", "mm_capi.hip", "mm_multi.hip", "mm_ingest.hip", "mm_sort.hip", "mm_plan.cpp")
@@ -58,6 +77,7 @@ def build_capi(force=False):
     if force or _newer(CAPI_SO, objs):
         # librccl: the multi-GPU offset gather (mm_multi.hip) calls RCCL itself
         _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", *objs, "-pthread", "-L" + ROCM_LIB, "-lrccl", "-o", CAPI_SO])
+    _write_stamp(CAPI_SO, digest)
     return CAPI_SO
 
 
@@ -68,10 +88,24 @@ def build_core(force=False):
         return None
     inc = os.path.join(ROOT, "include", "mmoore")
     deps = srcs + [os.path.join(inc, f) for f in os.listdir(inc)] + [CAPI_SO]
-    if force or _newer(CORE_SO, deps):
+    digest = _files_sha16(sorted(deps[:-1]) + [os.path.join(ROOT, "include", "mmoore_hip.h")]) + "-" + device_source_sha16()
+    if not force and _stamp_matches(CORE_SO, digest):
+        return CORE_SO
+    if force or _newer(CORE_SO, deps) or not _stamp_matches(CORE_SO, digest):
         _run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-pthread", "-I" + os.path.join(ROOT, "include"),
               *srcs, "-L" + LIB_DIR, "-lmmoore_hip", "-Wl,-rpath,$ORIGIN", "-o", CORE_SO])
+    _write_stamp(CORE_SO, digest)
     return CORE_SO
+
+
+def _files_sha16(paths):
+    import hashlib
+    h = hashlib.sha256()
+    for path in paths:
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def device_source_sha16():

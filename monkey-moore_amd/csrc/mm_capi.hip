@@ -75,14 +75,29 @@ mm::ResolveBuffers resolve_buffers(const MmWorkspace &w)
    return rb;
 }
 
-// the bucketed candidate store of a workspace (big ROMs only: 32 MiB), counters zeroed
-int ensure_buckets(mmh_ctx *c, MmWorkspace &w, hipStream_t st)
+// The bucketed candidate store of a workspace, counters zeroed: MM_BUCKET_CAP slots for each of the buckets THIS ROM is
+// cut into (mm::bucket_geom: <= 4096 buckets, 128 MiB for ROMs of >= 16 MiB; a 64 KiB ROM's 17 buckets take 544 KiB),
+// grown when a larger ROM arrives.  The counters are always there for all MM_MAX_BUCKETS (16 KiB: mm_scan_tail2 sums
+// them all).  (Until round 4 every workspace that met a ROM beyond the single-launch kernel's took the full 128 MiB.)
+int ensure_buckets(mmh_ctx *c, MmWorkspace &w, hipStream_t st, uint64_t rom_bytes)
 {
-   if (!w.d_bcand) {
+   const uint64_t need = mm::bucket_geom(rom_bytes).nb;
+   if (!w.d_bcount) {
       HIP_TRY(hipSetDevice(c->device));
-      HIP_TRY(hipMalloc(&w.d_bcand, mm::bucket_cand_bytes()));
       HIP_TRY(hipMalloc(&w.d_bcount, mm::bucket_count_bytes()));
       w.buckets_clean = false;
+   }
+   if (need > w.bcand_buckets) {
+      HIP_TRY(hipSetDevice(c->device));
+      if (w.d_bcand) {
+         // (nothing of this workspace is in flight: a workspace runs one scan at a time and the previous one was waited for)
+         HIP_TRY(hipFree(w.d_bcand));
+         w.d_bcand = nullptr;
+         w.bcand_buckets = 0;
+      }
+      const uint64_t want = std::min<uint64_t>(MM_MAX_BUCKETS, need + need / 4 + 1);
+      HIP_TRY(hipMalloc(&w.d_bcand, want * MM_BUCKET_CAP * sizeof(uint64_t)));
+      w.bcand_buckets = want;
    }
    if (!w.buckets_clean) {
       HIP_TRY(hipMemsetAsync(w.d_bcount, 0, mm::bucket_count_bytes(), st));
@@ -108,7 +123,10 @@ int ensure_workspace(mmh_ctx *c, MmWorkspace &w, uint64_t out_cap)
       HIP_TRY(hipMalloc(&w.d_scratch, mm::hard_scratch_bytes()));
       HIP_TRY(hipMalloc(&w.d_partials, mm::rank_partials_bytes(kMaxRankSort)));
       HIP_TRY(hipHostMalloc(&w.h_result, MM_RESULT_BLOCK_WORDS * sizeof(uint64_t), hipHostMallocDefault));
-      std::memset(w.h_result, 0, MM_RESULT_BLOCK_WORDS * sizeof(uint64_t));
+      std::memset(w.h_result, 0, kHeaderWords * sizeof(uint64_t));
+      std::memset(w.h_result + kHeaderWords, 0xFE, (size_t)MM_MAX_PUBLISH * sizeof(uint64_t));   // MM_SLOT_POISON in every slot
+      std::memset(w.h_result + MM_HDR_FLAG_WORD, 0, (MM_RESULT_BLOCK_WORDS - MM_HDR_FLAG_WORD) * sizeof(uint64_t));
+      w.dirty_slots = 0;
       for (auto &d : w.d_result) {
          HIP_TRY(hipMalloc(&d, MM_RESULT_BLOCK_WORDS * sizeof(uint64_t)));
       }
@@ -186,6 +204,11 @@ void release_rom(mmh_ctx *c)
 // Uploads of up to this many bytes are not copied to HBM at all: they are copied into a pinned host
 // buffer and the kernels read that over PCIe (a 128 KiB hipMemcpy from pageable memory costs ~20 us
 // of a ~45 us MonkeyMoore<T>::search; a CPU memcpy of it 4 us and the scan reads it once).
+// routes the first-use self-test found returning wrong results on this machine: off for the whole process
+std::atomic<uint32_t> g_routes_off{0};
+
+uint32_t routes_off(const mmh_ctx *c) { return c->route_off | g_routes_off.load(std::memory_order_relaxed); }
+
 uint64_t zero_copy_limit()
 {
    static const uint64_t v = [] {
@@ -214,12 +237,10 @@ extern "C" int mmh_device_count(int *count)
    return MMH_OK;
 }
 
-extern "C" int mmh_create(int device, mmh_ctx **out)
+namespace {
+
+int create_context(int device, mmh_ctx **out)
 {
-   if (!out) {
-      mmh_set_error("mmh_create: null argument");
-      return MMH_E_ARG;
-   }
    *out = nullptr;
    int n = 0;
    if (mmh_device_count(&n) != MMH_OK || n == 0) {
@@ -241,6 +262,65 @@ extern "C" int mmh_create(int device, mmh_ctx **out)
    }
    c->stream = c->own_stream;
    *out = c;
+   return MMH_OK;
+}
+
+// first-use self-test, once per device and process (mmh_selftest_run at the end of this file)
+constexpr int kSelftestDevices = 64;
+std::once_flag g_selftest_once[kSelftestDevices];
+std::atomic<int> g_selftest_state[kSelftestDevices];        // 0 not run, 1 passed, 2 passed with routes off, 3 failed
+std::atomic<uint32_t> g_selftest_off[kSelftestDevices];
+std::string g_selftest_error[kSelftestDevices];
+
+bool selftest_enabled()
+{
+   static const bool on = [] {
+      const char *v = getenv("MMOORE_SELFTEST");
+      return !(v && *v == '0');
+   }();
+   return on;
+}
+
+} // namespace
+
+extern "C" int mmh_create(int device, mmh_ctx **out)
+{
+   if (!out) {
+      mmh_set_error("mmh_create: null argument");
+      return MMH_E_ARG;
+   }
+   const int rc = create_context(device, out);
+   if (rc != MMH_OK) {
+      return rc;
+   }
+   if (selftest_enabled() && device < kSelftestDevices) {
+      std::call_once(g_selftest_once[device], [device] {
+         uint32_t off = 0;
+         const int st = mmh_selftest_run(device, &off);
+         g_selftest_off[device] = off;
+         if (st != MMH_OK) {
+            g_selftest_error[device] = mmh_last_error();
+            g_selftest_state[device] = 3;
+            fprintf(stderr, "libmmoore_hip: SELF-TEST FAILED on device %d: %s\n", device, g_selftest_error[device].c_str());
+         }
+         else if (off) {
+            g_routes_off.fetch_or(off);
+            g_selftest_state[device] = 2;
+            fprintf(stderr, "libmmoore_hip: self-test on device %d: a fast route returned wrong results; routes 0x%x are switched off for "
+                            "this process (MMH_ROUTE_*: 1 single-launch kernel, 2 zero-copy upload, 4 bucketed store, 8 polled results)\n",
+                    device, off);
+         }
+         else {
+            g_selftest_state[device] = 1;
+         }
+      });
+      if (g_selftest_state[device] == 3) {
+         mmh_destroy(*out);
+         *out = nullptr;
+         mmh_set_error("mmh_create: the device fails the known-answer self-test even on the plain kernels (%s)", g_selftest_error[device].c_str());
+         return MMH_E_DEVICE;
+      }
+   }
    return MMH_OK;
 }
 
@@ -343,7 +423,14 @@ extern "C" int mmh_rom_upload(mmh_ctx *c, const void *host, uint64_t nbytes)
       mmh_set_error("mmh_rom_upload: bad argument");
       return MMH_E_ARG;
    }
-   if (nbytes && nbytes <= zero_copy_limit()) {
+   {
+      // (copies of an aborted file load may still be on their way into the old ROM, or into the staging they came from)
+      const int rc = mm_ingest_drain(c);
+      if (rc != MMH_OK) {
+         return rc;
+      }
+   }
+   if (nbytes && nbytes <= zero_copy_limit() && !(routes_off(c) & MMH_ROUTE_NO_ZERO_COPY)) {
       HIP_TRY(hipSetDevice(c->device));
       if (!c->rom_host) {
          void *p = nullptr;
@@ -407,6 +494,12 @@ extern "C" int mmh_rom_synth(mmh_ctx *c, uint64_t seed, uint64_t rom_base_offset
       return MMH_E_ARG;
    }
    HIP_TRY(hipSetDevice(c->device));
+   {
+      const int rc = mm_ingest_drain(c);
+      if (rc != MMH_OK) {
+         return rc;
+      }
+   }
    mm::launch_synth(c->stream, c->rom, c->rom_bytes, seed, rom_base_offset);
    HIP_TRY(hipGetLastError());
    return MMH_OK;
@@ -419,6 +512,12 @@ extern "C" int mmh_rom_poke(mmh_ctx *c, uint64_t first_byte, const void *host, u
       return MMH_E_ARG;
    }
    HIP_TRY(hipSetDevice(c->device));
+   {
+      const int rc = mm_ingest_drain(c);
+      if (rc != MMH_OK) {
+         return rc;
+      }
+   }
    HIP_TRY(hipMemcpyAsync(c->rom + first_byte, host, nbytes, hipMemcpyDefault, c->stream));
    HIP_TRY(hipStreamSynchronize(c->stream));
    return MMH_OK;
@@ -431,6 +530,12 @@ extern "C" int mmh_rom_fill(mmh_ctx *c, uint64_t first_byte, uint64_t nbytes, in
       return MMH_E_ARG;
    }
    HIP_TRY(hipSetDevice(c->device));
+   {
+      const int rc = mm_ingest_drain(c);
+      if (rc != MMH_OK) {
+         return rc;
+      }
+   }
    mm::launch_pattern_fill(c->stream, c->rom, first_byte, nbytes, value, ramp);
    HIP_TRY(hipGetLastError());
    return MMH_OK;
@@ -476,6 +581,22 @@ bool fused_enabled()
    return on;
 }
 
+// slots of the pinned block that earlier scans wrote go back to the poison before the next launch (see MM_SLOT_POISON)
+void poison_dirty_slots(MmWorkspace &w)
+{
+   if (w.dirty_slots) {
+      std::memset(w.h_result + kHeaderWords, 0xFE, (size_t)std::min<uint64_t>(w.dirty_slots, MM_MAX_PUBLISH) * sizeof(uint64_t));
+      w.dirty_slots = 0;
+   }
+}
+
+// (only slots a kernel stores straight into pinned memory can be mistaken: lists beyond that arrive by a copy that
+// overwrites every slot it announces)
+void note_dirty_slots(MmWorkspace &w, uint64_t n)
+{
+   w.dirty_slots = std::max<uint64_t>(w.dirty_slots, std::min<uint64_t>(n, kMaxRankSort));
+}
+
 // An outstanding gather may still be sending the device-side result copy a pipeline is about to publish into
 // (mmh_gather_start(NULL, 0) sends a scan's list from there, and overlaps the scans that follow): wait for its
 // collective.  Called for every pipeline launch -- a scan that retries (out_cap grown, left-overs to the flagged-
@@ -502,9 +623,10 @@ int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev,
                      hipStream_t tail_st = nullptr, unsigned tail_blocks = 0)
 {
    const int count_index = sequential ? 1 : 0;
-   const bool polled = allow_polled && !sequential && !skip_bits && fused_enabled();
-   const bool single_launch = polled && allow_single_launch && c->fused_ok && mm::fused_applies(g);
-   const bool bucketed = polled && !single_launch && buckets_enabled();
+   const uint32_t off = routes_off(c);
+   const bool polled = allow_polled && !sequential && !skip_bits && fused_enabled() && !(off & MMH_ROUTE_NO_POLLED);
+   const bool single_launch = polled && allow_single_launch && c->fused_ok && !(off & MMH_ROUTE_NO_SINGLE_LAUNCH) && mm::fused_applies(g);
+   const bool bucketed = polled && !single_launch && buckets_enabled() && !(off & MMH_ROUTE_NO_BUCKETS);
    // Only the bucketed store takes the full limit: the list-based kernels keep round 2's (their lists share d_cand, and the
    // callers read "more candidates than this" as "a flood: take it apart domain by domain").
    if (!bucketed) {
@@ -512,7 +634,7 @@ int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev,
    }
    w.limit = max_candidates;
    if (bucketed) {
-      const int rc = ensure_buckets(c, w, st);
+      const int rc = ensure_buckets(c, w, st, g.nbytes);
       if (rc != MMH_OK) {
          return rc;
       }
@@ -520,6 +642,8 @@ int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev,
    w.bucketed = false;
    const mm::ResolveBuffers rb = resolve_buffers(w);
 
+   poison_dirty_slots(w);
+   w.max_rank = bucketed ? MM_MAX_PUBLISH : kMaxRankSort;
    w.h_result[6] = 0;                          // mm_rank_scatter publishes "matches + 1" here
    w.result_turn ^= 1;                         // the other device-side copy may still be feeding a gather ...
    {
@@ -593,17 +717,136 @@ int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev,
    return MMH_OK;
 }
 
-void read_outcome(const MmWorkspace &w, bool sequential, Outcome *oc)
+void read_outcome(MmWorkspace &w, bool sequential, Outcome *oc)
 {
    const int count_index = sequential ? 1 : 0;
    oc->candidates = w.h_result[0];
    oc->listed = w.h_result[count_index];
+   note_dirty_slots(w, oc->listed);            // (the rank kernels' list: up to kMaxRankSort slots)
    oc->tiles = w.h_result[2];
    oc->hard = (uint32_t)(w.h_result[3] & 0xFFFFFFFFu);
    // left-overs beyond what mm_resolve2 / mm_hard_resolve take, or a prefix too long for the latter
    oc->hard_overflow = (w.h_result[3] >> 32) != 0 || (w.h_result[5] & 0xFFFFFFFFu) > mm::mid_cap();
    oc->sorted_on_device = oc->listed <= kMaxRankSort && oc->listed <= w.out_cap;
    oc->matches = w.h_result[6] ? w.h_result[6] - 1 : oc->listed;
+}
+
+// ---- what a polled scan published, checked before it is trusted (include/mmoore_hip.h, "route health") -------------
+
+void note_violation(mmh_ctx *c, uint64_t reason, const MmWorkspace &w, const char *what)
+{
+   MmHealth &h = c->health;
+   if (!h.fallback_reason) {
+      h.fallback_reason = reason;
+   }
+   h.last_reason = reason;
+   h.fallbacks++;
+   // loud, but not endlessly so
+   if (h.fallbacks <= 8) {
+      fprintf(stderr, "libmmoore_hip: a scan published a block that fails validation (%s, reason %llu): header %llx %llx %llx %llx %llx %llx %llx %llx, "
+                      "flag word %llu for sequence %llu; the scan is rerun through the plain kernels\n", what, (unsigned long long)reason,
+              (unsigned long long)w.h_result[0], (unsigned long long)w.h_result[1], (unsigned long long)w.h_result[2], (unsigned long long)w.h_result[3],
+              (unsigned long long)w.h_result[4], (unsigned long long)w.h_result[5], (unsigned long long)w.h_result[6], (unsigned long long)w.h_result[7],
+              (unsigned long long)w.h_result[MM_HDR_FLAG_WORD], (unsigned long long)w.seq);
+   }
+}
+
+// the header of a polled scan: flag bits, counters against the scan's capacities
+uint64_t validate_header(const MmWorkspace &w, bool was_fused, bool was_bucketed)
+{
+   const uint64_t *h = w.h_result;
+   const uint64_t flags = h[4] & 0xFF;
+   if ((flags & ~7ull) || h[3] != 0 || h[7] != 0) {
+      return MMH_FB_HEADER;
+   }
+   if (((flags & 2) && (!was_fused || (flags & 1))) ||       // only the single-launch kernel gives up, and resolves nothing then
+       ((flags & 4) && !(was_bucketed && (flags & 1))) ||    // only mm_scan_tail2 leaves a resolved list on the device
+       (!was_fused && (h[4] >> 8) != 0)) {                   // only the single-launch kernel stamps its streaming phase
+      return MMH_FB_HEADER;
+   }
+   if (!(flags & 1)) {
+      return h[6] != 0 ? MMH_FB_HEADER : MMH_FB_NONE;       // nothing ordered: no match count
+   }
+   const uint64_t n = h[0];
+   if (n > w.out_cap || n > w.limit || n > w.max_rank || h[6] == 0 || h[6] - 1 > n) {
+      return MMH_FB_CAPACITY;
+   }
+   if ((h[5] & 0xFFFFFFFFull) > n) {
+      return MMH_FB_HEADER;                                 // more left-overs than candidates
+   }
+   return MMH_FB_NONE;
+}
+
+// The n slots of a resolved list without left-overs: none still poisoned (a slot store that has not landed is waited
+// for: 2 ms, a thousand PCIe round trips), values strictly ascending and inside the ROM, `matches` of them besides the
+// holes.  Holes are dropped on the way (the list is left compact).
+uint64_t validate_slots(mmh_ctx *c, MmWorkspace &w, const MmGeom &g, uint64_t base_offset, uint64_t n, uint64_t matches, bool direct)
+{
+   uint64_t *slots = w.h_result + kHeaderWords;
+   const uint64_t lo = g.whole ? 0 : base_offset;
+   const uint64_t hi = g.whole ? g.nbytes / g.S : base_offset + g.nbytes;
+   uint64_t kept = 0, prev = 0;
+   for (uint64_t i = 0; i < n; i++) {
+      uint64_t v = slots[i];
+      if (v == MM_SLOT_POISON) {
+         if (!direct) {
+            return MMH_FB_STALE_SLOT;
+         }
+         volatile uint64_t *slot = slots + i;
+         const auto t0 = std::chrono::steady_clock::now();
+         while ((v = *slot) == MM_SLOT_POISON) {
+            __builtin_ia32_pause();
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+               return MMH_FB_STALE_SLOT;
+            }
+         }
+         std::atomic_thread_fence(std::memory_order_acquire);
+         c->health.late_slots++;
+      }
+      if (v == ~0ull) {
+         continue;                                          // a candidate the reference does not report
+      }
+      if (v < lo || v >= hi) {
+         return MMH_FB_RANGE;
+      }
+      if (kept && v <= prev) {
+         return MMH_FB_ORDER;
+      }
+      slots[kept++] = prev = v;
+   }
+   return kept == matches ? MMH_FB_NONE : MMH_FB_ORDER;
+}
+
+// tests: damage the published block on the host the way a lost or reordered write would (mmh_debug_inject)
+void inject_header(mmh_ctx *c, MmWorkspace &w)
+{
+   if (c->health.inject == 1) {
+      w.h_result[4] |= 0x40;
+      c->health.inject = 0;
+   }
+   else if (c->health.inject == 5) {
+      w.h_result[6] += 1;
+      c->health.inject = 0;
+   }
+}
+
+void inject_slots(mmh_ctx *c, MmWorkspace &w, const MmGeom &g, uint64_t base_offset, uint64_t n)
+{
+   uint64_t *slots = w.h_result + kHeaderWords;
+   const uint32_t kind = c->health.inject;
+   if (kind == 2 && n >= 1) {
+      slots[n / 2] = MM_SLOT_POISON;
+   }
+   else if (kind == 3 && n >= 2) {
+      std::swap(slots[0], slots[n - 1]);
+   }
+   else if (kind == 4 && n >= 1) {
+      slots[n - 1] = (g.whole ? g.nbytes / g.S : base_offset + g.nbytes) + 5;
+   }
+   else {
+      return;
+   }
+   c->health.inject = 0;
 }
 
 // Wait for an enqueued scan and read what it published.  When mm_resolve left candidates over
@@ -679,10 +922,18 @@ int finish_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev, 
       if (was_bucketed) {
          w.buckets_clean = true;                  // mm_scan_tail2's last workgroup zeroed the bucket counters before it raised the flag
       }
-      if (flags & 1) {
+      // Nothing of the block is trusted before it has been validated (include/mmoore_hip.h, "route health"); a block that
+      // fails is not repaired: the scan runs again through the plain kernels, whose end is a HIP event.
+      inject_header(c, w);
+      c->health.validated++;
+      uint64_t violation = validate_header(w, was_fused, was_bucketed);
+      const char *what = "header";
+      if (!violation && (flags & 1)) {
          // one slot per candidate, in offset order; ~0 = a candidate the reference does not report
          oc->candidates = w.h_result[0];
-         if ((flags & 4) && (w.h_result[5] & 0xFFFFFFFFu) == 0 && oc->candidates != 0) {
+         const bool leftovers = (w.h_result[5] & 0xFFFFFFFFu) != 0;
+         const bool direct = !(flags & 4);
+         if (!direct && !leftovers && oc->candidates != 0) {
             // a long list: the slots were only written to the device-side copy of the block (a PCIe write per slot
             // would take longer than the scan): one copy brings them over.  On the context's own stream, behind the
             // tail kernel's end event (the flag word shows before the kernel has retired and its stores are visible to
@@ -694,26 +945,41 @@ int finish_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev, 
                                    hipMemcpyDeviceToHost, c->own_stream));
             HIP_TRY(hipStreamSynchronize(c->own_stream));
          }
+         note_dirty_slots(w, oc->candidates);
          oc->listed = oc->candidates;
          oc->tiles = w.h_result[2];
          oc->hard = 0;
          oc->hard_overflow = (w.h_result[5] & 0xFFFFFFFFu) > mm::mid_cap();
          oc->sorted_on_device = true;
          oc->matches = w.h_result[6] - 1;
-         if ((w.h_result[5] & 0xFFFFFFFFu) == 0) {
-            if (oc->matches != oc->candidates) {
-               uint64_t *slots = w.h_result + kHeaderWords;
-               uint64_t kept = 0;
-               for (uint64_t i = 0; i < oc->candidates; i++) {
-                  if (slots[i] != ~0ull) {
-                     slots[kept++] = slots[i];
-                  }
-               }
+         if (!leftovers) {
+            inject_slots(c, w, g, base_offset, oc->candidates);
+            violation = validate_slots(c, w, g, base_offset, oc->candidates, oc->matches, direct);
+            what = "result slots";
+            if (!violation) {
+               w.ctrl_clean = true;               // the kernel's last workgroup re-zeroed the control block
+               return MMH_OK;
             }
-            w.ctrl_clean = true;                  // the kernel's last workgroup re-zeroed the control block
-            return MMH_OK;
          }
          // left-overs: the second phase below orders the slots again with the rank kernels
+      }
+      if (violation) {
+         note_violation(c, violation, w, what);
+         HIP_TRY(hipEventSynchronize(ev[2]));     // (whatever published that block has retired)
+         mm::FilterChoice fc;
+         mm::choose_filter(pl, &fc);
+         w.ctrl_clean = false;
+         w.buckets_clean = false;
+         const int again = enqueue_pipeline(c, w, st, ev, g, pl, fc, false, base_offset, max_candidates, nullptr, false, false);
+         if (again != MMH_OK) {
+            return again;
+         }
+         max_candidates = oc->limit = w.limit;
+         HIP_TRY(hipEventSynchronize(ev[2]));
+         read_outcome(w, sequential, oc);
+      }
+      else if (flags & 1) {
+         // (left-overs: fall through to the second phase)
       }
       else if (was_bucketed) {
          // a bucket overflowed (a flood of candidates in one ROM neighbourhood) or there are more candidates than the
@@ -733,6 +999,7 @@ int finish_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev, 
          // too many candidates for the in-kernel ranking, or the kernel gave up: the plain
          // kernels take over on the candidate lists it left (control block kept)
          const mm::ResolveBuffers rb = resolve_buffers(w);
+         poison_dirty_slots(w);
          w.h_result[6] = 0;
          mm::launch_resolve(st, g, pl, rb, base_offset, max_candidates);
          mm::launch_rank_sort(st, w.d_out, w.d_ctrl, 0, w.out_cap, kMaxRankSort, w.d_partials, w.h_result, w.d_result[w.result_turn],
@@ -1347,6 +1614,7 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
    if (c) {
       c->mg.last_src = nullptr;
       c->mg.last_count = 0;
+      c->mg.last_slots = 0;
       c->mg.last_list.clear();
       c->mg.last_end = nullptr;
    }
@@ -1355,6 +1623,7 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
    int rc = scan_impl(c, plan, block_bytes, big_endian, base_offset, out, cap, out_count, &host_list, &on_device);
    if (c && (rc == MMH_OK || rc == MMH_E_CAPACITY)) {
       c->mg.last_count = *out_count;
+      c->mg.last_slots = on_device ? c->counters[0] : 0;      // (one slot per candidate)
       c->mg.last_src = on_device ? c->ws[0].d_result[c->ws[0].result_turn] : nullptr;
       c->mg.last_end = on_device ? c->ev[2] : nullptr;   // the gather's stream waits for the scan's last kernel to retire
       if (!on_device && c->mg.comm) {
@@ -1416,6 +1685,10 @@ extern "C" int mmh_scan_submit(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t b
       return MMH_E_STATE;
    }
    HIP_TRY(hipSetDevice(c->device));
+   rc = mm_ingest_drain(c);
+   if (rc != MMH_OK) {
+      return rc;
+   }
    MmWorkspace &w = c->ws[1 + lane];
    rc = ensure_workspace(c, w, std::max<uint64_t>(w.out_cap, kInitialCap));
    if (rc != MMH_OK) {
@@ -1598,6 +1871,7 @@ extern "C" int mmh_scan_collect(mmh_ctx *c, int ticket, uint64_t *out, uint64_t 
    c->mg.last_src = w.d_result[w.result_turn];
    c->mg.last_end = p.ev[2];
    c->mg.last_count = oc.matches;
+   c->mg.last_slots = oc.candidates;
    c->mg.last_list.clear();
    return MMH_OK;
 }
@@ -1699,5 +1973,203 @@ extern "C" int mmh_last_counters(mmh_ctx *c, uint64_t *c4)
       return MMH_E_ARG;
    }
    std::memcpy(c4, c->counters, sizeof(c->counters));
+   return MMH_OK;
+}
+
+// ---- route health: run-time switches, what the validation saw, the first-use self-test ------------------------------
+
+extern "C" int mmh_set_route(mmh_ctx *c, uint32_t mask)
+{
+   if (!c || (mask & ~15u)) {
+      mmh_set_error("mmh_set_route: bad argument");
+      return MMH_E_ARG;
+   }
+   c->route_off = mask;
+   return MMH_OK;
+}
+
+extern "C" int mmh_debug_inject(mmh_ctx *c, uint32_t kind)
+{
+   if (!c || kind > 5) {
+      mmh_set_error("mmh_debug_inject: bad argument");
+      return MMH_E_ARG;
+   }
+   c->health.inject = kind;
+   return MMH_OK;
+}
+
+extern "C" int mmh_health(mmh_ctx *c, uint64_t *h16)
+{
+   if (!c || !h16) {
+      mmh_set_error("mmh_health: bad argument");
+      return MMH_E_ARG;
+   }
+   std::memset(h16, 0, 16 * sizeof(uint64_t));
+   h16[0] = c->health.fallback_reason;
+   h16[1] = c->health.fallbacks;
+   h16[2] = c->health.late_slots;
+   h16[3] = c->health.last_reason;
+   h16[4] = routes_off(c);
+   h16[5] = g_routes_off.load();
+   h16[6] = c->device < kSelftestDevices ? (uint64_t)g_selftest_state[c->device].load() : 0;
+   h16[7] = c->health.validated;
+   if (c->ws[0].h_result) {
+      std::memcpy(h16 + 8, c->ws[0].h_result, 8 * sizeof(uint64_t));
+   }
+   return MMH_OK;
+}
+
+namespace {
+
+// The known answer: 4133 bytes of splitmix64 noise with the keyword's shape ("abcde": four deltas of +1) planted at
+// the start, across block boundaries (1020, 2044, 3068, 4092), behind a constant run, in the last bytes, twice back to
+// back, off the reference's skip chain and once modulo 256 (which the reference's signed compare does not report);
+// blocks of 1024 bytes.  What the reference reports is the constant below (tests/test_oracle.py holds it against the
+// oracle and the compiled reference).
+constexpr uint64_t kKatBytes = 4133, kKatBlock = 1024;
+// (15 plants, 12 reported: 1505 and 2050 are not on the reference's skip chain, 3000 wraps around 0xFF)
+const uint64_t kKatExpected[] = {0, 16, 600, 1020, 1028, 1500, 2044, 2596, 3068, 3500, 4092, 4128};
+
+void kat_rom(uint8_t *rom)
+{
+   uint64_t x = 0x6d6d6f6f72653432ull;
+   for (uint64_t i = 0; i < kKatBytes; i += 8) {
+      x += 0x9E3779B97F4A7C15ull;
+      uint64_t z = x;
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+      z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+      z ^= z >> 31;
+      for (uint64_t k = 0; k < 8 && i + k < kKatBytes; k++) {
+         rom[i + k] = (uint8_t)(z >> (8 * k));
+      }
+   }
+   std::memset(rom + 2500, 0x41, 96);                        // a constant run: the chain crosses it in default skips
+   const struct { uint32_t at; uint8_t base; } plants[] = {
+      {0, 0x30}, {16, 0x61}, {600, 0x11}, {1020, 0x10}, {1028, 0xF0}, {1500, 0x00}, {1505, 0x20}, {2044, 0x77}, {2050, 0x22},
+      {2596, 0x41}, {3000, 0xFD}, {3068, 0x05}, {3500, 0x90}, {4092, 0x80}, {4128, 0x33}};
+   for (const auto &p : plants) {
+      for (uint32_t k = 0; k < 5; k++) {
+         rom[p.at + k] = (uint8_t)(p.base + k);             // (0xFD: wraps -- matches modulo 256 only)
+      }
+   }
+}
+
+mmh_plan_desc kat_plan()
+{
+   const uint32_t kw[5] = {'a', 'b', 'c', 'd', 'e'};
+   mmh_plan_desc plan;
+   std::memset(&plan, 0, sizeof plan);
+   (void)mmh_plan_relative(1, kw, 5, 0, nullptr, 0, &plan);
+   return plan;
+}
+
+// one scan of the KAT on context t with `mask` routes off; through mmh_scan or through the submit lanes
+bool kat_scan(mmh_ctx *t, const uint8_t *rom, const mmh_plan_desc &plan, uint32_t mask, int engine, bool lanes, std::string *why)
+{
+   constexpr uint64_t n_expected = sizeof(kKatExpected) / sizeof(kKatExpected[0]);
+   uint64_t got[64] = {0}, n = 0;
+   t->route_off = mask;
+   t->engine = engine;
+   const uint64_t fallbacks = t->health.fallbacks;
+   int rc = mmh_rom_upload(t, rom, kKatBytes);
+   if (rc == MMH_OK) {
+      if (lanes) {
+         int ticket = 0;
+         rc = mmh_scan_submit(t, &plan, kKatBlock, 0, 0, &ticket);
+         if (rc == MMH_OK) {
+            rc = mmh_scan_collect(t, ticket, got, 64, &n);
+         }
+      }
+      else {
+         rc = mmh_scan(t, &plan, kKatBlock, 0, 0, got, 64, &n);
+      }
+   }
+   t->engine = 0;
+   char buf[256];
+   if (rc != MMH_OK) {
+      snprintf(buf, sizeof buf, "routes off 0x%x, engine %d%s: error %d (%s)", mask, engine, lanes ? ", lanes" : "", rc, mmh_last_error());
+      *why = buf;
+      return false;
+   }
+   if (t->health.fallbacks != fallbacks) {
+      snprintf(buf, sizeof buf, "routes off 0x%x%s: the published block failed validation (reason %llu)", mask, lanes ? ", lanes" : "",
+               (unsigned long long)t->health.last_reason);
+      *why = buf;
+      return false;
+   }
+   if (n != n_expected || std::memcmp(got, kKatExpected, n * sizeof(uint64_t)) != 0) {
+      uint64_t first = 0;
+      while (first < n && first < n_expected && got[first] == kKatExpected[first]) {
+         first++;
+      }
+      snprintf(buf, sizeof buf, "routes off 0x%x, engine %d%s: %llu offsets instead of %llu, first difference at entry %llu (%llu)", mask, engine,
+               lanes ? ", lanes" : "", (unsigned long long)n, (unsigned long long)n_expected, (unsigned long long)first,
+               (unsigned long long)(first < n ? got[first] : 0));
+      *why = buf;
+      return false;
+   }
+   return true;
+}
+
+} // namespace
+
+extern "C" int mmh_selftest_kat(uint8_t *rom, uint64_t rom_cap, uint64_t *rom_bytes, uint64_t *expected, uint64_t expected_cap,
+                                uint64_t *expected_count)
+{
+   constexpr uint64_t n_expected = sizeof(kKatExpected) / sizeof(kKatExpected[0]);
+   if (!rom || !rom_bytes || !expected_count || (!expected && expected_cap) || rom_cap < kKatBytes) {
+      mmh_set_error("mmh_selftest_kat: bad argument (the ROM takes %llu bytes)", (unsigned long long)kKatBytes);
+      return MMH_E_ARG;
+   }
+   kat_rom(rom);
+   *rom_bytes = kKatBytes;
+   *expected_count = n_expected;
+   if (expected_cap < n_expected) {
+      return MMH_E_CAPACITY;
+   }
+   std::memcpy(expected, kKatExpected, sizeof(kKatExpected));
+   return MMH_OK;
+}
+
+extern "C" int mmh_selftest_run(int device, uint32_t *routes_off_out)
+{
+   if (!routes_off_out) {
+      mmh_set_error("mmh_selftest_run: null argument");
+      return MMH_E_ARG;
+   }
+   *routes_off_out = 0;
+   mmh_ctx *t = nullptr;
+   int rc = create_context(device, &t);
+   if (rc != MMH_OK) {
+      return rc;
+   }
+   std::vector<uint8_t> rom(kKatBytes);
+   kat_rom(rom.data());
+   const mmh_plan_desc plan = kat_plan();
+   std::string why;
+   // the plain kernels and the sequential chain kernel must know the answer: everything else is measured against them
+   if (!kat_scan(t, rom.data(), plan, 15, 0, false, &why) || !kat_scan(t, rom.data(), plan, 15, 1, false, &why)) {
+      mmh_destroy(t);
+      mmh_set_error("self-test: %s", why.c_str());
+      return MMH_E_DEVICE;
+   }
+   // the fast routes, all on first; then with more and more of them switched off until the answer is right
+   static const bool trace = getenv("MMOORE_SELFTEST_TRACE") != nullptr;
+   const uint32_t masks[] = {0, MMH_ROUTE_NO_ZERO_COPY, MMH_ROUTE_NO_SINGLE_LAUNCH, MMH_ROUTE_NO_ZERO_COPY | MMH_ROUTE_NO_SINGLE_LAUNCH,
+                             MMH_ROUTE_NO_ZERO_COPY | MMH_ROUTE_NO_SINGLE_LAUNCH | MMH_ROUTE_NO_BUCKETS, 15};
+   uint32_t settled = 15;
+   for (uint32_t mask : masks) {
+      std::string w1;
+      if (kat_scan(t, rom.data(), plan, mask, 0, false, &w1) && kat_scan(t, rom.data(), plan, mask, 0, true, &w1)) {
+         settled = mask;
+         break;
+      }
+      fprintf(stderr, "libmmoore_hip: self-test on device %d: %s\n", device, w1.c_str());
+   }
+   if (trace) {
+      fprintf(stderr, "libmmoore_hip: self-test on device %d: routes off 0x%x\n", device, settled);
+   }
+   mmh_destroy(t);
+   *routes_off_out = settled;
    return MMH_OK;
 }

@@ -63,6 +63,24 @@ struct MmWorkspace {
    bool polled = false;             // the scan under way announces its end in h_result[MM_HDR_FLAG_WORD] (fused or filter + tail)
    float fused_filter_ms = 0;       // its streaming phase, from the kernel's own wall-clock stamps
    bool ctrl_clean = false;         // the previous scan's last kernel left d_ctrl zeroed
+   uint64_t bcand_buckets = 0;      // buckets d_bcand has room for (sized from the ROM, grown when a larger one arrives)
+   // Result slots of h_result that may hold something else than MM_SLOT_POISON (slots a scan published straight into
+   // pinned memory, the rank kernels' lists): re-poisoned before the next launch, so that a slot whose PCIe write has
+   // not landed when the flag word shows is recognised instead of read as an offset (validate_published, mm_capi.hip)
+   uint64_t dirty_slots = 0;
+   uint32_t max_rank = 0;           // slots the polled scan under way may publish (MM_MAX_RANK_SORT / MM_MAX_PUBLISH)
+};
+
+// What the library knows about the health of its fast routes (mmh_health): every polled scan's published block is
+// validated before it is trusted; a violation sends the scan through the plain, event-synchronised kernels and is
+// remembered here for good.
+struct MmHealth {
+   uint64_t fallback_reason = 0;    // MMH_FB_* of the FIRST violation on this context (sticky; 0: none)
+   uint64_t fallbacks = 0;          // scans that were rerun through the plain kernels because of a violation
+   uint64_t late_slots = 0;         // result slots that showed after the flag word (waited for, not a violation)
+   uint64_t last_reason = 0;
+   uint64_t validated = 0;          // polled scans whose block went through the validation
+   uint32_t inject = 0;             // tests: the next polled scan's block is damaged on the host (mmh_debug_inject)
 };
 
 // One offset gather in flight (mm_multi.hip): the all-gather's receive table, the pinned block the
@@ -76,6 +94,13 @@ struct MmGatherSlot {
    bool from_host = false;          // the local list came from host memory (long lists, forward engine)
    const uint64_t *src = nullptr;   // else: the device-side result copy (of the scan's workspace) it sends
    uint64_t local_count = 0;        // this rank's list length
+   // A device-resident list too long for a record (or with more slots than one holds): its published block is copied
+   // HERE when the gather starts.  The second phase runs at mmh_gather_finish, by when later scans -- a retry, two scans
+   // on, a second outstanding gather -- may have published into the result copy the first phase sent from (they only
+   // wait for the first phase's end event).
+   uint64_t *d_keep = nullptr;
+   uint64_t keep_cap = 0;           // words
+   bool kept = false;               // this gather's list lives in d_keep
    std::vector<uint64_t> host_list; // a host-resident list too long for a record: kept HERE for the second phase, so that no
                                     // later scan can take it away (all ranks must enter that phase or none)
    double start_wall_s = 0;         // host time spent in mmh_gather_start
@@ -98,6 +123,7 @@ struct MmComm {
    const uint64_t *last_src = nullptr; // the most recent scan's (or collected ticket's) list sits ordered in this device-side
                                     // result copy of its workspace; null: it only exists on the host (last_list)
    uint64_t last_count = 0;
+   uint64_t last_slots = 0;         // result slots of that block (>= last_count: one per candidate when the list has holes)
    hipEvent_t last_end = nullptr;   // end event of the scan that left last_src: a polled scan returns when its flag word shows in
                                     // pinned memory, which may be before its last kernel has retired and its plain stores to
                                     // last_src are visible device-wide -- the gather's stream waits for this event first
@@ -174,6 +200,8 @@ struct mmh_ctx {
    int next_ticket = 0;
    int engine = 0;
    bool fused_ok = true;            // cleared for good when a fused scan's grid barrier ever timed out on this context
+   uint32_t route_off = 0;          // MMH_ROUTE_* bits switched off on this context (mmh_set_route); the process-wide ones come on top
+   MmHealth health;
    uint64_t counters[4] = {0, 0, 0, 0};
    MmIngest ingest;
    MmComm mg;

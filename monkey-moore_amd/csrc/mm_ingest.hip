@@ -75,6 +75,8 @@ bool ingest_resources(mmh_ctx *c, int threads, std::string *err)
 // block -- never against the caller's abort word or byte counter, which may be gone by then.
 struct LoadJob {
    mmh_ctx *c = nullptr;
+   uint8_t *rom = nullptr;         // the ROM's base when the load began: a straggler of an aborted load never looks at c->rom,
+                                   // which a later upload may have pointed somewhere else by the time it queues its copy
    std::string path;
    uint64_t file_offset = 0, nbytes = 0, npieces = 0;
    std::atomic<uint64_t> next{0}, bytes_done{0};
@@ -138,7 +140,7 @@ static void read_pieces(std::shared_ptr<LoadJob> job, int t)
       if (got < len) {
          break;
       }
-      if (hipMemcpyAsync(j.c->rom + at, dst, len, hipMemcpyHostToDevice, in.streams[t]) != hipSuccess ||
+      if (hipMemcpyAsync(j.rom + at, dst, len, hipMemcpyHostToDevice, in.streams[t]) != hipSuccess ||
           hipEventRecord(in.events[slot], in.streams[t]) != hipSuccess) {
          j.give_up("host-to-device copy failed");
          break;
@@ -253,6 +255,7 @@ extern "C" int mmh_rom_load_file_watched(mmh_ctx *c, const char *path, uint64_t 
 
    auto job = std::make_shared<LoadJob>();
    job->c = c;
+   job->rom = c->rom;
    job->path = path;
    job->file_offset = file_offset;
    job->nbytes = nbytes;
@@ -306,6 +309,10 @@ extern "C" int mmh_rom_load_file_watched(mmh_ctx *c, const char *path, uint64_t 
    else {
       for (auto &th : pool) {
          th.join();
+      }
+      // (a reader may have queued its last piece between the supervisor's last look at the count and at `running`)
+      if (bytes_done) {
+         __atomic_store_n(bytes_done, job->bytes_done.load(), __ATOMIC_RELAXED);
       }
    }
    in.last_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

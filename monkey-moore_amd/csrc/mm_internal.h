@@ -58,6 +58,11 @@ constexpr uint32_t MM_DIRECT_PUBLISH = 8192;
 // sequence number in the first of them when everything is published (the host polls it)
 constexpr uint64_t MM_HDR_FLAG_WORD = MM_RESULT_HEADER_WORDS + MM_MAX_PUBLISH;
 constexpr uint64_t MM_RESULT_BLOCK_WORDS = MM_HDR_FLAG_WORD + 8;
+// What the host leaves in every result slot of the pinned block before a scan is launched (memset 0xFE).  A kernel's
+// slot stores and its flag word travel to host memory as separate PCIe writes from different compute units; should
+// the flag ever be seen first, the host recognises the slot that has not landed (no offset and no hole looks like
+// this) and waits for it instead of reading a stale offset.
+constexpr uint64_t MM_SLOT_POISON = 0xFEFEFEFEFEFEFEFEull;
 
 // ---- bucketed candidate store (big ROMs: streaming kernel + mm_scan_tail2) ---------------------------------------
 // The ROM is cut into nb <= MM_MAX_BUCKETS buckets of 2^shift bytes (>= 4 KiB, so a wave's 1 KiB piece lies in one

@@ -1550,7 +1550,7 @@ void launch_filter(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, con
                    uint64_t *cand, unsigned long long *ctrl, uint64_t cand_cap, hipEvent_t start, hipEvent_t stop,
                    unsigned int *dom_count, const uint32_t *skip_bits)
 {
-   MmFilterArgs a;
+   MmFilterArgs a{};
    // small ROMs are cut fine, as launch_fused does: 64 workgroups fill the 64 candidate lists evenly (a 1 MiB
    // ROM in spans of 7 groups is 10 workgroups = 10 lists, and a dense pattern overflows them) and every CU works
    uint32_t gps = filter_groups_per_span();
@@ -1574,7 +1574,7 @@ void launch_filter(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, con
 static void launch_loud(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc, unsigned long long *ctrl,
                         uint32_t *bits, uint32_t tpd, uint32_t tile)
 {
-   MmFilterArgs a;
+   MmFilterArgs a{};
    fill_filter_args(a, g, pl, fc, nullptr, ctrl, 0, filter_groups_per_span());
    a.loud_bits = bits; a.loud_tpd = tpd; a.loud_tile = tile;
    with_shape(pl.elem_bytes, fc, [&](auto elem, auto shape) {
@@ -1652,7 +1652,7 @@ bool launch_fused(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, cons
    if (resident == 0) {
       return false;
    }
-   MmFusedArgs a;
+   MmFusedArgs a{};
    const uint64_t ngroups = g.nbytes / 4096;
    // small ROMs are cut fine so that every wave has a span (a 128 KiB ROM: 32 waves of 4 KiB instead of 4 of 32 KiB)
    uint32_t gps = filter_groups_per_span();
@@ -1676,7 +1676,7 @@ void launch_tail(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const
                  uint64_t base_offset, uint32_t max_candidates, uint64_t *host_result, uint64_t *dev_result, uint32_t max_rank,
                  uint64_t seq, hipEvent_t stop)
 {
-   MmFusedArgs a;
+   MmFusedArgs a{};
    fill_filter_args(a, g, pl, fc, rb.cand, rb.ctrl, rb.cand_cap, filter_groups_per_span());
    fill_tail_args(a, rb, base_offset, max_candidates, host_result, dev_result, max_rank, seq);
    a.has_edge = 0;
@@ -1722,7 +1722,7 @@ static int span_ticket_percent()
 void launch_filter_buckets(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc, const ResolveBuffers &rb,
                            hipEvent_t start, hipEvent_t stop)
 {
-   MmFilterArgs a;
+   MmFilterArgs a{};
    uint32_t gps = filter_groups_per_span();
    while (gps > 1 && (g.nbytes / 4096) / gps < (uint64_t)MM_CAND_LISTS * MM_WAVES) {
       gps >>= 1;
@@ -1753,7 +1753,7 @@ void launch_tail2(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, cons
                   uint64_t base_offset, uint32_t max_candidates, uint64_t *host_result, uint64_t *dev_result, uint64_t seq,
                   hipEvent_t stop, unsigned tail_blocks)
 {
-   MmFusedArgs a;
+   MmFusedArgs a{};
    fill_filter_args(a, g, pl, fc, rb.cand, rb.ctrl, rb.cand_cap, filter_groups_per_span());
    fill_tail_args(a, rb, base_offset, max_candidates, host_result, dev_result, MM_MAX_PUBLISH, seq);
    fill_bucket_args(a, g, rb);
@@ -1766,7 +1766,7 @@ void launch_tail2(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, cons
 
 static MmTileArgs tile_args(const MmGeom &g, const mmh_plan_desc &pl)
 {
-   MmTileArgs t;
+   MmTileArgs t{};
    t.g = g; t.plan = pl;
    const uint32_t D = pl.L - 1;
    t.inv_d = (65536u + D - 1) / D;
@@ -1788,7 +1788,7 @@ static MmTileArgs tile_args(const MmGeom &g, const mmh_plan_desc &pl)
 void launch_resolve(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const ResolveBuffers &rb,
                     uint64_t base_offset, uint32_t max_candidates, uint32_t *flag_bits)
 {
-   MmResolveArgs a;
+   MmResolveArgs a{};
    a.t = tile_args(g, pl);
    a.cand = rb.cand; a.list_count = rb.ctrl + MM_CTRL_LISTS; a.list_cap = rb.cand_cap / MM_CAND_LISTS;
    a.total_out = rb.ctrl + MM_CTRL_TOTAL;
@@ -1805,7 +1805,7 @@ void launch_resolve(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, co
 // could not settle.  Two always-launched no-op kernels cost ~5 us each per scan.
 void launch_leftovers(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const ResolveBuffers &rb, uint64_t base_offset)
 {
-   MmResolve2Args m;
+   MmResolve2Args m{};
    m.t = tile_args(g, pl);
    m.mid_off = rb.mid_off; m.mid_hi = rb.mid_hi; m.mid_set = rb.mid_set; m.mid_slot = rb.mid_slot;
    m.mid_count = reinterpret_cast<unsigned int *>(rb.ctrl + MM_CTRL_MID);
@@ -1814,7 +1814,7 @@ void launch_leftovers(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, 
    m.hard_count = reinterpret_cast<unsigned int *>(rb.ctrl + MM_CTRL_HARD);
    hipLaunchKernelGGL(mm_resolve2, dim3(256), dim3(64 * MM_WAVES), 0, st, m);
 
-   MmHardArgs h;
+   MmHardArgs h{};
    h.t = m.t;
    h.hard_off = rb.hard_off; h.hard_hi = rb.hard_hi; h.hard_set = rb.hard_set; h.hard_slot = rb.hard_slot;
    h.hard_count = reinterpret_cast<unsigned int *>(rb.ctrl + MM_CTRL_HARD);
@@ -1856,7 +1856,7 @@ DenseGeom dense_geom(const MmGeom &g, uint64_t listed_domains)
 static void launch_forward(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const DenseGeom &dg, const DenseBuffers &db,
                            uint64_t base_offset, const uint32_t *dom_list)
 {
-   MmForwardArgs a;
+   MmForwardArgs a{};
    a.t = tile_args(g, pl);
    a.ndom = dg.ndom; a.dom_list = dom_list; a.tpd = dg.tpd; a.bpd = dg.bpd;
    const uint64_t nbatches = dg.ndom * dg.bpd;
@@ -1955,7 +1955,7 @@ void launch_dense(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, cons
 void launch_chain_seq(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, uint64_t *out,
                       unsigned long long *out_count, uint64_t out_cap, uint64_t base_offset)
 {
-   MmSeqArgs a;
+   MmSeqArgs a{};
    a.g = g; a.plan = pl; a.out = out; a.out_count = out_count; a.out_cap = out_cap; a.base_offset = base_offset;
    uint64_t ndom = g.whole ? 1 : g.nblocks * g.S;
    uint64_t blocks = (ndom + 63) / 64;

@@ -252,6 +252,7 @@ void comm_release(mmh_ctx *c)
    }
    for (auto &s : m.slot) {
       if (s.d_table) (void)hipFree(s.d_table);
+      if (s.d_keep) (void)hipFree(s.d_keep);
       if (s.h_merged) (void)hipHostFree(s.h_merged);
       if (s.begin) (void)hipEventDestroy(s.begin);
       if (s.end) (void)hipEventDestroy(s.end);
@@ -393,6 +394,25 @@ int gather_prepare(mmh_ctx *c, const uint64_t *offsets, uint64_t n, const uint64
             // the scan's kernels ran on another stream; its end shows in pinned memory before the kernel retires
             HIP_TRY(hipStreamWaitEvent(m.stream, m.last_end, 0));
          }
+         // A list (or slot count) beyond a record only travels in the second phase, which mmh_gather_finish enqueues:
+         // keep the block now -- the result copy itself is only protected until the first phase has ended
+         // (wait_for_gather_reading in mm_capi.hip), and a scan that retries, the scan after next or a second
+         // outstanding gather publish into it again before this gather is finished.
+         const uint64_t extent = std::max(m.last_count, m.last_slots);
+         s.kept = extent > MM_MAX_RANK_SORT;
+         if (s.kept) {
+            const uint64_t words = MM_RESULT_HEADER_WORDS + std::min<uint64_t>(extent, MM_MAX_PUBLISH);
+            if (words > s.keep_cap) {
+               if (s.d_keep) {
+                  HIP_TRY(hipFree(s.d_keep));
+                  s.d_keep = nullptr;
+                  s.keep_cap = 0;
+               }
+               HIP_TRY(hipMalloc(&s.d_keep, (words + words / 4) * sizeof(uint64_t)));
+               s.keep_cap = words + words / 4;
+            }
+            HIP_TRY(hipMemcpyAsync(s.d_keep, m.last_src, words * sizeof(uint64_t), hipMemcpyDeviceToDevice, m.stream));
+         }
       }
       else {
          offsets = m.last_list.data();
@@ -477,10 +497,12 @@ int long_prepare(mmh_ctx *c, MmGatherSlot &s, uint64_t longest)
                                 m.stream));
       }
       else {
-         // the scan's published block in HBM (nothing overwrites it while the gather is outstanding: enqueue_pipeline
-         // waits for gathers that read the copy it is about to publish into); it may have holes (one slot per
-         // candidate): the packing kernel on that one block leaves the list behind a header nobody reads
-         hipLaunchKernelGGL(mm_gather_pack, dim3(1), dim3(256), 0, m.stream, s.src, 1u, (uint64_t)MM_RESULT_BLOCK_WORDS,
+         // The scan's published block as it was when the gather started -- NOT the workspace's result copy, which later
+         // scans may have published into since the first phase ended: a long list was copied to the slot's own buffer
+         // then, a short one sits intact in this rank's record of the table the first phase gathered.  It may have
+         // holes (one slot per candidate): the packing kernel on that one block leaves the list behind a header nobody reads.
+         const uint64_t *block = s.kept ? s.d_keep : s.d_table + (uint64_t)m.rank * kRecordWords;
+         hipLaunchKernelGGL(mm_gather_pack, dim3(1), dim3(256), 0, m.stream, block, 1u, (uint64_t)MM_RESULT_BLOCK_WORDS,
                             m.d_long, longest, 1u, (uint32_t)MM_MAX_PUBLISH);
          HIP_TRY(hipGetLastError());
       }

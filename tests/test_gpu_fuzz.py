@@ -12,6 +12,8 @@ pytestmark = pytest.mark.gpu
 import collections
 import os
 
+import _diag
+
 LOWER = "abcdefghijklmnopqrstuvwxyz"
 # 24 cases per seed.  Round 2's suite ran 40 seeds and a parity bug of that round only showed at seed 303 of a soak:
 # the default now covers it (raise for a longer soak: profiles/r03_fuzz_soak.log ran 8000).
@@ -91,15 +93,17 @@ def test_fuzz_against_oracle(mm, gpu_engine, oracle, seed):
         got = gpu_engine.scan(plan, block_bytes=block, big_endian=be, cap=1 << 12)
         _note(gpu_engine, "fused")
         want = oracle.engine(oplan, rom, block, be)
-        assert got.tolist() == want.tolist(), (seed, case, kw, elem, be, block, nbytes, alphabet)
+        _diag.same(mm, gpu_engine, rom, plan, got, want, (seed, case, kw, elem, be, block, nbytes, alphabet), block_bytes=block, big_endian=be)
         # the same through the submit lanes (streaming kernel + tail kernel, never the single-launch kernel), three at a time
         tickets = [gpu_engine.submit(plan, block_bytes=block, big_endian=be) for _ in range(3 if case % 4 == 0 else 1)]
-        for t in tickets:
-            assert gpu_engine.collect(t, cap=1 << 12).tolist() == want.tolist(), (seed, case, kw, elem, be, block, nbytes, alphabet, "lanes")
+        lane_results = [gpu_engine.collect(t, cap=1 << 12) for t in tickets]      # (collect them all before anything may raise)
+        for got in lane_results:
+            _diag.same(mm, gpu_engine, rom, plan, got, want, (seed, case, kw, elem, be, block, nbytes, alphabet, "lanes"), block_bytes=block,
+                       big_endian=be)
             _note(gpu_engine, "lanes")
         whole = rom[: (nbytes // elem) * elem]
         data = whole if elem == 1 else whole.view("<u2")
-        assert gpu_engine.scan(plan, cap=1 << 12).tolist() == oracle.search(oplan, data).tolist(), (seed, case, kw, "whole")
+        _diag.same(mm, gpu_engine, rom, plan, gpu_engine.scan(plan, cap=1 << 12), oracle.search(oplan, data), (seed, case, kw, "whole"))
 
 
 MEDIUM = int(os.environ.get("MM_FUZZ_MEDIUM", "32"))       # raise for a soak
@@ -135,10 +139,12 @@ def test_fuzz_medium_roms(mm, gpu_engine, oracle, seed):
     want = oracle.engine(oplan, rom, block, be)
     got = gpu_engine.scan(plan, block_bytes=block, big_endian=be, cap=1 << 16)
     _note(gpu_engine, "plain")
-    assert got.tolist() == want.tolist(), (seed, kw, elem, be, block, nbytes, alphabet, gpu_engine.counters())
+    _diag.same(mm, gpu_engine, rom, plan, got, want, (seed, kw, elem, be, block, nbytes, alphabet, gpu_engine.counters()), block_bytes=block,
+               big_endian=be)
     tickets = [gpu_engine.submit(plan, block_bytes=block, big_endian=be) for _ in range(3)]
-    for t in tickets:
-        assert gpu_engine.collect(t, cap=1 << 16).tolist() == want.tolist(), (seed, kw, "lanes")
+    lane_results = [gpu_engine.collect(t, cap=1 << 16) for t in tickets]
+    for got in lane_results:
+        _diag.same(mm, gpu_engine, rom, plan, got, want, (seed, kw, "lanes"), block_bytes=block, big_endian=be)
         _note(gpu_engine, "lanes")
     # one chain over the whole buffer (MonkeyMoore<T>::search semantics): long prefixes, the hard resolver
     if not be:
@@ -189,10 +195,20 @@ def test_fuzz_long_keywords(mm, gpu_engine, oracle, seed):
             block = 65536
         got = gpu_engine.scan(plan, block_bytes=block, big_endian=be, cap=1 << 12)
         want = oracle.engine(oplan, rom, block, be)
-        assert got.tolist() == want.tolist(), (seed, case, L, kw, elem, be, block, nbytes, alphabet)
+        _diag.same(mm, gpu_engine, rom, plan, got, want, (seed, case, L, kw, elem, be, block, nbytes, alphabet), block_bytes=block, big_endian=be)
         whole = rom[: (nbytes // elem) * elem]
         data = whole if elem == 1 else whole.view("<u2")
-        assert gpu_engine.scan(plan, cap=1 << 12).tolist() == oracle.search(oplan, data).tolist(), (seed, case, L, kw, "whole")
+        _diag.same(mm, gpu_engine, rom, plan, gpu_engine.scan(plan, cap=1 << 12), oracle.search(oplan, data), (seed, case, L, kw, "whole"))
+
+
+def test_fuzz_left_the_routes_healthy(gpu_engine):
+    """Not one block the fuzz's polled scans published failed the library's validation, the first-use self-test passed
+    with every route on, and no result slot arrived behind its flag word (mmh_health)."""
+    h = gpu_engine.health()
+    print("route health after the fuzz:", h)
+    assert h["fallback_reason"] == 0 and h["fallbacks"] == 0, h
+    assert h["selftest"] == 1 and h["routes_off"] == 0, h
+    assert h["validated"] > 0 or SEEDS == 0, h
 
 
 def _path_report():

@@ -96,6 +96,44 @@ def test_long_scan_lists_take_the_second_phase(mm, comm_engine, oracle):
     assert eng.gather_finish(cap=1 << 20).tolist() == want.tolist()
 
 
+def test_long_device_list_survives_the_scans_behind_its_gather(mm, comm_engine, oracle):
+    """a list beyond a gather record (16384 slots) travels in the second phase, which mmh_gather_finish
+    enqueues -- by then later scans have published into the result copy the first phase sent from (they only wait for the
+    first phase).  The gather keeps its own copy of the block: what comes out is the list of the scan it was started
+    for, also with holes in the slots, also when the list itself is short but its slots are many, also from a ticket."""
+    eng = comm_engine
+    rng = np.random.default_rng(12)
+    nbytes = 24 << 20
+    kw = "monkeybars"
+    plan = mm.plan_relative(1, kw)
+    oplan = oracle.plan(1, kw)
+    other = mm.plan_relative(1, "relativesrch")
+
+    def rom_with(every, breaks=0):
+        rom = rng.integers(0, 256, nbytes).astype(np.uint8)
+        for i, at in enumerate(range(100, nbytes - 64, every)):
+            base = int(rng.integers(0, 200))
+            rom[at:at + len(kw)] = [base + ord(c) - ord("a") for c in kw]
+            if breaks and i % breaks == 0:
+                rom[at] ^= 0x55                            # a candidate of the streaming filter (its key is the keyword's tail) that is no match: a hole
+        return rom
+
+    for every, breaks, via_ticket in ((1000, 0, False), (1000, 3, False), (600, 2, True), (1400, 2, False)):
+        rom = rom_with(every, breaks)
+        want = oracle.engine(oplan, rom, BLOCK).tolist()
+        eng.upload(rom)
+        if via_ticket:
+            local = eng.collect(eng.submit(plan, block_bytes=BLOCK), cap=1 << 16)
+        else:
+            local = eng.scan(plan, block_bytes=BLOCK, cap=1 << 16)
+        assert local.tolist() == want and eng.counters()["candidates"] > 16384 and eng.counters()["path"] == 0, eng.counters()
+        eng.gather_start(None)
+        # scans behind it on the same workspace: the second one publishes into the copy the gather was sent from
+        for _ in range(2):
+            assert len(eng.scan(other, block_bytes=BLOCK)) < len(want)
+        assert eng.gather_finish(cap=1 << 16).tolist() == want, (every, breaks, via_ticket)
+
+
 def test_two_gathers_in_flight_overlap_the_next_scan(mm, comm_engine, oracle):
     # bench.py's pattern at N > 1: scan k, start gather k, finish gather k-1
     eng = comm_engine
