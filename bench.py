@@ -14,8 +14,11 @@ synthetic ROM already resident in HBM.  One step = one full scan of the ROM:
 filter kernel + resolver + ordering + D2H of the offsets, plus -- at N > 1 --
 the RCCL gather of the per-GPU offset lists, issued by the library itself from
 device memory (include/mmoore_hip.h: mmh_gather_start / mmh_gather_finish).
-Weak scaling: every GPU holds its own partition (block-aligned, pattern-length
+Weak scaling (`value`): every GPU holds its own partition (block-aligned, pattern-length
 overlap) of an N x 4 GiB ROM (--config C5: N x 8 GiB, BASELINE.json configs[4]).
+Strong scaling (`strong`, in the same line; `--scaling strong` makes it the value): ONE
+4 GiB ROM dealt over the N GPUs with mmh_partition, the way the reference's dispatcher
+deals one file over its workers (src/core/search_engine.cpp:66-188, :218-253).
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel
 (mm_filter_u8) with HIP events recorded on the scan's own stream;
@@ -84,6 +87,25 @@ def launch_ranks(n, argv, dry):
     return subprocess.run(cmd, env=env).returncode
 
 
+class c_stdout_to_stderr:
+    """What C libraries printf to stdout inside the block goes to stderr instead: RCCL prints a version banner from its
+    communicator bring-up, and rank 0's stdout is ONE JSON line.  (Python's own stdout buffer is flushed first; the C
+    stdio buffers are flushed while file descriptor 1 points at stderr.)"""
+
+    def __enter__(self):
+        import ctypes
+        sys.stdout.flush()
+        self.libc = ctypes.CDLL(None)
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *a):
+        self.libc.fflush(None)
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def _timed(fn, warmups, runs):
     for _ in range(warmups):
         fn()
@@ -95,10 +117,69 @@ def _timed(fn, warmups, runs):
     return times, last
 
 
-def cpu_baseline(eng, shard_bytes, cfg, want_bytes, warmups, runs):
+class Facade:
+    """libmonkey-core.so through its C bindings (host/c_bindings.cpp): SearchEngine<T>::run of THIS repository."""
+
+    def __init__(self, mm):
+        import ctypes as C
+        self.C = C
+        self.lib = C.CDLL(mm.build.CORE_SO)
+        u32p, u64p, i16p = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_int16)
+        self.lib.mmoore_c_last_error.restype = C.c_char_p
+        self.lib.mmoore_c_engine_run.restype = C.c_int64
+        self.lib.mmoore_c_engine_run.argtypes = [C.c_int, C.c_char_p, u32p, C.c_int, C.c_uint32, u32p, C.c_int, i16p, C.c_int, C.c_int,
+                                                 C.c_int, C.c_int, C.c_int, u64p, C.c_uint64]
+        self.lib.mmoore_c_result_maps.restype = C.c_int64
+        self.lib.mmoore_c_result_maps.argtypes = [u32p, u32p, C.c_uint64, C.c_int]
+
+    def engine(self, elem, path, keyword, wildcard, big_endian, block, cap):
+        C = self.C
+        kw = np.array([ord(c) for c in keyword], np.uint32)
+        out = np.zeros(cap, np.uint64)
+        n = self.lib.mmoore_c_engine_run(elem, path.encode(), kw.ctypes.data_as(C.POINTER(C.c_uint32)), len(kw), wildcard, None, 0, None, 0,
+                                         int(big_endian), block, 50, 0, out.ctypes.data_as(C.POINTER(C.c_uint64)), cap)
+        if n < 0:
+            raise RuntimeError("SearchEngine<T>::run on the GPU facade failed: " + self.lib.mmoore_c_last_error().decode())
+        return out[:min(n, cap)].copy()
+
+    def maps(self, n, pairs=2):
+        C = self.C
+        sym, val = np.zeros(n * pairs, np.uint32), np.zeros(n * pairs, np.uint32)
+        got = self.lib.mmoore_c_result_maps(sym.ctypes.data_as(C.POINTER(C.c_uint32)), val.ctypes.data_as(C.POINTER(C.c_uint32)), n, pairs)
+        return got, sym, val
+
+
+def end_to_end(mm, ref, path, nbytes, cfg, ref_offs, warmups, runs):
+    """The apples-to-apples figure ("also report H2D-inclusive end-to-end separately"): the facade's
+    SearchEngine<T>::run on the very tmpfs file the CPU baseline was timed on -- file -> parallel readers -> pinned
+    staging -> PCIe -> HBM -> scan -> offsets + equivalency maps -- against the reference's run of the same call."""
+    fac = Facade(mm)
+    elem, kw, wc, be = cfg["elem"], cfg["keyword"], cfg["wildcard"] or ord("*"), cfg["be"]
+    cap = len(ref_offs) + 64
+    times, offs = _timed(lambda: fac.engine(elem, path, kw, wc, be, BLOCK, cap), warmups, runs)
+    same_offsets = bool(np.array_equal(offs, np.asarray(ref_offs, dtype=np.uint64)))
+    # equivalency maps of every match, both sides (ASCII keyword: the 'A' and 'a' bases)
+    got, sym, val = fac.maps(len(offs))
+    ref.engine(elem, None, kw, wc, None, big_endian=be, threads=os.cpu_count() or 1, block_size=BLOCK, path=path)
+    same_maps = got == len(offs)
+    for i in range(len(offs)) if same_maps else ():
+        if sorted(ref.result_map(i).items()) != sorted(zip(sym[2 * i: 2 * i + 2].tolist(), val[2 * i: 2 * i + 2].tolist())):
+            same_maps = False
+            break
+    med, best = float(np.median(times)), min(times)
+    assert same_offsets and same_maps, "the facade's file search differs from the reference's (offsets %s, maps %s)" % (same_offsets, same_maps)
+    return dict(value=nbytes / med / 1e9, unit="GB/s", ms_per_run=med * 1e3, best_ms=best * 1e3, best_GBps=nbytes / best / 1e9,
+                runs=runs, warmups=warmups, bytes=nbytes, matches=int(len(offs)),
+                same_offsets_as_reference=same_offsets, same_values_maps_as_reference=same_maps,
+                what="SearchEngine<uint%d_t>::run of libmonkey-core.so (the include/mmoore facade over the C ABI) on the tmpfs file of "
+                     "cpu_baseline: ingest over PCIe + scan + equivalency maps, no previews; median of the timed runs; NOT `value` "
+                     "(which scans a ROM resident in HBM)" % (8 * elem))
+
+
+def cpu_baseline(mm, eng, shard_bytes, cfg, want_bytes, warmups, runs, with_end_to_end=True):
     """the reference CPU engine on the bench ROM written to tmpfs,
     hardware_concurrency threads, 512 KiB blocks, >= 3 warm-ups, >= 10 timed runs, median + min.
-    Returns (json object, offsets, bytes covered)."""
+    Returns (json object, offsets, bytes covered, end_to_end object or None)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from _oracle import Oracle, Ref
     cores = os.cpu_count() or 1
@@ -112,7 +193,7 @@ def cpu_baseline(eng, shard_bytes, cfg, want_bytes, warmups, runs):
         offs = orc.engine(orc.plan(elem, plan_kw, wc), rom, BLOCK, be)
         dt = time.perf_counter() - t0
         return dict(value=n / dt / 1e9, unit="GB/s", cores=1, kind="port",
-                    sample="first %d MiB of the bench ROM, scalar C restatement, 1 run" % (n >> 20)), offs, n
+                    sample="first %d MiB of the bench ROM, scalar C restatement, 1 run" % (n >> 20)), offs, n, None
     ref = Ref()
     tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
     # the whole 4 GiB (the largest file the shipped engine handles, search_engine.cpp:241-242) when
@@ -132,6 +213,14 @@ def cpu_baseline(eng, shard_bytes, cfg, want_bytes, warmups, runs):
                 f.write(memoryview(eng.download(at, min(piece, n - at))))
         times, offs = _timed(lambda: ref.engine(elem, None, plan_kw, wc or ord("*"), None, big_endian=be, threads=cores,
                                                 block_size=BLOCK, path=path), warmups, runs)
+        e2e = None
+        if with_end_to_end:
+            try:
+                e2e = end_to_end(mm, ref, path, n, cfg, offs, warmups, runs)
+            except AssertionError:
+                raise
+            except Exception as e:                            # noqa: BLE001 -- reported, never hidden
+                e2e = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
     finally:
         if os.path.exists(path):
             os.unlink(path)
@@ -150,7 +239,7 @@ def cpu_baseline(eng, shard_bytes, cfg, want_bytes, warmups, runs):
                 median_GBps=n / med / 1e9, best_GBps=n / best / 1e9, runs=runs, warmups=warmups, bytes=n,
                 single_thread=single,
                 single_thread_sample="MonkeyMoore<uint8_t>::search, 1 thread, 16 MiB mt19937(42) buffer "
-                                     "(benchmarks/bench_search.cpp shape), 3 warm-ups, 10 runs"), offs, n
+                                     "(benchmarks/bench_search.cpp shape), 3 warm-ups, 10 runs"), offs, n, e2e
 
 
 def pmc_traffic(mm, shard):
@@ -176,6 +265,21 @@ def pmc_traffic(mm, shard):
     return None, None
 
 
+def condition_device(eng, scan, settle=0.005, most_s=1.5, least_s=0.1):
+    """Scans until the streaming kernel's duration (HIP events) has settled: three consecutive scans within `settle` of
+    each other, at least least_s and at most most_s of load.  Returns what it took."""
+    t0 = time.perf_counter()
+    last, scans = [], 0
+    while True:
+        scan()
+        scans += 1
+        last = (last + [eng.timings()["filter_ms"]])[-3:]
+        dt = time.perf_counter() - t0
+        settled = len(last) == 3 and min(last) > 0 and (max(last) - min(last)) / min(last) <= settle
+        if (settled and dt >= least_s) or dt >= most_s:
+            return {"scans": scans, "seconds": round(dt, 3), "settled": bool(settled), "last_kernel_ms": [round(x, 4) for x in last]}
+
+
 def other_config(mm, torch, dev, name, scans, steps):
     """One of BASELINE.json's other single-GPU configurations behind the timed region: `scans` synchronous scans
     (mmh_scan) for the kernel's own duration and the caller's latency, `steps` steps with three scans in flight
@@ -191,10 +295,12 @@ def other_config(mm, torch, dev, name, scans, steps):
         eng.attach(buf.data_ptr(), nbytes)
         mm.synth.RomSpec(SEED, nbytes, kw, elem, wc, be, BLOCK).apply_device(eng)
         plan = mm.plan_relative(elem, kw, wc or 0)
-        # untimed: clocks back up after the ROM's set-up, the lanes' streams and workspaces created
-        t_pre = time.perf_counter()
-        while time.perf_counter() - t_pre < 0.2:
-            offs = eng.scan(plan, block_bytes=BLOCK, big_endian=be)
+        # untimed: clocks back up after the ROM's set-up (an 8 GiB allocation + fill leaves the device idle-clocked for
+        # longer than a fixed 0.2 s covers on some boxes: round 3's driver line had C3's kernel 5 % above its profile),
+        # the lanes' streams and workspaces created.  Condition until the streaming kernel's own duration has settled:
+        # three consecutive scans within 0.5 % of each other (at most 1.5 s).
+        conditioning = condition_device(eng, lambda: eng.scan(plan, block_bytes=BLOCK, big_endian=be))
+        offs = eng.scan(plan, block_bytes=BLOCK, big_endian=be)
         for t in [eng.submit(plan, block_bytes=BLOCK, big_endian=be) for _ in range(3)]:
             eng.collect(t)
         for _ in range(3):
@@ -223,11 +329,13 @@ def other_config(mm, torch, dev, name, scans, steps):
         lim = (n // BLOCK - 1) * BLOCK
         g, c = offs[offs < lim].tolist(), [int(x) for x in want if x < lim]
         assert g == c, name + ": GPU offsets differ from the oracle on the first %d MiB" % (lim >> 20)
-        k = float(np.mean(filt))
+        k = float(np.median(filt))
         return {
             "workload": "%s: %s, engine semantics, 512 KiB blocks, %.1f GiB splitmix64 ROM resident in HBM" % (name, cfg["what"], cfg["gib"]),
             "kernel": "mm_filter_u%d<%d>" % (8 * elem, mm.filter_shape(plan)["shape"]),
-            "kernel_ms": k, "kernel_ms_min": float(np.min(filt)), "scan_device_ms": float(np.mean(tot)),
+            "kernel_ms": k, "kernel_ms_mean": float(np.mean(filt)), "kernel_ms_min": float(np.min(filt)),
+            "kernel_ms_is": "median over the synchronous scans", "conditioning": conditioning,
+            "scan_device_ms": float(np.median(tot)),
             "achieved_GBps": nbytes / (k * 1e-3) / 1e9, "frac": nbytes / (k * 1e-3) / 1e9 / PEAK_HBM_GBS,
             "synchronous": {"scans": scans, "ms_per_scan": sync_s / scans * 1e3, "GBps": nbytes * scans / sync_s / 1e9},
             "in_flight": {"steps": steps, "ms_per_step": flight_s / steps * 1e3, "GBps": nbytes * steps / flight_s / 1e9},
@@ -272,6 +380,13 @@ def main():
                          "never used for a reported figure")
     ap.add_argument("--force-gather", action="store_true",
                     help="N = 1 only (tests): take the N > 1 path anyway -- process group, communicator and gather of ONE rank")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default): N x the config's ROM, one partition per GPU -- `value`; the line also carries `strong`: "
+                         "ONE ROM of the config's size dealt over the N GPUs.  strong: that figure becomes `value`")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling leg behind the timed region")
+    ap.add_argument("--no-end-to-end", action="store_true",
+                    help="skip the facade's SearchEngine<T>::run on the CPU baseline's tmpfs file (`end_to_end`)")
+    ap.add_argument("--no-read-probe", action="store_true", help="skip the pure-read probe (`roofline.measured_read_ceiling_GBps`)")
     ap.add_argument("--no-other-depth", action="store_true",
                     help="skip the extra K steps at the other depth after the timed region (the 'synchronous' / 'in_flight' object)")
     args = ap.parse_args()
@@ -287,7 +402,18 @@ def main():
                          % (args.gpus, world))
         raise SystemExit(2)
     if args.dry_launch:
-        print(json.dumps({"dry_launch": True, "rank": rank, "local_rank": local_rank, "world": world, "gpus": args.gpus}), flush=True)
+        # (host only: the partition rule of mmh_partition for both scaling modes, no GPU touched)
+        from __graft_entry__ import load_package
+        mm = load_package()
+        cfg = CONFIGS[args.config]
+        gib = args.gib_per_gpu if args.gib_per_gpu is not None else cfg["gib"]
+        per_gpu = int(gib * (1 << 30)) // BLOCK * BLOCK
+        L, ELEM = len(cfg["keyword"]), cfg["elem"]
+        wb, ws = mm.partition_range(per_gpu * world, BLOCK, L, ELEM, rank, world)
+        sb, ss = mm.partition_range(per_gpu, BLOCK, L, ELEM, rank, world)
+        print(json.dumps({"dry_launch": True, "rank": rank, "local_rank": local_rank, "world": world, "gpus": args.gpus,
+                          "scaling": args.scaling, "weak": {"total": per_gpu * world, "base": wb, "bytes": ws},
+                          "strong": {"total": per_gpu, "base": sb, "bytes": ss, "overlap": (L - 1) * ELEM}}), flush=True)
         return
 
     # (the pool's host driver only supports dmabuf IPC: RCCL across processes needs this; exported on the boxes already)
@@ -306,7 +432,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     multi = world > 1 or args.force_gather
+    banner = c_stdout_to_stderr() if multi else None     # (RCCL's version banner: until both communicators are up)
     if multi:
+        banner.__enter__()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -360,7 +488,9 @@ def main():
         # all ranks must take the same path
         ok = torch.tensor([1 if (gather_backend or args.torch_gather) else 0], device=dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0:
+        all_up = int(ok.item())
+        banner.__exit__()                                     # both communicators have made their first calls
+        if all_up == 0:
             # The product path is the library's own collective.  Timing the torch.distributed double in its place would
             # print a throughput the product did not deliver: say so in a line without a value and fail the run.
             if rank == 0:
@@ -422,20 +552,23 @@ def main():
             while time.perf_counter() < t_end:
                 pass
 
-    def run_steps(k, depth):
-        """k steps = k scans of the shard + k deliveries, nothing left in flight at the end"""
+    def run_steps(k, depth, at=None, gather=True):
+        """k steps = k scans of the shard + k deliveries, nothing left in flight at the end.  at: the shard's base offset
+        (default: this rank's weak-scaling partition); gather=False: no collective (a rank measuring on its own)"""
+        at = base if at is None else at
+        hand = deliver if gather else (lambda offs: offs)
         last, tickets = None, []
         for _ in range(k):
             late_host()
             if depth == 1:
-                last = deliver(eng.scan(plan, block_bytes=BLOCK, big_endian=BE, base_offset=base))
+                last = hand(eng.scan(plan, block_bytes=BLOCK, big_endian=BE, base_offset=at))
             else:
-                tickets.append(eng.submit(plan, block_bytes=BLOCK, big_endian=BE, base_offset=base))
+                tickets.append(eng.submit(plan, block_bytes=BLOCK, big_endian=BE, base_offset=at))
                 if len(tickets) == depth:
-                    last = deliver(eng.collect(tickets.pop(0)))
+                    last = hand(eng.collect(tickets.pop(0)))
         while tickets:
-            last = deliver(eng.collect(tickets.pop(0)))
-        return drain(last)
+            last = hand(eng.collect(tickets.pop(0)))
+        return drain(last) if gather else last
 
     def fence():
         if multi:
@@ -451,6 +584,11 @@ def main():
     while time.perf_counter() - t_pre < args.prewarm_s:
         eng.scan(plan, block_bytes=BLOCK, big_endian=BE, base_offset=base)
         prewarm_scans += 1
+    if multi:
+        # ... and the collective's own first calls (RCCL sets up its channels and buffers on the first all-gathers:
+        # measured with one rank, the first ~10 gathered steps cost 0.1 ms more each than the steady state)
+        run_steps(max(12, args.warmup), args.depth)
+        prewarm_scans += max(12, args.warmup)
     run_steps(args.warmup, args.depth)
     fence()
     del gather_dev_ms[:], gather_host_ms[:]
@@ -493,6 +631,104 @@ def main():
         tmax = torch.tensor([elapsed, elapsed_other], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed, elapsed_other = float(tmax[0].item()), float(tmax[1].item())
+
+    def over_ranks(x):
+        """every rank's x, as a list on every rank"""
+        if not multi:
+            return [float(x)]
+        t = torch.zeros(world, dtype=torch.float64, device=dev)
+        t[rank] = float(x)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [float(v) for v in t.tolist()]
+
+    # what RCCL saw: the size of the library's own communicator on every rank (0: none -- N = 1 without --force-gather)
+    rccl_ranks = over_ranks(eng.comm_info()[1] if native else 0)
+    # the streaming kernel's own duration on every rank (launches that overlap nothing where the run has them)
+    own_filt = filt_other if (args.depth > 1 and not args.no_other_depth) else filt_ms
+    kernel_ms_ranks = over_ranks(float(np.mean(own_filt)))
+
+    # The box's measured read ceiling beside the data-sheet peak: a pure-read kernel over this rank's ROM, <= 50 ms
+    read_probe = None
+    if not args.no_read_probe:
+        try:
+            read_probe = eng.read_probe(20)
+        except Exception as e:                                # noqa: BLE001
+            read_probe = {"error": "%s: %s" % (type(e).__name__, e)}
+    probe_ranks = over_ranks(read_probe.get("mean_GBps", 0.0) if read_probe else 0.0)
+
+    # ---- strong scaling: ONE ROM of the config's size dealt over the N GPUs -------------------------------------------
+    # (the reference's dispatcher deals ONE file over its workers, search_engine.cpp:66-188 / :218-253; at N = 8 a 4 GiB
+    # ROM is 512 MiB per GPU = ~90 us of streaming + tail + gather: the one configuration in which the RCCL gather's
+    # latency shows at all)
+    strong = None
+    if not args.no_strong:
+        stotal = per_gpu
+        sbase, sshard = mm.partition_range(stotal, BLOCK, L, ELEM, rank, world)
+        # N = 1 in the same run: rank 0 scans the whole ROM of that size alone (its weak-scaling shard IS one), the others wait
+        n1_ms = 0.0
+        fence()
+        if rank == 0:
+            run_steps(max(args.warmup, 4), args.depth, gather=False)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run_steps(args.steps, args.depth, gather=False)
+            torch.cuda.synchronize()
+            n1_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        fence()
+        if world > 1:
+            # this rank's partition of the ONE ROM: regenerated in place (the generator is position-determined)
+            eng.attach(buf.data_ptr(), sshard)
+            eng.set_stream(torch.cuda.current_stream().cuda_stream)
+            if sshard:
+                mm.synth.RomSpec(SEED, stotal, KEYWORD, ELEM, WC, BE, BLOCK, base=sbase, nbytes=sshard, partitions=8).apply_device(eng)
+            torch.cuda.synchronize()
+        for _ in range(8):
+            eng.scan(plan, block_bytes=BLOCK, big_endian=BE, base_offset=sbase)
+        run_steps(max(args.warmup, 4), args.depth, at=sbase)
+        fence()
+        del gather_dev_ms[:], gather_host_ms[:]
+        t1 = time.perf_counter()
+        soffs = run_steps(args.steps, args.depth, at=sbase)
+        fence()
+        selapsed = time.perf_counter() - t1
+        sfilt, stot = eng.timing_history(min(args.steps, 64))
+        sg_dev, sg_host = list(gather_dev_ms), list(gather_host_ms)
+        # one scan at a time as well: the latency a caller of the reference API sees (scan + gather, nothing overlapped)
+        fence()
+        t1 = time.perf_counter()
+        soffs1 = run_steps(args.steps, 1, at=sbase)
+        fence()
+        selapsed1 = time.perf_counter() - t1
+        sfilt1, _ = eng.timing_history(min(args.steps, 64))
+        if multi:
+            tm = torch.tensor([selapsed, selapsed1], dtype=torch.float64, device=dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            selapsed, selapsed1 = float(tm[0].item()), float(tm[1].item())
+        s_kernel_ranks = over_ranks(float(np.mean(sfilt1)))
+        n1_ms = max(over_ranks(n1_ms))
+        if rank == 0:
+            assert (np.diff(soffs.astype(np.int64)) > 0).all() and np.array_equal(soffs, soffs1), "strong-scaling lists differ"
+            sms = selapsed / args.steps * 1e3
+            strong = {
+                "rom_bytes_total": stotal, "n_gpus": world, "bytes_per_gpu": [int(v) for v in over_ranks(sshard)] if False else None,
+                "ms_per_step": sms, "GBps": stotal / (selapsed / args.steps) / 1e9,
+                "one_at_a_time": {"ms_per_step": selapsed1 / args.steps * 1e3, "GBps": stotal / (selapsed1 / args.steps) / 1e9},
+                "n1_ms_per_step_same_run": n1_ms,
+                "efficiency_vs_n1": n1_ms / (world * sms) if sms > 0 else None,
+                "kernel_ms_per_rank": {"min": min(s_kernel_ranks), "max": max(s_kernel_ranks)},
+                "gather_ms": ({"device_collective_and_pack": float(np.mean(sg_dev)) if sg_dev else None,
+                               "host_start_plus_finish": float(np.mean(sg_host)) if sg_host else None} if multi else None),
+                "matches": int(len(soffs)), "scans_in_flight": args.depth,
+                "what": "ONE %.1f GiB ROM dealt over %d GPU(s) with mmh_partition (whole 512 KiB blocks per rank, %d bytes of "
+                        "pattern-length overlap), every step = every rank scans its partition + the offset lists are gathered; "
+                        "efficiency = this run's N = 1 time per step / (N x this time)" % (stotal / (1 << 30), world, (L - 1) * ELEM),
+            }
+        if world > 1:
+            # back to the weak-scaling shard (cpu_baseline reads the ROM of the timed configuration)
+            eng.attach(buf.data_ptr(), shard)
+            eng.set_stream(torch.cuda.current_stream().cuda_stream)
+            spec.apply_device(eng)
+            torch.cuda.synchronize()
 
     if rank == 0:
         ctr = eng.counters()
@@ -558,6 +794,9 @@ def main():
                 "frac": achieved / PEAK_HBM_GBS,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                "measured_read_ceiling_GBps": (read_probe or {}).get("mean_GBps"),
+                "frac_of_measured": (achieved / read_probe["mean_GBps"]) if read_probe and read_probe.get("mean_GBps") else None,
+                "measured_read_ceiling": read_probe,
                 "algorithmic_bytes": shard,
                 "kernel_ms": filt,
                 "kernel_ms_median": float(np.median(alone_filt)),
@@ -579,7 +818,24 @@ def main():
             "stages_ms": {"filter": filt, "resolve_order_publish": float(np.mean(alone_tot)) - filt,
                           "device_total": float(np.mean(alone_tot)), "host_wall_per_step": elapsed / args.steps * 1e3},
             "counters_rank0": ctr,
+            # what RCCL saw (the library's communicator on every rank; [0]: N = 1 without a communicator) and the streaming
+            # kernel's own duration on every rank
+            "rccl_ranks": {"min": int(min(rccl_ranks)), "max": int(max(rccl_ranks)), "expected": world if native else 0},
+            "kernel_ms_per_rank": {"min": min(kernel_ms_ranks), "max": max(kernel_ms_ranks),
+                                   **({"all": kernel_ms_ranks} if world > 1 else {})},
+            "health_rank0": eng.health(),
         }
+        if world > 1:
+            res["roofline"]["measured_read_ceiling_per_rank_GBps"] = {"min": min(probe_ranks), "max": max(probe_ranks)}
+        if strong is not None:
+            res["strong"] = strong
+            if args.scaling == "strong":
+                # the strong-scaling figure as the line's value: ONE ROM over N GPUs
+                res["weak"] = {"value": res["value"], "ms_per_step": res["ms_per_step"], "rom_bytes_total": total}
+                res["value"], res["ms_per_step"], res["scaling"] = strong["GBps"], strong["ms_per_step"], "strong"
+                res["metric"] = "GB/s scanned (ONE %g GiB synthetic ROM over %d GPU(s), %d-char %d-bit relative pattern)" % (
+                    gib, world, L, 8 * ELEM)
+                res["config"]["rom_bytes_total"] = per_gpu
         if multi:
             # where an N > 1 step's time goes besides the scan: the collective + packing on the device
             # (HIP events on the communication stream) and the host's share of start + finish
@@ -610,21 +866,26 @@ def main():
             # BASELINE.json's other single-GPU configurations, NOT part of `value`
             res["other_configs"] = {name: other_config(mm, torch, dev, name, args.other_scans, 2 * args.other_scans)
                                     for name in OTHER_CONFIGS}
-        if not multi and not args.no_cpu_baseline:
-            cb, cpu_offs, ncov = cpu_baseline(eng, shard, cfg, args.cpu_sample_mib << 20, args.cpu_warmups, args.cpu_runs)
+        if not args.no_cpu_baseline:
+            # (N > 1: rank 0 alone, behind every timed region; the other ranks wait at the barrier below)
+            cb, cpu_offs, ncov, e2e = cpu_baseline(mm, eng, shard, cfg, args.cpu_sample_mib << 20, args.cpu_warmups, args.cpu_runs,
+                                                   with_end_to_end=not args.no_end_to_end)
             res["cpu_baseline"] = cb
+            if e2e is not None:
+                res["end_to_end"] = e2e
             # parity of the timed configuration: the whole ROM when the CPU run covered it, else
             # the blocks fully inside the covered prefix
+            mine = offs[offs < np.uint64(base + shard - (L - 1) * ELEM)] if multi else offs      # (N > 1: rank 0's partition of the gathered list)
             if ncov >= shard:
-                g, c = offs.tolist(), [int(x) for x in cpu_offs]
+                g, c = mine.tolist(), [int(x) for x in cpu_offs]
                 res["config"]["parity_vs_cpu"] = "whole ROM: %d offsets identical" % len(g) if g == c else "MISMATCH"
             else:
                 lim = (ncov // BLOCK - 1) * BLOCK
-                g = offs[offs < lim].tolist()
+                g = mine[mine < lim].tolist()
                 c = [int(x) for x in cpu_offs if x < lim]
                 res["config"]["parity_vs_cpu"] = "first %d MiB: %d offsets identical" % (lim >> 20, len(g)) if g == c else "MISMATCH"
             assert g == c, "GPU offsets differ from the reference CPU engine"
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)            # (flushed here: a redirected stdout is block-buffered, and what runs at exit must not cost the line)
     if multi:
         dist.barrier()
         dist.destroy_process_group()

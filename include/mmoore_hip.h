@@ -292,6 +292,11 @@ int mmh_selftest_kat(uint8_t *rom, uint64_t rom_cap, uint64_t *rom_bytes, uint64
 /* Runs the self-test again on this context's device (a context of its own); *routes_off = what it would switch off;
  * MMH_E_DEVICE when the plain kernels fail it. */
 int mmh_selftest_run(int device, uint32_t *routes_off);
+/* What this box's HBM delivers to a kernel that only reads (csrc/mm_probe.hip): `reps` timed passes of two pure-read
+ * kernels over the context's ROM (>= 64 MiB, in HBM), HIP events around every pass.  *mean_GBps = the better pattern's mean
+ * rate -- the measured ceiling bench.py reports beside the data sheet's 8 TB/s --, *best_GBps its
+ * fastest pass, *ms_per_pass (may be NULL) its mean duration. */
+int mmh_selftest_read_probe(mmh_ctx *ctx, int reps, double *best_GBps, double *mean_GBps, double *ms_per_pass);
 /* Tests only: damage the block the next polled scan of this context publishes, on the host, before it is validated --
  * 1 flag bits, 2 a slot left at the poison, 3 two slots swapped, 4 a slot outside the ROM, 5 the announced count. */
 int mmh_debug_inject(mmh_ctx *ctx, uint32_t kind);

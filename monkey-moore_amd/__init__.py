@@ -31,7 +31,7 @@ EXPORTS = [
     "mmh_scan_submit", "mmh_scan_collect", "mmh_rom_load_file_watched",
     "mmh_partition", "mmh_comm_unique_id", "mmh_comm_init_rank", "mmh_comm_init_all", "mmh_comm_info", "mmh_comm_destroy",
     "mmh_gather_start", "mmh_gather_finish", "mmh_last_gather_timings", "mmh_scan_multi", "mmh_selftest_gather_pack",
-    "mmh_set_route", "mmh_health", "mmh_selftest_kat", "mmh_selftest_run", "mmh_debug_inject",
+    "mmh_set_route", "mmh_health", "mmh_selftest_kat", "mmh_selftest_run", "mmh_debug_inject", "mmh_selftest_read_probe",
 ]
 ROUTE_NO_SINGLE_LAUNCH, ROUTE_NO_ZERO_COPY, ROUTE_NO_BUCKETS, ROUTE_NO_POLLED = 1, 2, 4, 8
 FB_NONE, FB_HEADER, FB_CAPACITY, FB_STALE_SLOT, FB_ORDER, FB_RANGE, FB_SELFTEST = range(7)
@@ -134,6 +134,7 @@ def lib():
         L.mmh_selftest_kat.argtypes = [C.POINTER(C.c_uint8), C.c_uint64, u64p, u64p, C.c_uint64, u64p]
         L.mmh_selftest_run.argtypes = [C.c_int, u32p]
         L.mmh_debug_inject.argtypes = [C.c_void_p, C.c_uint32]
+        L.mmh_selftest_read_probe.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _lib = L
     return _lib
 
@@ -441,6 +442,14 @@ class Engine:
         _check(lib().mmh_health(self._h, h))
         return dict(fallback_reason=int(h[0]), fallbacks=int(h[1]), late_slots=int(h[2]), last_reason=int(h[3]), routes_off=int(h[4]),
                     process_routes_off=int(h[5]), selftest=int(h[6]), validated=int(h[7]), header=[int(v) for v in h[8:16]])
+
+    def read_probe(self, reps=20):
+        """Pure-read passes over the ROM (mmh_selftest_read_probe): the box's measured HBM read ceiling."""
+        best, mean, ms = C.c_double(0), C.c_double(0), C.c_double(0)
+        _check(lib().mmh_selftest_read_probe(self._h, reps, C.byref(best), C.byref(mean), C.byref(ms)))
+        return dict(mean_GBps=mean.value, best_GBps=best.value, ms_per_pass=ms.value, passes=reps,
+                    what="pure-read kernels over the same ROM (grid-stride and 64 KiB wave spans, 16-byte loads), HIP events per pass, "
+                         "the better pattern's mean")
 
     def counters(self):
         c = (C.c_uint64 * 4)()

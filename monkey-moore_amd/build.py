@@ -62,7 +62,7 @@ def build_capi(force=False):
         return CAPI_SO
     obj_dir = os.path.join(LIB_DIR, "obj")
     os.makedirs(obj_dir, exist_ok=True)
-    units = ("mm_kernels.hip", "mm_capi.hip", "mm_multi.hip", "mm_ingest.hip", "mm_sort.hip", "mm_plan.cpp")
+    units = ("mm_kernels.hip", "mm_capi.hip", "mm_multi.hip", "mm_ingest.hip", "mm_sort.hip", "mm_probe.hip", "mm_plan.cpp")
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(ROOT, "include", "mmoore_hip.h")]
     flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
@@ -83,7 +83,7 @@ def build_capi(force=False):
 
 def build_core(force=False):
     """The C++17 facade (MonkeyMoore<T>, SearchEngine<T>) over the C ABI."""
-    srcs = [os.path.join(HOST, f) for f in ("monkey_moore.cpp", "search_engine.cpp")]
+    srcs = [os.path.join(HOST, f) for f in ("monkey_moore.cpp", "search_engine.cpp", "c_bindings.cpp")]
     if not all(os.path.exists(s) for s in srcs):
         return None
     inc = os.path.join(ROOT, "include", "mmoore")

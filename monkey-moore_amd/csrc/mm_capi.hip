@@ -1293,7 +1293,8 @@ int run_flagged_domains(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, ui
 // with the flagged domains masked out; (4) the forward engine over the flagged domains;
 // (5) merge.  Engine mode only.  *handled = false: no use (floods everywhere) -> caller's fallback.
 int run_candidate_floods(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, const mm::FilterChoice &fc, uint64_t base_offset,
-                         uint32_t max_candidates, std::vector<uint64_t> *merged, uint64_t *domains_flagged, bool *handled)
+                         uint32_t max_candidates, std::vector<uint64_t> *merged, uint64_t *domains_flagged, bool *handled,
+                         uint64_t *counted)
 {
    hipStream_t st = c->stream;
    MmWorkspace &w = c->ws[0];
@@ -1327,6 +1328,7 @@ int run_candidate_floods(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, c
       order[d] = (uint32_t)d;
       total += count[d];
    }
+   *counted = total;                              // (what the count pass saw: the scan's candidate counter, mmh_last_counters)
    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return count[x] > count[y]; });
    std::vector<uint32_t> bits(words, 0), doms;
    for (uint64_t k = 0; k < ndom && total > max_candidates / 2; k++) {
@@ -1540,11 +1542,13 @@ int scan_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int b
       if (mode == FAST && !g.whole && (oc.candidates > c->ws[0].out_cap || oc.candidates > max_candidates)) {
          // candidate flood: forward engine on the flooded domains, the per-candidate path on the rest
          bool handled = false;
-         rc = run_candidate_floods(c, g, *plan, fc, base_offset, max_candidates, &long_list, &oc.tiles, &handled);
+         uint64_t counted = 0;
+         rc = run_candidate_floods(c, g, *plan, fc, base_offset, max_candidates, &long_list, &oc.tiles, &handled, &counted);
          if (rc != MMH_OK) {
             return rc;
          }
          if (handled) {
+            oc.candidates = counted;                 // (the first pass only knew "a list overflowed": ~0)
             oc.matches = long_list.size();
             host_list = true;
             flooded_domains = true;
@@ -1584,7 +1588,7 @@ int scan_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int b
       oc.matches = long_list.size();
       host_list = true;
    }
-   c->counters[0] = oc.candidates;
+   c->counters[0] = oc.candidates == ~0ull ? 0 : oc.candidates;   // (~0: "a candidate list overflowed" of a pass that was abandoned)
    c->counters[1] = oc.matches;
    c->counters[2] = oc.tiles;
    c->counters[3] = mode == SEQUENTIAL ? 1 : (mode == DENSE ? 3 : (flooded_domains ? 5 : (flagged_domains ? 4 : (oc.hard ? 2 : 0))));

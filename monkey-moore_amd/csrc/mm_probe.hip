@@ -1,0 +1,131 @@
+// SPDX-License-Identifier: GPL-3.0-or-later
+// mm_probe.hip -- what this box's HBM delivers to a kernel that does nothing but read: the measured ceiling the
+// streaming filter is priced against beside the 8 TB/s of the data sheet ("to be cross-checked on
+// the box with a streaming-read microbenchmark"; SURVEY 8d: "report measured-achievable alongside spec").
+//
+// Two access patterns over the context's ROM, both with fully coalesced 16-byte loads and no work on the data beyond an
+// XOR that keeps the loads alive: a grid-stride sweep (every wave instruction reads 1 KiB, consecutive waves consecutive
+// KiB) and the filter's own pattern (a wave streams a contiguous 64 KiB span, four loads in flight).  The figure is the
+// best mean over the patterns -- a ceiling, so the most favourable honest reading counts.  Round 1 measured 6.2-6.3 TB/s
+// with tools/stream_probe.hip (profiles/r01_stream_probe_read_ceiling.log); bench.py now runs this in every line.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "mm_context.h"
+#include "mm_internal.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void mm_probe_gridstride(const uint4 *p, uint64_t nchunks, uint32_t *sink)
+{
+   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+   uint32_t acc = 0;
+   for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nchunks; c += stride) {
+      const uint4 w = p[c];
+      acc ^= w.x ^ w.y ^ w.z ^ w.w;
+   }
+   if (acc == 0x12345678u) {
+      sink[0] = acc;                                        // (practically never: keeps the loads from being optimised away)
+   }
+}
+
+__global__ __launch_bounds__(256) void mm_probe_wavespan(const uint4 *p, uint64_t nchunks, uint64_t span_chunks, uint32_t *sink)
+{
+   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+   const uint32_t lane = threadIdx.x & 63;
+   const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+   uint32_t acc = 0;
+   for (uint64_t s = wave * span_chunks; s < nchunks; s += nwaves * span_chunks) {
+      const uint64_t e = s + span_chunks < nchunks ? s + span_chunks : nchunks;
+      uint64_t c = s + lane;
+      for (; c + 64 * 3 < e; c += 64 * 4) {
+         const uint4 w0 = p[c], w1 = p[c + 64], w2 = p[c + 128], w3 = p[c + 192];
+         acc ^= w0.x ^ w0.y ^ w0.z ^ w0.w ^ w1.x ^ w1.y ^ w1.z ^ w1.w ^ w2.x ^ w2.y ^ w2.z ^ w2.w ^ w3.x ^ w3.y ^ w3.z ^ w3.w;
+      }
+      for (; c < e; c += 64) {
+         const uint4 w = p[c];
+         acc ^= w.x ^ w.y ^ w.z ^ w.w;
+      }
+   }
+   if (acc == 0x12345678u) {
+      sink[0] = acc;
+   }
+}
+
+} // namespace
+
+extern "C" int mmh_selftest_read_probe(mmh_ctx *c, int reps, double *best_GBps, double *mean_GBps, double *ms_per_pass)
+{
+   if (!c || !best_GBps || !mean_GBps || reps < 1 || reps > 1000) {
+      mmh_set_error("mmh_selftest_read_probe: bad argument");
+      return MMH_E_ARG;
+   }
+   if (!c->rom || c->rom == c->rom_host || c->rom_bytes < (64u << 20)) {
+      mmh_set_error("mmh_selftest_read_probe: needs a ROM of at least 64 MiB in HBM");
+      return MMH_E_STATE;
+   }
+   auto ok = [](hipError_t e, const char *what) {
+      if (e != hipSuccess) {
+         mmh_set_error("%s: %s", what, hipGetErrorString(e));
+         return false;
+      }
+      return true;
+   };
+   if (!ok(hipSetDevice(c->device), "hipSetDevice")) {
+      return MMH_E_DEVICE;
+   }
+   uint32_t *sink = nullptr;
+   hipEvent_t a = nullptr, b = nullptr;
+   if (!ok(hipMalloc(&sink, 64), "hipMalloc") || !ok(hipEventCreate(&a), "hipEventCreate") || !ok(hipEventCreate(&b), "hipEventCreate")) {
+      return MMH_E_DEVICE;
+   }
+   const uint4 *p = reinterpret_cast<const uint4 *>(c->rom);
+   const uint64_t nchunks = c->rom_bytes / 16;
+   const double bytes = (double)nchunks * 16.0;
+   hipStream_t st = c->stream;
+   double best_mean_ms = 1e30, best_min_ms = 1e30;
+   int rc = MMH_OK;
+   for (int pattern = 0; pattern < 2 && rc == MMH_OK; pattern++) {
+      auto launch = [&]() {
+         if (pattern == 0) {
+            hipLaunchKernelGGL(mm_probe_gridstride, dim3(2048), dim3(256), 0, st, p, nchunks, sink);
+         }
+         else {
+            hipLaunchKernelGGL(mm_probe_wavespan, dim3(2048), dim3(256), 0, st, p, nchunks, (uint64_t)4096, sink);
+         }
+      };
+      for (int i = 0; i < 3; i++) {
+         launch();
+      }
+      double sum = 0, least = 1e30;
+      for (int i = 0; i < reps && rc == MMH_OK; i++) {
+         float ms = 0;
+         if (!ok(hipEventRecord(a, st), "hipEventRecord")) { rc = MMH_E_DEVICE; break; }
+         launch();
+         if (!ok(hipEventRecord(b, st), "hipEventRecord") || !ok(hipEventSynchronize(b), "hipEventSynchronize") ||
+             !ok(hipEventElapsedTime(&ms, a, b), "hipEventElapsedTime")) {
+            rc = MMH_E_DEVICE;
+            break;
+         }
+         sum += ms;
+         least = std::min<double>(least, ms);
+      }
+      if (rc == MMH_OK) {
+         best_mean_ms = std::min(best_mean_ms, sum / reps);
+         best_min_ms = std::min(best_min_ms, least);
+      }
+   }
+   (void)hipEventDestroy(a);
+   (void)hipEventDestroy(b);
+   (void)hipFree(sink);
+   if (rc != MMH_OK) {
+      return rc;
+   }
+   *mean_GBps = bytes / (best_mean_ms * 1e-3) / 1e9;
+   *best_GBps = bytes / (best_min_ms * 1e-3) / 1e9;
+   if (ms_per_pass) {
+      *ms_per_pass = best_mean_ms;
+   }
+   return MMH_OK;
+}
