@@ -22,7 +22,19 @@ def _run(args, env=None, timeout=300):
 
 
 def _lines(out):
-    return [json.loads(ln) for ln in out.splitlines() if ln.startswith("{")]
+    """every JSON object in the text (the ranks of a dry launch write to one inherited pipe: two lines may arrive glued)"""
+    found, dec, at = [], json.JSONDecoder(), 0
+    while True:
+        at = out.find("{", at)
+        if at < 0:
+            return found
+        try:
+            obj, end = dec.raw_decode(out, at)
+        except json.JSONDecodeError:
+            at += 1
+            continue
+        found.append(obj)
+        at = end
 
 
 def test_gpus_n_launches_n_ranks_by_itself():
