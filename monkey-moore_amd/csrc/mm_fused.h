@@ -58,8 +58,6 @@ struct MmFusedArgs {
    unsigned int *bcount;
    unsigned long long *boverflow;
    uint32_t bshift;
-   uint32_t static_rounds;
-   unsigned long long *span_tickets;   // always null here (static span hand-out)
    uint32_t nbuckets;
    uint32_t direct_limit;              // mm_scan_tail2: lists of up to this many slots are also stored straight into pinned host memory
    uint64_t ngroups;

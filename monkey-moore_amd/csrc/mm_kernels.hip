@@ -255,10 +255,6 @@ struct MmFilterArgs {
    unsigned int *bcount;             // [nb] members of every bucket
    unsigned long long *boverflow;    // appends that found their bucket full
    uint32_t bshift;                  // log2 of a bucket's width in bytes
-   uint32_t static_rounds;           // with span tickets: the first rounds stay static, the rest of the ROM is drawn
-   // Dynamic span hand-out (bucketed scans; null: the static round-robin): MM_CAND_LISTS ticket counters, one 128-byte
-   // line each.  Counter c hands out the spans of the c-th 64th of the ROM to the workgroups with blockIdx % 64 == c.
-   unsigned long long *span_tickets;
 
    uint64_t ngroups;       // span kernel: number of whole 4 KiB groups it covers
    uint32_t groups_per_span;
@@ -369,6 +365,81 @@ __device__ __forceinline__ uint64_t *mm_bucket_reserve(const A &a, uint64_t piec
    return a.bcand + b * MM_BUCKET_CAP + base;
 }
 
+// ---- the wave's survivor queue (bucketed scans, round 4) ---------------------------------------------------------------
+// mm_bucket_reserve costs the streaming wave one RETURNING atomic per flagged piece -- a round trip to L2 of a microsecond
+// or two during which the wave streams nothing.  Harmless at one candidate per MiB; in the script of a ROM, where a common
+// word sits every few hundred bytes, every piece of a span is flagged: 28 round trips on a span that streams in 28 us, and
+// the kernel is as slow as its slowest round (profiles/r03_candidate_density.log: 0.72 -> 0.80-0.82 ms at 90 K candidates).
+// So a span's survivors are parked in LDS -- MM_QCAP entries per wave, candidate offsets in the order they were found -- and
+// their buckets are reserved behind the span: one atomic per RUN of entries of the same bucket (a span lies in one or two
+// buckets of a big ROM) instead of one per flagged piece.  Survivors that do not fit (a flood) take the old way.
+constexpr uint32_t MM_QCAP = 128;                 // entries per wave: 1 KiB of LDS (4 KiB per workgroup)
+constexpr int MM_FILTER_WAVES = 4;
+// Queue AND fill count live in LDS, the wave's number is worked out where it is needed: nothing of this is held in a
+// register across the streaming loop (the 16-bit kernel sits at 71 VGPRs = 7 waves per SIMD and at the SGPR limit: two more
+// live scalars spilled into VGPR lanes and cost it a wave per SIMD).
+struct MmSurvivorQueue {
+   uint64_t entry[MM_FILTER_WAVES][MM_QCAP];
+   uint32_t count[MM_FILTER_WAVES];
+};
+
+// this wave's queue (computed on the spot: the asm keeps the compiler from hoisting it out of the streaming loop)
+__device__ __forceinline__ int mm_queue_wave()
+{
+   uint32_t t = threadIdx.x;
+   asm volatile("" : "+v"(t));
+   return __builtin_amdgcn_readfirstlane((int)(t >> 6)) & (MM_FILTER_WAVES - 1);
+}
+
+// queue entries [0, n) to their buckets.  key_bytes: candidate offset + key_bytes = the position the filter keyed on, which is
+// what orders candidates into buckets (monotone in the offset, and inside the piece the wave read it from -- 16-bit odd
+// stream: at most one byte in front of it, which still keeps bucket order = offset order)
+template <class A>
+__device__ __forceinline__ void mm_queue_flush(const A &a, MmSurvivorQueue &Q, uint32_t key_bytes)
+{
+   const int w = mm_queue_wave();
+   const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)Q.count[w]);
+   if (n == 0) {
+      return;
+   }
+   Q.count[w] = 0;
+   const uint64_t *q = Q.entry[w];
+   const uint32_t lane = __lane_id();
+   for (uint32_t pos = 0; pos < n;) {                                     // wave uniform
+      const uint32_t left = n - pos;
+      const uint64_t e = lane < left ? q[pos + lane] : 0ull;
+      const uint64_t b = (e + key_bytes) >> a.bshift;
+      const uint64_t b0 = mm_uniform64_k(b);
+      const unsigned long long same = __ballot(lane < left && b == b0);   // (lane 0 is always in)
+      const uint32_t run = same == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~same);
+      unsigned int base = 0;
+      if (lane == 0) {
+         base = atomicAdd(a.bcount + b0, run);
+         if (base + run > MM_BUCKET_CAP) {
+            atomicAdd(a.boverflow, 1ull);
+         }
+      }
+      base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+      if (lane < run && base + lane < MM_BUCKET_CAP) {
+         mm_store_shared(a.bcand + b0 * MM_BUCKET_CAP + base + lane, e);
+      }
+      pos += run;
+   }
+}
+
+// exclusive prefix of cnt over the wave's lanes; *total = the wave's sum (wave uniform)
+__device__ __forceinline__ uint32_t mm_wave_prefix(uint32_t cnt, uint32_t *total)
+{
+   uint32_t incl = cnt;
+#pragma unroll
+   for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t v = (uint32_t)__shfl_up((int)incl, d);
+      incl += (int)__lane_id() >= d ? v : 0u;
+   }
+   *total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+   return incl - cnt;
+}
+
 __device__ __forceinline__ uint4 mm_load_chunk(const uint8_t *rom, uint64_t nbytes, uint64_t byte0)
 {
    if (byte0 + 16 <= nbytes) {
@@ -466,7 +537,7 @@ __device__ __forceinline__ uint32_t mm_f8_pack(const uint32_t (&h)[4])
 // verify the survivors flagged in `bits` (bit 8*b + k of this lane's chunk at byte `chunk0`)
 // and append the real candidates; the whole wave takes part (ballots inside)
 template <class A>
-__device__ __forceinline__ void mm_f8_survivors(const A &a, uint64_t chunk0, uint32_t bits)
+__device__ __forceinline__ void mm_f8_survivors(const A &a, uint64_t chunk0, uint32_t bits, MmSurvivorQueue *Q = nullptr)
 {
    const bool head = __ballot(bits != 0 && chunk0 < MMH_MAX_KEYWORD) != 0;   // a survivor may lie in front of the anchor
    if (a.bcount) {
@@ -482,6 +553,27 @@ __device__ __forceinline__ void mm_f8_survivors(const A &a, uint64_t chunk0, uin
             }
          }
          bits = keep;
+      }
+      if (Q) {
+         // the streaming kernel: park them in the wave's queue (no round trip to L2 here)
+         uint32_t total;
+         uint32_t at = mm_wave_prefix((uint32_t)__popc(bits), &total);
+         if (total == 0) {
+            return;
+         }
+         const int w = mm_queue_wave();
+         const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)Q->count[w]);
+         if (len + total <= MM_QCAP) {
+            at += len;
+            while (bits) {
+               const int bit = __ffs((int)bits) - 1;
+               bits &= bits - 1;
+               Q->entry[w][at++] = chunk0 + 4 * (bit & 3) + (bit >> 3) - a.iA;
+            }
+            Q->count[w] = len + total;
+            return;
+         }
+         // (the queue is full -- a span with more than MM_QCAP survivors is a flood: straight to the bucket)
       }
       uint32_t slot, room;
       uint64_t *list = mm_bucket_reserve(a, mm_uniform64_k(chunk0), (uint32_t)__popc(bits), &slot, &room);
@@ -556,58 +648,35 @@ __device__ __forceinline__ void mm_f8_survivors(const A &a, uint64_t chunk0, uin
 }
 
 
-// Which span a wave works on next.  Static (tickets == null): round i hands span i*nwaves + ((wave + 2731 i) mod nwaves)
-// to this wave -- neighbouring waves stream neighbouring spans, and anything periodic in the ROM (candidates at every
-// 32 MiB, say) lands on a different wave every round instead of piling up on a few.  Dynamic: the wave draws a ticket
-// from the counter of its workgroup's share of the ROM.  With every wave owning a fixed 1 / nwaves of the ROM a kernel
-// ends when its LAST-started workgroup has done its whole share -- next to another scan's streaming kernel (scans in
-// flight) workgroups start up to 0.7 ms apart, the early ones leave their slots idle long before the kernel ends, and
-// the device ran 2 % below its streaming rate; with tickets whoever is running takes what is left.
+// Which span a wave works on next: round i hands span i*nwaves + ((wave + 2731 i) mod nwaves) to this wave -- neighbouring
+// waves stream neighbouring spans, and anything periodic in the ROM (candidates at every 32 MiB, say) lands on a different
+// wave every round instead of piling up on a few.  (Round 3 also had spans drawn through tickets, for the scans-in-flight
+// case where workgroups start up to 0.7 ms apart: measured worse in every mix -- the ticket's round trip at every span
+// boundary and the loss of "neighbouring waves stream neighbouring spans" cost more than the balance gains, 0.742 against
+// 0.705 ms per 4 GiB, profiles/r03_lane_gate_and_span_tickets.log -- and its cursor held 16 SGPRs across the streaming
+// loop of a kernel that sits at the SGPR limit: removed in round 4.)  32-bit throughout: a span is >= 4 KiB.
 struct MmSpanCursor {
-   uint64_t round, nwaves, wave, nspans;
-   uint64_t static_spans;                   // spans [0, static_spans) go round by round, the rest through tickets
-   unsigned long long *ticket;
-   uint64_t first, end;                     // dynamic: this counter's spans
+   uint32_t round, nwaves, wave, nspans;
 };
 
 template <class A>
-__device__ __forceinline__ MmSpanCursor mm_span_cursor(const A &a, uint64_t wave, uint64_t nwaves, uint64_t nspans)
+__device__ __forceinline__ MmSpanCursor mm_span_cursor(const A &, uint64_t wave, uint64_t nwaves, uint64_t nspans)
 {
    MmSpanCursor c;
-   c.round = 0; c.nwaves = nwaves; c.wave = wave; c.nspans = nspans;
-   c.ticket = nullptr; c.first = 0; c.end = 0; c.static_spans = nspans;
-   if (a.span_tickets) {
-      // the first static_rounds rounds as ever; what is left of the ROM is cut into 64 shares, one ticket counter each
-      const uint64_t fixed = (uint64_t)a.static_rounds * nwaves;
-      c.static_spans = fixed < nspans ? fixed : nspans;
-      const uint64_t rest = nspans - c.static_spans;
-      const uint32_t k = blockIdx.x & (MM_CAND_LISTS - 1);
-      const uint64_t per = (rest + MM_CAND_LISTS - 1) / MM_CAND_LISTS;
-      c.ticket = a.span_tickets + k * MM_LIST_STRIDE;
-      c.first = c.static_spans + k * per;
-      c.end = c.first + per < nspans ? c.first + per : nspans;
-   }
+   c.round = 0; c.nwaves = (uint32_t)nwaves; c.wave = (uint32_t)wave; c.nspans = (uint32_t)nspans;
    return c;
 }
 
 // the next span of this wave (wave uniform), false when there is none left
 __device__ __forceinline__ bool mm_next_span(MmSpanCursor &c, uint64_t *span)
 {
-   for (; c.round * c.nwaves < c.static_spans; c.round++) {
-      const uint64_t s = c.round * c.nwaves + (c.wave + c.round * 2731) % c.nwaves;
-      if (s < c.static_spans) {
+   for (; (uint64_t)c.round * c.nwaves < c.nspans; c.round++) {
+      const uint64_t s = (uint64_t)c.round * c.nwaves + (c.wave + c.round * 2731u) % c.nwaves;
+      if (s < c.nspans) {
          c.round++;
          *span = s;
          return true;
       }
-   }
-   if (c.ticket) {
-      unsigned long long t = 0;
-      if (__lane_id() == 0) {
-         t = atomicAdd(c.ticket, 1ull);
-      }
-      *span = c.first + mm_uniform64_k(t);
-      return *span < c.end;
    }
    return false;
 }
@@ -637,6 +706,22 @@ __device__ __forceinline__ void mm_edge_u8(const A &a, uint32_t block, uint32_t 
    }
 }
 
+// The four dwordx4 loads of one 4 KiB group: scalar base (the group's first byte: wave uniform, handed to the compiler as
+// two opaque SGPRs so that it cannot fold the lane's share into a loop-invariant 64-bit VGPR pointer) + the lane's 32-bit
+// byte offset -- global_load_dwordx4 v, v_offset, s[base] offset:k*1024.  With the pointer in VGPRs the 16-bit kernel
+// needed 73 registers (72 is where the seventh wave per SIMD fits) and an add of 64 bits per group.
+__device__ __forceinline__ void mm_load_group(uint4 (&w)[4], const uint8_t *rom, uint64_t group, uint32_t lane16)
+{
+   const uint64_t base = reinterpret_cast<uint64_t>(rom) + group * 4096;
+   uint32_t lo = (uint32_t)base, hi = (uint32_t)(base >> 32);
+   asm volatile("" : "+s"(lo), "+s"(hi));
+   const uint8_t *sb = reinterpret_cast<const uint8_t *>(((uint64_t)hi << 32) | lo);
+   w[0] = *reinterpret_cast<const uint4 *>(sb + lane16);
+   w[1] = *reinterpret_cast<const uint4 *>(sb + lane16 + 1024u);
+   w[2] = *reinterpret_cast<const uint4 *>(sb + lane16 + 2048u);
+   w[3] = *reinterpret_cast<const uint4 *>(sb + lane16 + 3072u);
+}
+
 // The hot kernel.  The ROM is cut into 4 KiB groups; a wave owns SPANS of
 // consecutive groups and streams through them, 4 x dwordx4 per lane per group
 // (each wave instruction = 1 KiB contiguous), with the loads of the next TWO
@@ -663,6 +748,11 @@ __device__ __forceinline__ void mm_stream_u8(const A &a)
 
    const uint64_t nspans = (a.ngroups + gps - 1) / gps;
    MmSpanCursor cursor = mm_span_cursor(a, wave, nwaves, nspans);
+   // the wave's survivor queue (bucketed scans only: see mm_queue_flush)
+   __shared__ MmSurvivorQueue Q;
+   if ((threadIdx.x & 63) == 0) {
+      Q.count[threadIdx.x >> 6] = 0;                               // (wave-private: no barrier)
+   }
    uint64_t span;
    while (mm_next_span(cursor, &span)) {
       const uint64_t g0 = span * gps;
@@ -672,8 +762,7 @@ __device__ __forceinline__ void mm_stream_u8(const A &a)
 #pragma unroll
       for (int d = 0; d < DEPTH; d++) {
          const uint64_t gg = g0 + d < g1 ? g0 + d : g1 - 1;
-         const uint4 *p = rom4 + gg * 256 + lane;
-         w[d][0] = p[0]; w[d][1] = p[64]; w[d][2] = p[128]; w[d][3] = p[192];
+         mm_load_group(w[d], a.t.g.rom, gg, lane * 16u);
       }
       for (uint64_t g = g0; g < g1; g += DEPTH + 1) {
          uint32_t pending = 0;                                  // bit 4*s + u: piece u of group g+s has stage-1 hits
@@ -683,8 +772,7 @@ __device__ __forceinline__ void mm_stream_u8(const A &a)
             constexpr int RING = DEPTH + 1;
             const int slot_new = (s + DEPTH) % RING;
             const uint64_t gn = g + s + DEPTH < g1 ? g + s + DEPTH : g1 - 1;
-            const uint4 *pn = rom4 + gn * 256 + lane;
-            w[slot_new][0] = pn[0]; w[slot_new][1] = pn[64]; w[slot_new][2] = pn[128]; w[slot_new][3] = pn[192];
+            mm_load_group(w[slot_new], a.t.g.rom, gn, lane * 16u);
             if (g + s < g1) {
 #pragma unroll
                for (int u = 0; u < 4; u++) {
@@ -709,9 +797,13 @@ __device__ __forceinline__ void mm_stream_u8(const A &a)
             const uint32_t back = byte0 ? *reinterpret_cast<const uint32_t *>(a.t.g.rom + byte0 - 4) : 0u;
             uint32_t h[4];
             if (__ballot(mm_f8_chunk<SHAPE>(wu, back, a.pat, a.sh, h) != 0) != 0) {
-               mm_f8_survivors(a, byte0, mm_f8_pack(h));
+               mm_f8_survivors(a, byte0, mm_f8_pack(h), a.bcount ? &Q : nullptr);
             }
          }
+      }
+      // the span's survivors to their buckets (the ring registers are dead here; a span without survivors: one LDS read)
+      if (a.bcount) {
+         mm_queue_flush(a, Q, a.iA);
       }
    }
 }
@@ -832,7 +924,7 @@ __device__ __forceinline__ uint32_t mm_f16_pack(const uint32_t (&he)[4], const u
 }
 
 template <class A>
-__device__ __forceinline__ void mm_f16_survivors(const A &a, uint64_t chunk0, uint32_t bits)
+__device__ __forceinline__ void mm_f16_survivors(const A &a, uint64_t chunk0, uint32_t bits, MmSurvivorQueue *Q = nullptr)
 {
    if (a.bcount) {
       // bucketed store (see mm_f8_survivors).  The odd stream's first position of a chunk starts one byte in front of it,
@@ -851,6 +943,25 @@ __device__ __forceinline__ void mm_f16_survivors(const A &a, uint64_t chunk0, ui
             }
          }
          bits = keep;
+      }
+      if (Q) {
+         uint32_t total;
+         uint32_t at = mm_wave_prefix((uint32_t)__popc(bits), &total);
+         if (total == 0) {
+            return;
+         }
+         const int w = mm_queue_wave();
+         const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)Q->count[w]);
+         if (len + total <= MM_QCAP) {
+            at += len;
+            while (bits) {
+               const int bit = __ffs((int)bits) - 1;
+               bits &= bits - 1;
+               Q->entry[w][at++] = (uint64_t)offset_of(bit);
+            }
+            Q->count[w] = len + total;
+            return;
+         }
       }
       uint32_t slot, room;
       uint64_t *list = mm_bucket_reserve(a, mm_uniform64_k(chunk0), (uint32_t)__popc(bits), &slot, &room);
@@ -945,6 +1056,10 @@ __device__ __forceinline__ void mm_stream_u16(const A &a)
 
    const uint64_t nspans = (a.ngroups + gps - 1) / gps;
    MmSpanCursor cursor = mm_span_cursor(a, wave, nwaves, nspans);
+   __shared__ MmSurvivorQueue Q;                                   // the waves' survivor queues (mm_queue_flush)
+   if ((threadIdx.x & 63) == 0) {
+      Q.count[threadIdx.x >> 6] = 0;
+   }
    uint64_t span;
    while (mm_next_span(cursor, &span)) {
       const uint64_t g0 = span * gps;
@@ -958,8 +1073,7 @@ __device__ __forceinline__ void mm_stream_u16(const A &a)
 #pragma unroll
       for (int d = 0; d < DEPTH; d++) {
          const uint64_t gg = g0 + d < g1 ? g0 + d : g1 - 1;
-         const uint4 *p = rom4 + gg * 256 + lane;
-         w[d][0] = p[0]; w[d][1] = p[64]; w[d][2] = p[128]; w[d][3] = p[192];
+         mm_load_group(w[d], a.t.g.rom, gg, lane * 16u);
       }
       uint32_t flagged = 0;                                     // bit 4*(g - g0) + u: piece u of group g has stage-1 hits
       for (uint64_t g = g0; g < g1; g += DEPTH + 1) {
@@ -968,8 +1082,7 @@ __device__ __forceinline__ void mm_stream_u16(const A &a)
             constexpr int RING = DEPTH + 1;
             const int slot_new = (s + DEPTH) % RING;
             const uint64_t gn = g + s + DEPTH < g1 ? g + s + DEPTH : g1 - 1;
-            const uint4 *pn = rom4 + gn * 256 + lane;
-            w[slot_new][0] = pn[0]; w[slot_new][1] = pn[64]; w[slot_new][2] = pn[128]; w[slot_new][3] = pn[192];
+            mm_load_group(w[slot_new], a.t.g.rom, gn, lane * 16u);
             if (g + s < g1) {
                const uint32_t first_bit = 4u * (uint32_t)(g + s - g0);
 #pragma unroll
@@ -1009,8 +1122,11 @@ __device__ __forceinline__ void mm_stream_u16(const A &a)
          }
          uint32_t he[4], ho[4];
          if (__ballot(mm_f16_chunk<SHAPE>(r, be, a.pat, he, ho) != 0) != 0) {
-            mm_f16_survivors(a, c * 16, mm_f16_pack(he, ho));
+            mm_f16_survivors(a, c * 16, mm_f16_pack(he, ho), a.bcount ? &Q : nullptr);
          }
+      }
+      if (a.bcount) {
+         mm_queue_flush(a, Q, 2 * a.iA);
       }
    }
 }
@@ -1538,8 +1654,6 @@ static void fill_filter_args(A &a, const MmGeom &g, const mmh_plan_desc &pl, con
    a.dom_count = nullptr; a.skip_bits = nullptr;
    a.loud_bits = nullptr; a.loud_tpd = 0; a.loud_tile = 1;
    a.bcand = nullptr; a.bcount = nullptr; a.boverflow = nullptr; a.bshift = 0;
-   a.span_tickets = nullptr;
-   a.static_rounds = 0;
    // whole 4 KiB groups go to the span code, the ragged end to the bounds-checked one
    a.ngroups = g.nbytes / 4096;
    a.groups_per_span = groups_per_span;
@@ -1708,17 +1822,6 @@ static void fill_bucket_args(A &a, const MmGeom &g, const ResolveBuffers &rb)
    a.boverflow = rb.ctrl + MM_CTRL_BOVERFLOW; a.bshift = b.shift;
 }
 
-// MMOORE_SPAN_TICKETS=p: the last p percent of a bucketed scan's spans are drawn through tickets instead of being
-// dealt out round by round (development knob; 0 / unset = all static).  Tickets for ALL spans were measured and are
-// worse: the ticket's round trip at every span boundary and the loss of "neighbouring waves stream neighbouring spans"
-// cost more than the balance gains -- streaming kernel alone 0.742 ms per 4 GiB against 0.705 static, scans in flight
-// 0.775 against 0.69 (profiles/r03_lane_gate_and_span_tickets.log).
-static int span_ticket_percent()
-{
-   static const int p = [] { const char *e = getenv("MMOORE_SPAN_TICKETS"); return e && *e ? std::min(100, std::max(0, atoi(e))) : 0; }();
-   return p;
-}
-
 void launch_filter_buckets(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc, const ResolveBuffers &rb,
                            hipEvent_t start, hipEvent_t stop)
 {
@@ -1729,15 +1832,6 @@ void launch_filter_buckets(hipStream_t st, const MmGeom &g, const mmh_plan_desc 
    }
    fill_filter_args(a, g, pl, fc, rb.cand, rb.ctrl, rb.cand_cap, gps);
    fill_bucket_args(a, g, rb);
-   // (the 64 list counters of the control block are idle in a bucketed scan: they hand out the spans)
-   if (span_ticket_percent() > 0) {
-      const uint64_t nspans = (a.ngroups + gps - 1) / gps;
-      uint64_t spans = (nspans + 3) / 4;
-      const uint64_t nwaves = std::min<uint64_t>(spans, filter_max_blocks()) * 4;
-      const uint64_t rounds = (nspans + nwaves - 1) / nwaves;
-      a.span_tickets = rb.ctrl + MM_CTRL_LISTS;
-      a.static_rounds = (uint32_t)(rounds * (100 - span_ticket_percent()) / 100);
-   }
    with_shape(pl.elem_bytes, fc, [&](auto elem, auto shape) {
       constexpr int SHAPE = decltype(shape)::value;
       if constexpr (decltype(elem)::value == 1) {
