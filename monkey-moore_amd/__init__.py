@@ -342,7 +342,16 @@ class Engine:
                 continue
             if rc != MMH_OK:
                 _check(rc)
-            return out[: self._count.value].copy()
+            return self._take(out)
+
+    def _take(self, out):
+        """The call's offsets: a copy of the reusable buffer's head -- or, for a long list, the buffer itself (the next
+        call gets a new one: copying 100 MB a second time costs more than the allocation)."""
+        n = self._count.value
+        if n > (1 << 18):
+            self._out = None
+            return out[:n]
+        return out[:n].copy()
 
     def submit(self, plan, block_bytes=0, big_endian=False, base_offset=0):
         """Enqueue a scan (at most MMH_MAX_IN_FLIGHT = 3 outstanding); returns the ticket for collect()."""
@@ -360,7 +369,7 @@ class Engine:
                 continue
             if rc != MMH_OK:
                 _check(rc)
-            return out[: self._count.value].copy()
+            return self._take(out)
 
     # -- multi-GPU ------------------------------------------------------
     def comm_init_rank(self, unique_id, nranks, rank):

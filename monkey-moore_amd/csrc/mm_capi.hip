@@ -13,6 +13,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -357,6 +358,10 @@ extern "C" void mmh_destroy(mmh_ctx *c)
    if (c->d_domains) (void)hipFree(c->d_domains);
    if (c->d_sort_out) (void)hipFree(c->d_sort_out);
    if (c->d_sort_tmp) (void)hipFree(c->d_sort_tmp);
+   for (int k = 0; k < 2; k++) {
+      if (c->h_ring[k]) (void)hipHostFree(c->h_ring[k]);
+      if (c->ring_ev[k]) (void)hipEventDestroy(c->ring_ev[k]);
+   }
    for (auto &triple : c->ring) {
       for (auto &e : triple) {
          if (e) (void)hipEventDestroy(e);
@@ -933,18 +938,8 @@ int finish_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev, 
          oc->candidates = w.h_result[0];
          const bool leftovers = (w.h_result[5] & 0xFFFFFFFFu) != 0;
          const bool direct = !(flags & 4);
-         if (!direct && !leftovers && oc->candidates != 0) {
-            // a long list: the slots were only written to the device-side copy of the block (a PCIe write per slot
-            // would take longer than the scan): one copy brings them over.  On the context's own stream, behind the
-            // tail kernel's end event (the flag word shows before the kernel has retired and its stores are visible to
-            // a copy engine) -- NOT on the scan's stream: with scans in flight the next scan's streaming kernel is
-            // already queued there, and waiting for the copy would mean waiting for that scan (measured: C4 / C5,
-            // 8.2 - 8.5 K candidates, ran one scan at a time with three tickets outstanding).
-            HIP_TRY(hipStreamWaitEvent(c->own_stream, ev[2], 0));
-            HIP_TRY(hipMemcpyAsync(w.h_result + kHeaderWords, w.d_result[w.result_turn] + kHeaderWords, oc->candidates * sizeof(uint64_t),
-                                   hipMemcpyDeviceToHost, c->own_stream));
-            HIP_TRY(hipStreamSynchronize(c->own_stream));
-         }
+         // (a long list without left-overs: mm_publish_long has copied the slots to pinned memory before it raised the
+         // flag -- round 3 fetched them here with a DMA copy on the context's own stream, 60 us per scan)
          note_dirty_slots(w, oc->candidates);
          oc->listed = oc->candidates;
          oc->tiles = w.h_result[2];
@@ -1074,13 +1069,9 @@ int grow(uint64_t **buf, uint64_t *cap, uint64_t need)
    return MMH_OK;
 }
 
-// n keys in device memory -> ascending in host memory, "not a match" slots (~0) dropped
-int sort_to_host(mmh_ctx *c, const uint64_t *keys, uint64_t n, std::vector<uint64_t> *sorted)
+// n keys in device memory -> ascending in c->d_sort_out ("not a match" slots, ~0, end up behind the matches)
+int sort_on_device(mmh_ctx *c, const uint64_t *keys, uint64_t n)
 {
-   sorted->clear();
-   if (n == 0) {
-      return MMH_OK;
-   }
    int rc = grow(&c->d_sort_out, &c->sort_out_cap, n);
    if (rc != MMH_OK) {
       return rc;
@@ -1096,21 +1087,96 @@ int sort_to_host(mmh_ctx *c, const uint64_t *keys, uint64_t n, std::vector<uint6
       c->sort_tmp_bytes = tmp + tmp / 4;
    }
    HIP_TRY(mm::sort_keys(c->stream, keys, c->d_sort_out, n, c->d_sort_tmp, c->sort_tmp_bytes));
-   sorted->resize(n);
-   HIP_TRY(hipMemcpyAsync(sorted->data(), c->d_sort_out, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+   return MMH_OK;
+}
+
+// An ascending device list of n keys (holes behind the matches) to the caller: through a ring of two pinned pieces, the
+// DMA of piece k + 1 under way while the CPU copies piece k to its place -- 8-10 GB/s, bound by that copy.  (Round 3 let
+// hipMemcpyAsync write straight into a freshly value-initialised std::vector, pageable memory: 134 MB of offsets reached the
+// caller at 1.6 GB/s, through three passes over them.)  dst may be null or too small: then the keys are only counted.
+// *matches = keys in front of the first hole.
+int fetch_device_list(mmh_ctx *c, const uint64_t *d_list, uint64_t n, uint64_t *dst, uint64_t cap, uint64_t *matches)
+{
+   constexpr uint64_t kPiece = 1u << 20;                     // keys per piece: 8 MiB
+   *matches = 0;
+   if (n == 0) {
+      return MMH_OK;
+   }
+   for (int k = 0; k < 2; k++) {
+      if (!c->h_ring[k]) {
+         HIP_TRY(hipHostMalloc(&c->h_ring[k], kPiece * sizeof(uint64_t), hipHostMallocDefault));
+         HIP_TRY(hipEventCreateWithFlags(&c->ring_ev[k], hipEventDisableTiming));
+      }
+   }
+   const uint64_t pieces = (n + kPiece - 1) / kPiece;
+   auto issue = [&](uint64_t k) -> hipError_t {
+      const uint64_t len = std::min(kPiece, n - k * kPiece);
+      hipError_t e = hipMemcpyAsync(c->h_ring[k & 1], d_list + k * kPiece, len * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream);
+      return e != hipSuccess ? e : hipEventRecord(c->ring_ev[k & 1], c->stream);
+   };
+   HIP_TRY(issue(0));
+   uint64_t kept = 0;
+   bool holes = false;
+   for (uint64_t k = 0; k < pieces; k++) {
+      HIP_TRY(hipEventSynchronize(c->ring_ev[k & 1]));
+      if (k + 1 < pieces && !holes) {
+         HIP_TRY(issue(k + 1));
+      }
+      const uint64_t len = std::min(kPiece, n - k * kPiece);
+      const uint64_t *src = static_cast<const uint64_t *>(c->h_ring[k & 1]);
+      uint64_t valid = len;
+      if (src[len - 1] == ~0ull) {
+         valid = (uint64_t)(std::lower_bound(src, src + len, ~0ull) - src);
+         holes = true;
+      }
+      if (dst && kept + valid <= cap) {
+         std::memcpy(dst + kept, src, valid * sizeof(uint64_t));
+      }
+      kept += valid;
+      if (holes) {
+         break;                                               // (everything behind the first hole is holes)
+      }
+   }
    HIP_TRY(hipStreamSynchronize(c->stream));
-   sorted->erase(std::lower_bound(sorted->begin(), sorted->end(), ~0ull), sorted->end());
+   *matches = kept;
+   return MMH_OK;
+}
+
+// n keys in device memory -> ascending in host memory, "not a match" slots (~0) dropped
+int sort_to_host(mmh_ctx *c, const uint64_t *keys, uint64_t n, std::vector<uint64_t> *sorted)
+{
+   sorted->clear();
+   if (n == 0) {
+      return MMH_OK;
+   }
+   int rc = sort_on_device(c, keys, n);
+   if (rc != MMH_OK) {
+      return rc;
+   }
+   sorted->resize(n);
+   uint64_t matches = 0;
+   rc = fetch_device_list(c, c->d_sort_out, n, sorted->data(), n, &matches);
+   if (rc != MMH_OK) {
+      return rc;
+   }
+   sorted->resize(matches);
    return MMH_OK;
 }
 
 // The candidate-free forward engine (mm_forward.h).  Matches land in MM_CAND_LISTS device
 // lists; they are fetched and ordered on the host (dense results are long lists anyway).
+// found == nullptr: the list stays on the device, ordered, in c->d_sort_out; *device_n = its length incl. nothing but matches
 int run_dense(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, uint64_t base_offset, std::vector<uint64_t> *found,
-              bool *grew, const uint32_t *dom_list = nullptr, uint64_t listed_domains = 0)
+              bool *grew, const uint32_t *dom_list = nullptr, uint64_t listed_domains = 0, uint64_t *device_n = nullptr)
 {
    hipStream_t st = c->stream;
    *grew = false;
-   found->clear();
+   if (found) {
+      found->clear();
+   }
+   if (device_n) {
+      *device_n = 0;
+   }
    const mm::DenseGeom dg = mm::dense_geom(g, listed_domains);
    if (dg.tpd == 0) {
       return MMH_OK;                              // no alignment fits anywhere
@@ -1170,6 +1236,10 @@ int run_dense(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, uint64_t bas
       return MMH_OK;
    }
    // order them the way search_engine.cpp:193-197 does -- on the device
+   if (!found) {
+      *device_n = total;
+      return total ? sort_on_device(c, c->d_sort_in, total) : MMH_OK;
+   }
    return sort_to_host(c, c->d_sort_in, total, found);
 }
 
@@ -1425,6 +1495,27 @@ int check_scan_args(const mmh_ctx *c, const mmh_plan_desc *plan, const char *who
    return MMH_OK;
 }
 
+// identifies a search on this context: plan, block size, byte order, ROM (FNV-1a; 0 is never returned)
+uint64_t search_key(const mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian)
+{
+   uint64_t h = 1469598103934665603ull;
+   auto mix = [&](const void *p, size_t n) {
+      const unsigned char *b = static_cast<const unsigned char *>(p);
+      for (size_t i = 0; i < n; i++) {
+         h = (h ^ b[i]) * 1099511628211ull;
+      }
+   };
+   // (the plan's used part: header + L entries of each table)
+   mix(plan, offsetof(mmh_plan_desc, expected));
+   mix(plan->expected, plan->L * sizeof(int32_t));
+   mix(plan->cmp_mask, plan->L * sizeof(uint32_t));
+   mix(plan->bridge, plan->L);
+   mix(plan->wst, plan->L);
+   const uint64_t more[4] = {block_bytes, (uint64_t)(big_endian != 0), (uint64_t)reinterpret_cast<uintptr_t>(c->rom), c->rom_bytes};
+   mix(more, sizeof more);
+   return h ? h : 1;
+}
+
 MmGeom scan_geometry(const mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian)
 {
    MmGeom g;
@@ -1500,11 +1591,13 @@ int scan_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int b
    Outcome oc;
    std::vector<uint64_t> long_list;
    bool host_list = false, flagged_domains = false, flooded_domains = false;
+   bool device_list = false;                      // the result sits ordered in c->d_sort_out (forward engine, radix sort)
+   uint64_t device_list_n = 0;
    bool settled = false;                          // the loop ended with a complete result (not by running out of attempts)
    for (int attempt = 0; attempt < 6 && !settled; attempt++) {
       if (mode == DENSE) {
          bool grew = false;
-         rc = run_dense(c, g, *plan, base_offset, &long_list, &grew);
+         rc = run_dense(c, g, *plan, base_offset, nullptr, &grew, nullptr, 0, &device_list_n);
          if (rc != MMH_OK) {
             return rc;
          }
@@ -1512,7 +1605,7 @@ int scan_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int b
             continue;
          }
          oc = Outcome();
-         oc.matches = long_list.size();
+         device_list = true;                      // (ordered in c->d_sort_out: fetched straight into the caller's buffer below)
          host_list = true;
          settled = true;
          break;
@@ -1581,17 +1674,50 @@ int scan_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int b
    // lists too long for the rank kernels: radix sort on the device, "not a match" slots dropped
    // (search_engine.cpp:193-197 does a std::sort)
    if (!host_list && !oc.sorted_on_device) {
-      rc = sort_to_host(c, c->ws[0].d_out, oc.listed, &long_list);
+      rc = oc.listed ? sort_on_device(c, c->ws[0].d_out, oc.listed) : MMH_OK;
       if (rc != MMH_OK) {
          return rc;
       }
-      oc.matches = long_list.size();
+      device_list = true;
+      device_list_n = oc.listed;
       host_list = true;
+   }
+   if (device_list) {
+      // device -> the caller's buffer, no host list in between (a communicator may ask for the list later: then it is kept)
+      rc = fetch_device_list(c, c->d_sort_out, device_list_n, out, cap, &oc.matches);
+      if (rc != MMH_OK) {
+         return rc;
+      }
+      if (c->mg.comm) {
+         if (oc.matches <= cap) {
+            long_list.assign(out, out + oc.matches);
+         }
+         else {
+            // (the caller's buffer is too small and it will scan again -- but a gather started right now must still
+            // find this scan's list)
+            long_list.resize(oc.matches);
+            uint64_t again = 0;
+            rc = fetch_device_list(c, c->d_sort_out, device_list_n, long_list.data(), long_list.size(), &again);
+            if (rc != MMH_OK) {
+               return rc;
+            }
+         }
+      }
    }
    c->counters[0] = oc.candidates == ~0ull ? 0 : oc.candidates;   // (~0: "a candidate list overflowed" of a pass that was abandoned)
    c->counters[1] = oc.matches;
    c->counters[2] = oc.tiles;
    c->counters[3] = mode == SEQUENTIAL ? 1 : (mode == DENSE ? 3 : (flooded_domains ? 5 : (flagged_domains ? 4 : (oc.hard ? 2 : 0))));
+   if (c->engine == 0) {
+      // (what mmh_scan_submit goes by: this search ended on the forward engine / a flood path -- or no longer does)
+      const uint64_t key = search_key(c, plan, block_bytes, big_endian);
+      if (c->counters[3] >= 3) {
+         c->flood_key = key;
+      }
+      else if (c->flood_key == key) {
+         c->flood_key = 0;
+      }
+   }
 
    *out_count = oc.matches;
    *on_device = !host_list;
@@ -1601,7 +1727,7 @@ int scan_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int b
                     (unsigned long long)oc.matches, (unsigned long long)cap);
       rc = MMH_E_CAPACITY;
    }
-   else if (oc.matches != 0) {
+   else if (oc.matches != 0 && !device_list) {
       std::memcpy(out, host_list ? long_list.data() : c->ws[0].h_result + kHeaderWords, oc.matches * sizeof(uint64_t));
    }
    if (host_list) {
@@ -1746,7 +1872,8 @@ extern "C" int mmh_scan_submit(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t b
    const MmGeom g = scan_geometry(c, plan, block_bytes, big_endian);
    mm::FilterChoice fc;
    const bool have_filter = mm::choose_filter(*plan, &fc);
-   if (c->engine != 0 || !have_filter || g.nbytes == 0 || plan->L > MM_RESOLVER_MAX_KEYWORD) {
+   if (c->engine != 0 || !have_filter || g.nbytes == 0 || plan->L > MM_RESOLVER_MAX_KEYWORD ||
+       (c->flood_key != 0 && c->flood_key == search_key(c, plan, block_bytes, big_endian))) {
       p.needs_rescan = true;                    // collect runs mmh_scan
    }
    else {

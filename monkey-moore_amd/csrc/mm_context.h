@@ -171,6 +171,8 @@ struct mmh_ctx {
    uint64_t sort_out_cap = 0;
    void *d_sort_tmp = nullptr;
    size_t sort_tmp_bytes = 0;
+   void *h_ring[2] = {nullptr, nullptr};   // pinned pieces long device lists travel through (fetch_device_list, mm_capi.hip)
+   hipEvent_t ring_ev[2] = {nullptr, nullptr};
 
    // Ring of event triples {scan start, behind the streaming kernel, scan end}: elapsed
    // times are only computed when somebody asks (mmh_last_timings / mmh_timing_history),
@@ -199,6 +201,10 @@ struct mmh_ctx {
    MmPending pending[kLanes];
    int next_ticket = 0;
    int engine = 0;
+   // What the last synchronous scan that went to the forward engine or a flood path (counters[3] >= 3) looked like: a
+   // ticket submitted for the same search is not put on a lane at all -- its streaming + tail kernels would be thrown
+   // away and collect would scan again synchronously (round 3 measured floods SLOWER in flight than one at a time).
+   uint64_t flood_key = 0;
    bool fused_ok = true;            // cleared for good when a fused scan's grid barrier ever timed out on this context
    uint32_t route_off = 0;          // MMH_ROUTE_* bits switched off on this context (mmh_set_route); the process-wide ones come on top
    MmHealth health;
