@@ -322,6 +322,7 @@ class Engine:
     def _result_buffer(self, cap):
         # one result buffer reused from scan to scan; its ctypes pointer is cached (ndarray.ctypes
         # builds a new object on every access, which costs more than the call itself)
+        cap = max(cap, getattr(self, "_long", 0))            # (a long list was handed out last time: room for one like it)
         out = getattr(self, "_out", None)
         if out is None or out.size < cap:
             out = self._out = np.empty(cap, np.uint64)
@@ -350,7 +351,9 @@ class Engine:
         n = self._count.value
         if n > (1 << 18):
             self._out = None
+            self._long = n + 16
             return out[:n]
+        self._long = 0
         return out[:n].copy()
 
     def submit(self, plan, block_bytes=0, big_endian=False, base_offset=0):

@@ -92,6 +92,12 @@ struct MmForwardArgs {
    uint32_t loud_pat[2];     // expected deltas, replicated over the bytes of a dword
    uint32_t loud_sh1;        // v_alignbit amount of condition 1
    uint32_t chunk;           // consecutive batches per ticket (a workgroup's block)
+   // 16-bit elements, plain keywords (round 4, mm_fwd_exceptional16): a position jumps the default L - 1 -- and so keeps
+   // the chain in its phase -- unless the delta of its first compare is one of the <= L listed ones; a tile without such a
+   // position maps every phase onto itself and reports nothing, and is never staged.  quiet16: the test applies;
+   // q16_bloom: three 32-bit filters on bits 0-4, 5-9 and 10-14 of the delta (a listed delta passes all three).
+   uint32_t quiet16;
+   uint32_t q16_bloom[3];
 };
 
 struct MmFwdTables {
@@ -507,6 +513,98 @@ __device__ __forceinline__ uint32_t mm_fwd_loud_mask(const MmForwardArgs &a, uin
    }
 }
 
+// 16-bit elements, plain keywords.  A 16-bit delta is practically never in the skip table (<= L entries among 131071
+// values), so nearly every position jumps the default L - 1: its chain stays in its phase, a tile's map is the identity and
+// there is nothing for the sparse sweep to settle (maps never turn constant) -- round 3 mapped every tile on the general
+// jump path, 3.9 ms per GiB.  But an identity map needs no mapping: the tiles among [t0, ...) that hold an EXCEPTIONAL
+// position -- one whose first compare's delta x[h + i1] - x[h + i1 - 1] is listed (a shorter jump, or the compare holds
+// and the loop goes on) -- are found from the bytes alone, 4 KiB per wave and step straight from global memory: both
+// elements of a dword against three 32-bit filters (11 VALU operations per element), what passes (1.6 % with 8 listed
+// deltas) against the list itself from bytes loaded again.  Returns bit k set when tile t0 + k holds such a position; the
+// others are quiet: identity map, no report, never staged.  Positions [lo0, lo1) of the domain at `start`.  Wave uniform.
+__device__ __forceinline__ uint32_t mm_fwd_exceptional16(const MmForwardArgs &a, const MmPlanLds &P, uint64_t start, int64_t lo0, int64_t lo1,
+                                                          int lane)
+{
+   const MmGeom &g = a.t.g;
+   const bool be = g.big_endian != 0;
+   const int64_t i1 = (int64_t)a.i1;
+   const uint32_t odd = (uint32_t)(start & 1);
+   const uint64_t first = start + 2 * (uint64_t)(lo0 + i1);               // the compared element of position lo0 ...
+   const uint64_t last = start + 2 * (uint64_t)(lo1 - 1 + i1);            // ... and of the last position
+   const uint32_t b0 = a.q16_bloom[0], b1 = a.q16_bloom[1], b2 = a.q16_bloom[2];
+   const uint32_t all = (uint32_t)(((lo1 - 1 - lo0) / MM_FWD_TILE) + 1);   // tiles asked about
+   const uint32_t full = all >= 32 ? 0xFFFFFFFFu : (1u << all) - 1u;
+   uint32_t mask = 0;
+   // a lane's 64 bytes at byte0 hold the 32 elements at byte0 - odd + 2 k
+   for (uint64_t piece = (first + odd) & ~(uint64_t)4095; piece <= last + odd && mask != full; piece += 4096) {
+      const uint64_t byte0 = piece + 64u * (uint32_t)lane;
+      uint32_t prev = byte0 >= 4 && byte0 <= g.nbytes ? *reinterpret_cast<const uint32_t *>(g.rom + byte0 - 4) : 0u;
+      // the element in front of the lane's first one: bytes byte0 - 2, byte0 - 1 (even) / byte0 - 3, byte0 - 2 (odd)
+      uint32_t pe = odd ? (prev >> 8) & 0xFFFFu : prev >> 16;
+      pe = be ? ((pe >> 8) | (pe << 8)) & 0xFFFFu : pe;
+      uint32_t pass = 0;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+         const uint4 w4 = mm_load_chunk(g.rom, g.nbytes, byte0 + 16u * (uint32_t)q);
+         const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+         for (int j = 0; j < 4; j++) {
+            uint32_t pair = odd ? mm_alignbit(w[j], prev, 24) : w[j];       // two elements: low half first
+            pair = be ? mm_bswap16x2(pair) : pair;
+            prev = w[j];
+            const uint32_t lo = pair & 0xFFFFu, hi = pair >> 16;
+            const uint32_t d0 = lo - pe, d1 = hi - lo;                      // (two's complement: the filters were built that way)
+            pe = hi;
+            const uint32_t t0 = (b0 >> (d0 & 31)) & (b1 >> ((d0 >> 5) & 31)) & (b2 >> ((d0 >> 10) & 31)) & 1u;
+            const uint32_t t1 = (b0 >> (d1 & 31)) & (b1 >> ((d1 >> 5) & 31)) & (b2 >> ((d1 >> 10) & 31)) & 1u;
+            pass |= (t0 | (t1 << 1)) << (2 * (4 * q + j));
+         }
+      }
+      const unsigned long long crowd = __ballot(pass != 0);
+      if (crowd == 0) {
+         continue;
+      }
+      const uint64_t e0 = piece > first + odd ? piece - odd : first, e1 = piece + 4095 - odd < last ? piece + 4095 - odd : last;
+      if (__popcll(crowd) > 40) {
+         // hits all over the step (low-entropy data, a flood): its tiles are exceptional, no questions asked
+         const uint32_t k0 = (uint32_t)((e0 - first) / 2) / MM_FWD_TILE, k1 = (uint32_t)((e1 - first) / 2) / MM_FWD_TILE;
+         mask |= ((k1 >= 31 ? 0u : (2u << k1)) - (1u << k0)) & full;
+         continue;
+      }
+      // what passed the filters against the list itself (rare: from bytes loaded again -- indexing the 16 dwords above
+      // with a run-time number would move them to scratch)
+      uint32_t mine = 0;
+      const int n = (int)a.t.plan.n_skip;
+      while (pass) {
+         const int bit = __ffs((int)pass) - 1;
+         pass &= pass - 1;
+         const uint64_t u = byte0 - odd + 2u * (uint32_t)bit;              // the element's first byte
+         if (u < first || u > last) {
+            continue;
+         }
+         const int64_t m = (int64_t)((u - start) >> 1);                    // its number in the domain
+         const uint32_t tbit = 1u << ((uint32_t)(m - i1 - lo0) / MM_FWD_TILE);
+         if ((mask | mine) & tbit) {
+            continue;
+         }
+         const int d = mm_elem(g, start, m) - mm_elem(g, start, m - 1);
+         bool listed = d == P.expected[i1];
+         for (int k = 0; k < n; k++) {
+            listed = listed || P.skip_diff[k] == d;
+         }
+         mine |= listed ? tbit : 0u;
+      }
+      if (__ballot(mine != 0) != 0) {
+#pragma unroll
+         for (int d = 1; d < 64; d <<= 1) {
+            mine |= (uint32_t)__shfl_xor((int)mine, d);
+         }
+         mask |= (uint32_t)__builtin_amdgcn_readfirstlane((int)mine);
+      }
+   }
+   return mask & full;
+}
+
 // the look-back word of batch b, once it is non-zero (wave uniform)
 __device__ __forceinline__ unsigned long long mm_fwd_wait(const unsigned long long *status, uint64_t b, int lane)
 {
@@ -638,6 +736,24 @@ __global__ __launch_bounds__(64 * MM_WAVES) __attribute__((amdgpu_waves_per_eu(E
          const uint64_t two = (uint64_t)a.loud[bit0 >> 5] | ((uint64_t)a.loud[(bit0 >> 5) + 1] << 32);
          loud = (uint32_t)(two >> (bit0 & 31)) & ((2u << (tl - (int)t0)) - 1u);
          loud = (uint32_t)__builtin_amdgcn_readfirstlane((int)loud);
+      }
+      if (ELEM == 2 && a.quiet16 && !sweep && tl >= (int)t0) {
+         // plain 16-bit keyword: the batch's quiet tiles (no position with a listed delta) map every phase onto itself and
+         // report nothing -- only the others are staged and mapped below
+         const int64_t lo1 = (int64_t)(tl + 1) * MM_FWD_TILE;
+         const uint32_t exceptional = mm_fwd_exceptional16(a, P, start, (int64_t)t0 * MM_FWD_TILE, lo1 < nv ? lo1 : nv, lane);
+         const uint32_t quiet = ~exceptional & ((2u << (tl - (int)t0)) - 1u);
+         for (uint32_t rest = quiet; rest; rest &= rest - 1) {
+            const int k = __ffs((int)rest) - 1;
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+               if (lane + 64 * h < MAXD) {
+                  tilemap[wave][k][lane + 64 * h] = (uint8_t)(lane + 64 * h);
+               }
+            }
+         }
+         have |= quiet;
+         mm_wave_sync();
       }
       bool need_ex = sweep, need_tg = false;
       uint32_t target = 0;

@@ -2007,6 +2007,25 @@ static void launch_forward(hipStream_t st, const MmGeom &g, const mmh_plan_desc 
       capped = capped || pl.wst[i] != 255;
    }
    const bool prepass = sweeps && !a.fast && capped && !dom_list && dg.loud_bytes != 0;
+   // plain 16-bit keywords: quiet tiles (every jump the default one) are recognised from their bytes and never mapped
+   // (mm_fwd_exceptional16): the first compare must be against the left neighbour, on the signed path, no capped jumps
+   a.quiet16 = 0;
+   a.q16_bloom[0] = a.q16_bloom[1] = a.q16_bloom[2] = 0;
+   if (pl.elem_bytes == 2 && !a.fast && !capped && i1 >= 1 && pl.bridge[i1] == -1 && pl.cmp_mask[i1] == 0xFFFFFFFFu &&
+       pl.default_skip == (int32_t)pl.L - 1 && !(getenv("MMOORE_FORWARD_QUIET16") && *getenv("MMOORE_FORWARD_QUIET16") == '0')) {
+      a.quiet16 = 1;
+      a.i1 = (uint32_t)i1;
+      auto add = [&](int32_t d) {
+         const uint32_t x = (uint32_t)d;
+         a.q16_bloom[0] |= 1u << (x & 31);
+         a.q16_bloom[1] |= 1u << ((x >> 5) & 31);
+         a.q16_bloom[2] |= 1u << ((x >> 10) & 31);
+      };
+      add(pl.expected[i1]);
+      for (uint32_t k = 0; k < pl.n_skip; k++) {
+         add(pl.skip_diff[k]);
+      }
+   }
    {
       // A workgroup's block of batches (mm_forward.h): four -- one per wave, as round 2 handed them out.  Bigger blocks are
       // slower, and badly so (1 GiB, wildcard keyword: 4 / 8 / 16 / 32 batches -> 0.31 / 0.67 / 0.94 / 1.19 ms): the
