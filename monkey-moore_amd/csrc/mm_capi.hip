@@ -1585,6 +1585,17 @@ int scan_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int b
    // (keywords beyond 32 symbols: the resolvers' phase sets do not hold their D > 31 phases)
    const bool narrow = plan->L <= MM_RESOLVER_MAX_KEYWORD;
    enum { FAST, SEQUENTIAL, DENSE } mode = c->engine == 1 ? SEQUENTIAL : (c->engine == 2 || !have_filter || !narrow) ? DENSE : FAST;
+   // A search that ended on the forward engine or a flood path last time goes to the forward engine at once (the passes
+   // that found the flood out -- bucketed scan, list-based scan, count pass, filtered pass: 3-4 times over the ROM -- cost
+   // more than the engine itself where its sweep works: 'the' on a ROM with 3 % of script, 6.2 -> ~2.5 ms per 4 GiB).
+   // Every 16th such scan takes the candidate path again: the ROM behind the pointer may have changed.
+   const uint64_t key = c->engine == 0 ? search_key(c, plan, block_bytes, big_endian) : 0;
+   bool hinted = false;
+   static const bool hints = [] { const char *e = getenv("MMOORE_FLOOD_HINT"); return !(e && *e == '0'); }();   // (tests: every scan takes the candidate path first)
+   if (hints && mode == FAST && key != 0 && c->flood_key == key && (++c->flood_uses & 15u) != 0) {
+      mode = DENSE;
+      hinted = true;
+   }
    const uint32_t scan_limit = candidate_limit(c->ws[0]);
    uint32_t max_candidates = scan_limit;
 
@@ -1709,15 +1720,19 @@ int scan_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int b
    c->counters[2] = oc.tiles;
    c->counters[3] = mode == SEQUENTIAL ? 1 : (mode == DENSE ? 3 : (flooded_domains ? 5 : (flagged_domains ? 4 : (oc.hard ? 2 : 0))));
    if (c->engine == 0) {
-      // (what mmh_scan_submit goes by: this search ended on the forward engine / a flood path -- or no longer does)
-      const uint64_t key = search_key(c, plan, block_bytes, big_endian);
+      // (what mmh_scan_submit and the hint above go by: this search ended on the forward engine / a flood path -- or no
+      // longer does)
       if (c->counters[3] >= 3) {
+         if (c->flood_key != key) {
+            c->flood_uses = 0;
+         }
          c->flood_key = key;
       }
       else if (c->flood_key == key) {
          c->flood_key = 0;
       }
    }
+   (void)hinted;
 
    *out_count = oc.matches;
    *on_device = !host_list;
@@ -1873,7 +1888,8 @@ extern "C" int mmh_scan_submit(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t b
    mm::FilterChoice fc;
    const bool have_filter = mm::choose_filter(*plan, &fc);
    if (c->engine != 0 || !have_filter || g.nbytes == 0 || plan->L > MM_RESOLVER_MAX_KEYWORD ||
-       (c->flood_key != 0 && c->flood_key == search_key(c, plan, block_bytes, big_endian))) {
+       (c->flood_key != 0 && c->flood_key == search_key(c, plan, block_bytes, big_endian) &&
+        !(getenv("MMOORE_FLOOD_HINT") && *getenv("MMOORE_FLOOD_HINT") == '0'))) {
       p.needs_rescan = true;                    // collect runs mmh_scan
    }
    else {

@@ -205,6 +205,7 @@ struct mmh_ctx {
    // ticket submitted for the same search is not put on a lane at all -- its streaming + tail kernels would be thrown
    // away and collect would scan again synchronously (round 3 measured floods SLOWER in flight than one at a time).
    uint64_t flood_key = 0;
+   uint32_t flood_uses = 0;         // synchronous scans that took the hint since (every 16th tries the candidate path again)
    bool fused_ok = true;            // cleared for good when a fused scan's grid barrier ever timed out on this context
    uint32_t route_off = 0;          // MMH_ROUTE_* bits switched off on this context (mmh_set_route); the process-wide ones come on top
    MmHealth health;

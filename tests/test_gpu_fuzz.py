@@ -232,8 +232,10 @@ def test_fuzz_reached_every_engine_path():
     by_path = collections.Counter()
     for (route, path), n in PATH_HITS.items():
         by_path[path] += n
-    # (measured with the default seeds: 23010 / 830 / 94 / 114 scans; the seeds are fixed, so these only move with the code)
-    floor = {0: 10000, 2: 400, 3: 60, 4: 60}
+    # (measured with the default seeds: 22930 / 830 / 237 / 46 scans; the seeds are fixed, so these only move with the code.
+    # Round 4: a search that took a flood path once goes straight to the forward engine when it is scanned again -- the
+    # lanes' collect and the whole-buffer scan of the same keyword: path 4 is what first scans take, 114 -> 46.)
+    floor = {0: 10000, 2: 400, 3: 60, 4: 30}
     for path, least in floor.items():
         assert by_path[path] >= least, (path, by_path[path], least, dict(PATH_HITS))
     for route in ("fused", "plain", "lanes"):
@@ -251,8 +253,10 @@ def test_fuzz_with_a_small_candidate_limit(tmp_path):
     import subprocess
     import sys
     report = tmp_path / "paths.json"
+    # (MMOORE_FLOOD_HINT=0: every scan takes the candidate path first -- with the hint a search that flooded once goes to
+    # the forward engine at once when it is scanned again, and paths 4 / 5 are only what first scans take)
     env = dict(os.environ, MMOORE_MAX_CANDIDATES="16384", MM_FUZZ_SEEDS="48", MM_FUZZ_MEDIUM="32", MM_FUZZ_LONG="1",
-               MM_FUZZ_REPORT=str(report))
+               MM_FUZZ_REPORT=str(report), MMOORE_FLOOD_HINT="0")
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_fuzz.py"), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
                         "-k", "against_oracle or medium_roms or reached_every"], env=env, capture_output=True, text=True, timeout=1500,
