@@ -245,7 +245,7 @@ def cpu_baseline(mm, eng, shard_bytes, cfg, want_bytes, warmups, runs, with_end_
 def pmc_traffic(mm, shard):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes -- only when they were taken
     with THIS device code (the summary carries the hash of the library's sources), else null."""
-    for name in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
+    for name in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue

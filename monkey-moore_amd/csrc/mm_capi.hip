@@ -32,6 +32,8 @@ thread_local std::string g_error;
 constexpr uint64_t kHeaderWords = MM_RESULT_HEADER_WORDS;   // counters in front of the ordered list (pinned host memory)
 constexpr uint32_t kMaxRankSort = MM_MAX_RANK_SORT;         // longest list the device orders
 constexpr uint64_t kInitialCap = 1u << 20;
+constexpr uint64_t kDenseCandidates = 32768;                // candidates per scan from which a search counts as dense (scan_split)
+constexpr uint64_t kSplitMinBytes = 1ull << 30;             // ... on a ROM of at least this size
 
 bool hip_ok(hipError_t e, const char *what)
 {
@@ -938,8 +940,18 @@ int finish_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev, 
          oc->candidates = w.h_result[0];
          const bool leftovers = (w.h_result[5] & 0xFFFFFFFFu) != 0;
          const bool direct = !(flags & 4);
-         // (a long list without left-overs: mm_publish_long has copied the slots to pinned memory before it raised the
-         // flag -- round 3 fetched them here with a DMA copy on the context's own stream, 60 us per scan)
+         if (!direct && !leftovers && oc->candidates != 0) {
+            // a long list: the slots were only written to the device-side copy of the block (a PCIe write per slot
+            // would take longer than the scan): one copy brings them over.  On the context's own stream, behind the
+            // tail kernel's end event (the flag word shows before the kernel has retired and its stores are visible to
+            // a copy engine) -- NOT on the scan's stream: with scans in flight the next scan's streaming kernel is
+            // already queued there, and waiting for the copy would mean waiting for that scan (measured: C4 / C5,
+            // 8.2 - 8.5 K candidates, ran one scan at a time with three tickets outstanding).
+            HIP_TRY(hipStreamWaitEvent(c->own_stream, ev[2], 0));
+            HIP_TRY(hipMemcpyAsync(w.h_result + kHeaderWords, w.d_result[w.result_turn] + kHeaderWords, oc->candidates * sizeof(uint64_t),
+                                   hipMemcpyDeviceToHost, c->own_stream));
+            HIP_TRY(hipStreamSynchronize(c->own_stream));
+         }
          note_dirty_slots(w, oc->candidates);
          oc->listed = oc->candidates;
          oc->tiles = w.h_result[2];
@@ -1516,11 +1528,15 @@ uint64_t search_key(const mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_
    return h ? h : 1;
 }
 
-MmGeom scan_geometry(const mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian)
+MmGeom scan_geometry(const mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian, const MmPending *view = nullptr)
 {
    MmGeom g;
    g.rom = c->rom;
    g.nbytes = c->rom_bytes;
+   if (view && view->view) {
+      g.rom = c->rom + view->view_first;          // (block-aligned, hence 16-byte aligned: scan_split)
+      g.nbytes = view->view_bytes;
+   }
    g.block_bytes = block_bytes;
    g.S = plan->elem_bytes;
    g.L = plan->L;
@@ -1731,6 +1747,15 @@ int scan_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int b
       else if (c->flood_key == key) {
          c->flood_key = 0;
       }
+      // a dense search that the candidate path settled on a big ROM in HBM, engine semantics: the next scan of it is split
+      const bool dense = c->counters[3] == 0 && !g.whole && c->counters[0] >= kDenseCandidates && c->rom_bytes >= kSplitMinBytes &&
+                         c->rom != c->rom_host;
+      if (dense) {
+         c->dense_key = key;
+      }
+      else if (c->dense_key == key) {
+         c->dense_key = 0;
+      }
    }
    (void)hinted;
 
@@ -1752,6 +1777,12 @@ int scan_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int b
 }
 } // namespace
 
+namespace {
+bool split_applies(const mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian);
+int scan_split(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian, uint64_t base_offset, uint64_t *out,
+               uint64_t cap, uint64_t *out_count, bool *settled);
+}
+
 // mmh_scan proper + what the multi-GPU gather needs to know about its list (mm_multi.hip)
 extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian,
                         uint64_t base_offset, uint64_t *out, uint64_t cap, uint64_t *out_count)
@@ -1762,6 +1793,14 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
       c->mg.last_slots = 0;
       c->mg.last_list.clear();
       c->mg.last_end = nullptr;
+   }
+   if (c && plan && out_count && (out || !cap) && split_applies(c, plan, block_bytes, big_endian)) {
+      bool settled = false;
+      const int rc = scan_split(c, plan, block_bytes, big_endian, base_offset, out, cap, out_count, &settled);
+      if (settled) {
+         return rc;
+      }
+      // (a part could not be settled on its lane, or the search turned sparse: one scan of the whole ROM, as ever)
    }
    std::vector<uint64_t> host_list;
    bool on_device = false;
@@ -1812,8 +1851,20 @@ void settle_lane_timing(mmh_ctx *c, int lane)
 }
 } // namespace
 
+namespace {
+int submit_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian, uint64_t base_offset, int *ticket,
+                bool view, uint64_t view_first, uint64_t view_bytes);
+}
+
 extern "C" int mmh_scan_submit(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian,
                                uint64_t base_offset, int *ticket)
+{
+   return submit_impl(c, plan, block_bytes, big_endian, base_offset, ticket, false, 0, 0);
+}
+
+namespace {
+int submit_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian, uint64_t base_offset, int *ticket,
+                bool view, uint64_t view_first, uint64_t view_bytes)
 {
    if (!c || !plan || !ticket) {
       mmh_set_error("mmh_scan_submit: bad argument");
@@ -1883,12 +1934,15 @@ extern "C" int mmh_scan_submit(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t b
    p.big_endian = big_endian;
    p.base_offset = base_offset;
    p.max_candidates = candidate_limit(w);
+   p.view = view;
+   p.view_first = view_first;
+   p.view_bytes = view_bytes;
 
-   const MmGeom g = scan_geometry(c, plan, block_bytes, big_endian);
+   const MmGeom g = scan_geometry(c, plan, block_bytes, big_endian, &p);
    mm::FilterChoice fc;
    const bool have_filter = mm::choose_filter(*plan, &fc);
    if (c->engine != 0 || !have_filter || g.nbytes == 0 || plan->L > MM_RESOLVER_MAX_KEYWORD ||
-       (c->flood_key != 0 && c->flood_key == search_key(c, plan, block_bytes, big_endian) &&
+       (!view && c->flood_key != 0 && c->flood_key == search_key(c, plan, block_bytes, big_endian) &&
         !(getenv("MMOORE_FLOOD_HINT") && *getenv("MMOORE_FLOOD_HINT") == '0'))) {
       p.needs_rescan = true;                    // collect runs mmh_scan
    }
@@ -1940,7 +1994,17 @@ extern "C" int mmh_scan_submit(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t b
    return MMH_OK;
 }
 
+int collect_impl(mmh_ctx *c, int ticket, uint64_t *out, uint64_t cap, uint64_t *out_count, bool *unsettled);
+} // namespace
+
 extern "C" int mmh_scan_collect(mmh_ctx *c, int ticket, uint64_t *out, uint64_t cap, uint64_t *out_count)
+{
+   return collect_impl(c, ticket, out, cap, out_count, nullptr);
+}
+
+namespace {
+// unsettled (tickets of scan_split only): set when the lane could not settle its part -- nothing is rescanned here then
+int collect_impl(mmh_ctx *c, int ticket, uint64_t *out, uint64_t cap, uint64_t *out_count, bool *unsettled)
 {
    if (!c || !out_count || (!out && cap)) {
       mmh_set_error("mmh_scan_collect: bad argument");
@@ -1958,7 +2022,7 @@ extern "C" int mmh_scan_collect(mmh_ctx *c, int ticket, uint64_t *out, uint64_t 
    Outcome oc;
    MmWorkspace &w = c->ws[1 + lane];
    if (!rescan) {
-      const MmGeom g = scan_geometry(c, &p.plan, p.block_bytes, p.big_endian);
+      const MmGeom g = scan_geometry(c, &p.plan, p.block_bytes, p.big_endian, &p);
       // (a second phase, if any, goes behind whatever later scans have been enqueued on the ticket's stream: it
       // works on this ticket's own workspace)
       const hipStream_t lane_st = c->pending_tail_stream[lane];
@@ -1994,6 +2058,13 @@ extern "C" int mmh_scan_collect(mmh_ctx *c, int ticket, uint64_t *out, uint64_t 
          settle_lane_timing(c, lane);
       }
    }
+   if (rescan && p.view) {
+      p.active = false;                         // (a part of scan_split: the caller falls back to one scan of the whole ROM)
+      if (unsettled) {
+         *unsettled = true;
+      }
+      return MMH_OK;
+   }
    if (rescan) {
       // (the ticket stays outstanding when the caller's buffer turns out too small: collect again)
       int rc = mmh_scan(c, &p.plan, p.block_bytes, p.big_endian, p.base_offset, out, cap, out_count);
@@ -2022,6 +2093,137 @@ extern "C" int mmh_scan_collect(mmh_ctx *c, int ticket, uint64_t *out, uint64_t 
    c->mg.last_list.clear();
    return MMH_OK;
 }
+} // namespace
+
+namespace {
+
+// ---- dense searches: one synchronous scan as a pipeline of parts ---------------------------------------------------------
+//
+// A scan with tens of thousands of candidates spends a fifth of its time behind the streaming kernel: the tail kernel
+// (0.16 ms at 90 K candidates) and the host's share -- reading 720 KB of freshly written pinned memory, validating,
+// copying out: 0.1 ms -- all of it while the device streams nothing.  When the previous scan of the same search was like
+// that (mmh_ctx::dense_key), mmh_scan cuts the ROM into block-aligned parts (the multi-GPU partition rule: whole blocks
+// plus (L - 1) S bytes of overlap, so the concatenated lists ARE the whole ROM's list) and sends them through the submit
+// lanes three at a time: part k's tail kernel and host work run while part k + 1 streams; what is left in the open is
+// the last part's.  'water' on the text-like 4 GiB ROM: 1.02 -> ~0.87 ms one at a time.  A part its lane cannot settle
+// (a flood, left-overs beyond the second phase) abandons the pipeline: the whole ROM is scanned the usual way.
+bool split_applies(const mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian)
+{
+   static const bool on = [] { const char *e = getenv("MMOORE_DENSE_SPLIT"); return !(e && *e == '0'); }();
+   if (!on || c->engine != 0 || block_bytes == 0 || !c->rom || c->rom == c->rom_host || c->rom_bytes < kSplitMinBytes || c->dense_key == 0 ||
+       (block_bytes & 15) != 0) {
+      return false;
+   }
+   for (const MmPending &q : c->pending) {
+      if (q.active) {
+         return false;                              // the caller has tickets of its own outstanding
+      }
+   }
+   return c->dense_key == search_key(c, plan, block_bytes, big_endian);
+}
+
+int scan_split(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian, uint64_t base_offset, uint64_t *out,
+               uint64_t cap, uint64_t *out_count, bool *settled)
+{
+   *settled = false;
+   *out_count = 0;
+   const uint64_t N = c->rom_bytes, S = plan->elem_bytes;
+   const uint64_t nblocks = (N + block_bytes - 1) / block_bytes;
+   const uint64_t parts = std::min<uint64_t>(std::min<uint64_t>(8, std::max<uint64_t>(2, N >> 30)), nblocks);
+   const uint64_t overlap = (uint64_t)(plan->L - 1) * S;
+   int tickets[mmh_ctx::kLanes];
+   int outstanding = 0;
+   uint64_t total = 0, candidates = 0, tiles = 0;
+   bool failed = false, hard = false;
+   int error = MMH_OK;
+   auto collect_oldest = [&]() {
+      uint64_t n = 0;
+      bool unsettled = false;
+      const uint64_t room = total <= cap ? cap - total : 0;
+      uint64_t nowhere = 0;                         // (no room left: the part is only counted)
+      int rc = collect_impl(c, tickets[0], room ? out + total : &nowhere, room, &n, &unsettled);
+      if (rc == MMH_E_CAPACITY) {
+         // (the part's list is in its lane's block; only the count matters now: the caller comes back with more room)
+         c->pending[((tickets[0] % mmh_ctx::kLanes) + mmh_ctx::kLanes) % mmh_ctx::kLanes].active = false;
+         rc = MMH_OK;
+      }
+      for (int k = 1; k < outstanding; k++) {
+         tickets[k - 1] = tickets[k];
+      }
+      outstanding--;
+      if (rc != MMH_OK) {
+         error = error == MMH_OK ? rc : error;
+         failed = true;
+         return;
+      }
+      if (unsettled) {
+         failed = true;
+         return;
+      }
+      total += n;
+      candidates += c->counters[0];
+      tiles += c->counters[2];
+      hard = hard || c->counters[3] == 2;
+   };
+   for (uint64_t i = 0; i < parts && !failed; i++) {
+      const uint64_t b0 = nblocks * i / parts, b1 = nblocks * (i + 1) / parts;
+      if (b1 == b0) {
+         continue;
+      }
+      const uint64_t first = b0 * block_bytes;
+      const uint64_t bytes = std::min((b1 - b0) * block_bytes + overlap, N - first);
+      if (outstanding == mmh_ctx::kLanes) {
+         collect_oldest();
+         if (failed) {
+            break;
+         }
+      }
+      int t = 0;
+      const int rc = submit_impl(c, plan, block_bytes, big_endian, base_offset + first, &t, true, first, bytes);
+      if (rc != MMH_OK) {
+         error = rc;
+         failed = true;
+         break;
+      }
+      tickets[outstanding++] = t;
+   }
+   while (outstanding) {
+      collect_oldest();                             // (also behind a failure: no ticket stays outstanding)
+   }
+   if (error != MMH_OK) {
+      *settled = true;
+      return error;
+   }
+   if (failed) {
+      c->dense_key = 0;                             // (the search is not what it was: find out again the usual way)
+      return MMH_OK;
+   }
+   *settled = true;
+   *out_count = total;
+   c->counters[0] = candidates;
+   c->counters[1] = total;
+   c->counters[2] = tiles;
+   c->counters[3] = hard ? 2 : 0;
+   if (candidates < kDenseCandidates) {
+      c->dense_key = 0;
+   }
+   // the list exists in the caller's buffer only (a gather that wants it: from the host)
+   c->mg.last_src = nullptr;
+   c->mg.last_end = nullptr;
+   c->mg.last_slots = 0;
+   c->mg.last_count = total;
+   c->mg.last_list.clear();
+   if (total > cap) {
+      mmh_set_error("mmh_scan: %llu matches do not fit the caller's buffer of %llu", (unsigned long long)total, (unsigned long long)cap);
+      return MMH_E_CAPACITY;
+   }
+   if (c->mg.comm) {
+      c->mg.last_list.assign(out, out + total);
+   }
+   return MMH_OK;
+}
+
+} // namespace
 
 namespace {
 // timings of scan number k (it must still be in the ring)

@@ -143,6 +143,10 @@ struct MmPending {
    uint64_t base_offset = 0;
    uint32_t max_candidates = 0;
    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // the lane's own event triple {start, behind the filter, end}
+   // a ticket of mmh_scan's split pipeline (dense searches, mm_capi.hip: scan_split) scans a VIEW of the ROM: bytes
+   // [view_first, view_first + view_bytes); what such a ticket cannot settle on its lane is not rescanned by collect
+   bool view = false;
+   uint64_t view_first = 0, view_bytes = 0;
 };
 
 struct mmh_ctx {
@@ -205,6 +209,11 @@ struct mmh_ctx {
    // ticket submitted for the same search is not put on a lane at all -- its streaming + tail kernels would be thrown
    // away and collect would scan again synchronously (round 3 measured floods SLOWER in flight than one at a time).
    uint64_t flood_key = 0;
+   // ... and of the last one that stayed on the candidate path with tens of thousands of candidates on a big ROM in HBM
+   // (engine semantics): the next synchronous scan of that search is cut into block-aligned parts that go through the
+   // lanes, so that the tail kernel and the host's share of a part (validation, copy-out: 0.1 ms at 90 K matches) run
+   // while the next part streams (scan_split)
+   uint64_t dense_key = 0;
    uint32_t flood_uses = 0;         // synchronous scans that took the hint since (every 16th tries the candidate path again)
    bool fused_ok = true;            // cleared for good when a fused scan's grid barrier ever timed out on this context
    uint32_t route_off = 0;          // MMH_ROUTE_* bits switched off on this context (mmh_set_route); the process-wide ones come on top

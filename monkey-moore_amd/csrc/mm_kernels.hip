@@ -1855,9 +1855,7 @@ void launch_tail2(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, cons
    static const uint32_t direct_limit = [] { const char *e = getenv("MMOORE_DIRECT_PUBLISH"); return (uint32_t)(e && *e ? atol(e) : MM_DIRECT_PUBLISH); }();
    a.direct_limit = direct_limit;
    a.has_edge = 0;
-   launch_timed(mm_scan_tail2<8>, dim3(tail_blocks ? tail_blocks : tuning().tail_blocks), dim3(64 * MM_WAVES), st, nullptr, nullptr, a);
-   // (long lists: device-side copy -> pinned memory, then the flag; a no-op otherwise.  The scan's end event rides here.)
-   launch_timed(mm_publish_long, dim3(128), dim3(256), st, nullptr, stop, a);
+   launch_timed(mm_scan_tail2<8>, dim3(tail_blocks ? tail_blocks : tuning().tail_blocks), dim3(64 * MM_WAVES), st, nullptr, stop, a);
 }
 
 static MmTileArgs tile_args(const MmGeom &g, const mmh_plan_desc &pl)

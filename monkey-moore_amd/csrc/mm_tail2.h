@@ -221,57 +221,18 @@ __global__ __launch_bounds__(64 * MM_WAVES, OCC) void mm_scan_tail2(MmFusedArgs 
    }
    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
    __syncthreads();
-   // A long list without left-overs only exists in the device-side copy so far: mm_publish_long (launched right behind
-   // this kernel) copies it to pinned memory in full cache lines and raises the flag when it is there.
-   const bool handed_on = resolvable && !direct && !keep;
-   if (threadIdx.x == 0 && !handed_on) {
+   if (threadIdx.x == 0) {
       __threadfence_system();
       __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.host_result) + MM_HDR_FLAG_WORD, (unsigned long long)a.seq,
                          __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
    }
 }
 
-// Behind mm_scan_tail2: a resolved list of more than `direct_limit` slots (header word 4: MM_HDR_ON_DEVICE, no left-overs) goes
-// from the device-side copy of the published block to pinned host memory -- consecutive slots from consecutive lanes, whole
-// cache lines per wave instruction, where one PCIe write per slot from the candidates' waves took 0.14 ms for 65 K slots -- and the flag is
-// raised when every workgroup's stores have been acknowledged.  (Round 3: the HOST fetched such lists with a DMA copy once
-// it saw the flag: wait for the tail's event, enqueue, synchronise = 60 us per scan.)  Any other scan: nothing to do, the
-// tail kernel has raised the flag itself.
-__global__ __launch_bounds__(256) void mm_publish_long(MmFusedArgs a)
-{
-   __shared__ int last_block;
-   const unsigned long long flags = a.dev_result[4], ncand = a.dev_result[0];
-   if (!(flags & MM_HDR_SPARSE) || !(flags & MM_HDR_ON_DEVICE) || (a.dev_result[5] & 0xFFFFFFFFull) != 0) {
-      return;
-   }
-   // System-scope stores (written through to host memory, like the tail's own slot stores): a plain store to pinned memory
-   // may stay dirty in the L2 of the XCD that issued it, and the __threadfence_system() of ONE workgroup only writes back
-   // its own XCD's L2 -- the first version of this kernel had the host see the flag in front of slots from the other seven
-   // (caught by the slot validation: poisoned slots).  Lane i takes slot base + i: 512 contiguous bytes per wave instruction.
-   const unsigned long long *src = reinterpret_cast<const unsigned long long *>(a.dev_result + MM_RESULT_HEADER_WORDS);
-   unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.host_result + MM_RESULT_HEADER_WORDS);
-   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncand; i += (uint64_t)gridDim.x * blockDim.x) {
-      __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-   }
-   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-   __syncthreads();
-   if (threadIdx.x == 0) {
-      last_block = mm_arrive_last(a.ctrl + MM_CTRL_ARRIVE_BARRIER, gridDim.x);     // (idle outside the single-launch kernel; zeroed by the tail)
-   }
-   __syncthreads();
-   if (!last_block) {
-      return;
-   }
-   for (uint32_t k = MM_CTRL_ARRIVE_BARRIER + threadIdx.x; k < MM_CTRL_ARRIVE_END; k += blockDim.x) {
-      a.ctrl[k] = 0;                                         // the arrival counters go back to zero for the next scan
-   }
-   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-   __syncthreads();
-   if (threadIdx.x == 0) {
-      __threadfence_system();
-      __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.host_result) + MM_HDR_FLAG_WORD, (unsigned long long)a.seq,
-                         __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-   }
-}
+// (Round 4 tried a kernel behind this one that copied long lists to pinned memory with system-scope stores and raised the
+// flag -- instead of the host's DMA copy once it has seen the flag: worth 10 us of a 1 ms scan at 90 K candidates, and as
+// a no-op behind every other scan it sat 4-16 us on the scan's stream (profiles/r04 interim kernel stats): taken out
+// again.  What it taught stays in the code: a plain store to pinned memory may stay dirty in the L2 of the XCD that issued
+// it, and one workgroup's __threadfence_system() only writes back its own XCD's L2 -- slots meant for the host are stored
+// at system scope.)
 
 #endif

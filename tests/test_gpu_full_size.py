@@ -140,3 +140,52 @@ def test_forward_engine_4gib(mm, gpu_engine, oracle, kw, wc):
     if len(kw) <= 32:
         assert gpu_engine.scan(plan, block_bytes=BLOCK).tolist() == want.tolist()      # the candidate path agrees
     assert whole.tolist() == oracle.search(oplan, rom).tolist()
+
+
+def test_dense_search_split_pipeline(mm, oracle):
+    """mmh_scan on a search that the previous scan found dense (tens of thousands of candidates, ROM of a GiB or more in
+    HBM, engine semantics) runs as a pipeline of block-aligned parts through the submit lanes (csrc/mm_capi.hip:
+    scan_split): the same list as one scan of the whole ROM -- plants at the parts' edges, 16-bit with both alignments,
+    a buffer that is too small, a base offset, then a sparse search that must leave the pipeline again."""
+    rng = np.random.default_rng(77)
+    for elem, kw, nbytes, be in ((1, "monkeybars", (2 << 30) + 524288 * 3 + 77, False), (2, "texts", (1 << 30) + 4098, True)):
+        n_el = nbytes // elem
+        rom = rng.integers(0, 256, nbytes, dtype=np.uint8)
+        # ~60 K plants, among them some straddling the boundaries the pipeline cuts at (multiples of nblocks / parts blocks)
+        pos = np.sort(rng.choice((nbytes - 64) // 32, size=60000, replace=False)) * 32 + rng.integers(0, 16, 60000)
+        nblocks = -(-nbytes // BLOCK)
+        parts = max(2, nbytes >> 30)
+        edges = [nblocks * i // parts * BLOCK for i in range(1, parts)]
+        pos = np.concatenate([pos, [e - 4 * elem for e in edges], [e - 1 - elem for e in edges], [e + elem for e in edges]]).astype(np.int64)
+        vals = np.array([ord(c) for c in kw], np.int64)
+        for p in pos:
+            shift = int(rng.integers(0, 100))
+            for j, v in enumerate(vals):
+                x = int(v) + shift
+                if elem == 1:
+                    rom[p + j] = x
+                else:
+                    b = x.to_bytes(2, "big" if be else "little")
+                    rom[p + 2 * j], rom[p + 2 * j + 1] = b[0], b[1]
+        want = oracle_engine_parallel(oracle, oracle.plan(elem, kw), rom, BLOCK, be)
+        plan = mm.plan_relative(elem, kw)
+        with mm.Engine(0) as eng:
+            eng.upload(rom)
+            first = eng.scan(plan, block_bytes=BLOCK, big_endian=be, cap=1 << 18)
+            assert first.tolist() == want.tolist() and eng.counters()["candidates"] >= 32768 and eng.counters()["path"] == 0, eng.counters()
+            v0 = eng.health()["validated"]
+            again = eng.scan(plan, block_bytes=BLOCK, big_endian=be, cap=1 << 18)           # the split pipeline
+            assert again.tolist() == want.tolist()
+            assert eng.health()["validated"] - v0 == parts, (eng.health(), parts)          # one validated block per part
+            assert eng.counters()["matches"] == len(want) and eng.counters()["candidates"] >= len(want)
+            based = eng.scan(plan, block_bytes=BLOCK, big_endian=be, base_offset=1 << 40, cap=16)   # too small a buffer: twice through it
+            assert (based - np.uint64(1 << 40)).tolist() == want.tolist()
+            # tickets of the caller's own in between: the pipeline steps aside
+            t = eng.submit(plan, block_bytes=BLOCK, big_endian=be)
+            assert eng.scan(plan, block_bytes=BLOCK, big_endian=be, cap=1 << 18).tolist() == want.tolist()
+            assert eng.collect(t, cap=1 << 18).tolist() == want.tolist()
+            # another keyword on the same ROM: sparse, scanned the usual way
+            other = mm.plan_relative(elem, "zqxjkvbwpy"[: len(kw)])
+            sparse = eng.scan(other, block_bytes=BLOCK, big_endian=be)
+            assert sparse.tolist() == oracle_engine_parallel(oracle, oracle.plan(elem, "zqxjkvbwpy"[: len(kw)]), rom, BLOCK, be).tolist()
+            assert eng.health()["fallbacks"] == 0

@@ -107,8 +107,8 @@ summary = {
     # bench.py reports `roofline.traffic` from this file only while the library's sources are THESE
     "device_source_sha16": device_source_sha16(),
     "library_sha16": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16],
-    "command_fetch": "rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 3 --warmup 1 --depth 1 --no-cpu-baseline --no-other-depth --no-other-configs --prewarm-s 0.05",
-    "command_write": "rocprofv3 --pmc WRITE_SIZE --output-format csv -- python3 bench.py --steps 3 --warmup 1 --depth 1 --no-cpu-baseline --no-other-depth --no-other-configs --prewarm-s 0.05",
+    "command_fetch": "rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 3 --warmup 1 --depth 1 --no-cpu-baseline --no-other-depth --no-other-configs --no-strong --no-read-probe --prewarm-s 0.05",
+    "command_write": "rocprofv3 --pmc WRITE_SIZE --output-format csv -- python3 bench.py --steps 3 --warmup 1 --depth 1 --no-cpu-baseline --no-other-depth --no-other-configs --no-strong --no-read-probe --prewarm-s 0.05",
     "note": "separate --pmc passes; counters are in KiB; per MI355X_MICROARCH.md gfx950 FETCH_SIZE reports half of the bytes of a "
             "wide coalesced (16 B/lane) streaming read, so the read side is doubled; WRITE_SIZE is exact "
             "(calibration: mm_synth_fill writes the whole ROM and reports exactly its size)",
