@@ -53,6 +53,34 @@ bool hip_ok(hipError_t e, const char *what)
 
 } // namespace
 
+// MMOORE_SYNC_TRACE=1 (development): where a synchronous scan's host time goes -- marks taken along mmh_scan, averages
+// printed every 256 scans: [0] entry -> launches done, [1] -> flag seen (device time + launch latency), [2] -> block
+// validated, [3] -> back at the caller
+namespace {
+struct SyncTrace {
+   bool on = getenv("MMOORE_SYNC_TRACE") != nullptr;
+   std::chrono::steady_clock::time_point t[5];
+   double sum[4] = {0, 0, 0, 0};
+   uint64_t n = 0;
+   void mark(int k) { if (on) { t[k] = std::chrono::steady_clock::now(); } }
+   void done()
+   {
+      if (!on) {
+         return;
+      }
+      for (int k = 0; k < 4; k++) {
+         sum[k] += std::chrono::duration<double>(t[k + 1] - t[k]).count() * 1e6;
+      }
+      if (++n % 256 == 0) {
+         fprintf(stderr, "mmh_scan host trace, mean of 256 scans: launches %.1f us, until the flag %.1f us, validation %.1f us, hand-over %.1f us\n",
+                 sum[0] / 256, sum[1] / 256, sum[2] / 256, sum[3] / 256);
+         sum[0] = sum[1] = sum[2] = sum[3] = 0;
+      }
+   }
+};
+thread_local SyncTrace g_sync_trace;
+} // namespace
+
 extern "C" void mmh_set_error(const char *fmt, ...)
 {
    char buf[512];
@@ -904,6 +932,7 @@ int finish_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev, 
       const bool was_fused = w.fused;
       w.fused = false;
       const int rc = wait_fused(w, ev[2]);
+      g_sync_trace.mark(2);
       if (was_fused) {
          g_fused_lock.unlock();
       }
@@ -965,6 +994,7 @@ int finish_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev, 
             what = "result slots";
             if (!violation) {
                w.ctrl_clean = true;               // the kernel's last workgroup re-zeroed the control block
+               g_sync_trace.mark(3);
                return MMH_OK;
             }
          }
@@ -1055,6 +1085,7 @@ int run_pipeline(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, const mm:
    if (rc != MMH_OK) {
       return rc;
    }
+   g_sync_trace.mark(1);
    const bool fused = c->ws[0].fused;
    if (fused) {
       c->ring_has_filter[slot] = false;            // one launch: no event marks the end of its streaming phase
@@ -1804,7 +1835,11 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
    }
    std::vector<uint64_t> host_list;
    bool on_device = false;
+   g_sync_trace.mark(0);
+   g_sync_trace.t[1] = g_sync_trace.t[2] = g_sync_trace.t[3] = g_sync_trace.t[0];
    int rc = scan_impl(c, plan, block_bytes, big_endian, base_offset, out, cap, out_count, &host_list, &on_device);
+   g_sync_trace.mark(4);
+   g_sync_trace.done();
    if (c && (rc == MMH_OK || rc == MMH_E_CAPACITY)) {
       c->mg.last_count = *out_count;
       c->mg.last_slots = on_device ? c->counters[0] : 0;      // (one slot per candidate)
