@@ -153,6 +153,9 @@ def end_to_end(mm, ref, path, nbytes, cfg, ref_offs, warmups, runs):
     """The apples-to-apples figure ("also report H2D-inclusive end-to-end separately"): the facade's
     SearchEngine<T>::run on the very tmpfs file the CPU baseline was timed on -- file -> parallel readers -> pinned
     staging -> PCIe -> HBM -> scan -> offsets + equivalency maps -- against the reference's run of the same call."""
+    # one GPU, the rank's own: `--gpus N` is what the line is about (left to itself the facade deals a file of 2 GiB and more
+    # over all VISIBLE GPUs -- on a multi-GPU node that would be another, faster experiment than "N = 1")
+    os.environ["MMOORE_HIP_DEVICES"] = "1"
     fac = Facade(mm)
     elem, kw, wc, be = cfg["elem"], cfg["keyword"], cfg["wildcard"] or ord("*"), cfg["be"]
     cap = len(ref_offs) + 64
@@ -172,7 +175,7 @@ def end_to_end(mm, ref, path, nbytes, cfg, ref_offs, warmups, runs):
                 runs=runs, warmups=warmups, bytes=nbytes, matches=int(len(offs)),
                 same_offsets_as_reference=same_offsets, same_values_maps_as_reference=same_maps,
                 what="SearchEngine<uint%d_t>::run of libmonkey-core.so (the include/mmoore facade over the C ABI) on the tmpfs file of "
-                     "cpu_baseline: ingest over PCIe + scan + equivalency maps, no previews; median of the timed runs; NOT `value` "
+                     "cpu_baseline, ONE GPU (MMOORE_HIP_DEVICES=1): ingest over PCIe + scan + equivalency maps, no previews; median of the timed runs; NOT `value` "
                      "(which scans a ROM resident in HBM)" % (8 * elem))
 
 
