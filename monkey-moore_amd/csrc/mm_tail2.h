@@ -85,6 +85,10 @@ __global__ __launch_bounds__(64 * MM_WAVES, OCC) void mm_scan_tail2(MmFusedArgs 
       // (the 64 bucket counters of the NEXT candidate's super-bucket are fetched while this one is resolved: one of the
       // three dependent loads in front of a candidate off the critical path)
       auto super_of = [&](uint64_t ci) { return 63u - (uint32_t)__builtin_clzll(__ballot(T.super_excl[lane] <= ci)); };
+      // (candidate ci, ci + nwaves, ...: round 4 measured RUNS of consecutive candidates per wave instead -- neighbours in the
+      // ROM, three of a candidate's four dependent loads from lines just touched -- and it was slower, `water` 1.01 ->
+      // 1.03 ms, `th*s` 1.69 -> 1.92: what a run wins in cache hits it loses to the waves that draw a run of expensive
+      // candidates; striding spreads those)
       uint64_t ci = (uint64_t)blockIdx.x * MM_WAVES + wave;
       uint32_t s = ci < ncand ? super_of(ci) : 0u;
       unsigned int n_next = ci < ncand ? a.bcount[s * MM_SUPER + (uint32_t)lane] : 0u;
