@@ -6,7 +6,14 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from __graft_entry__ import load_package
 mm = load_package()
+t0 = time.perf_counter()
 eng = mm.Engine(0)
+t1 = time.perf_counter()
+eng2 = mm.Engine(0)
+t2 = time.perf_counter()
+eng2.close()
+print("first mmh_create of the process (HIP initialisation + the known-answer self-test through every route): %.1f ms; the next one: %.2f ms" % (
+    (t1 - t0) * 1e3, (t2 - t1) * 1e3))
 n = 4 << 30
 eng.alloc(n)
 mm.synth.RomSpec(42, n, "relativesrch", 1, None, False, 524288).apply_device(eng)
