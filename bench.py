@@ -267,7 +267,7 @@ def measure_pmc_traffic(kernel):
         d = tempfile.mkdtemp(prefix="mm_pmc_", dir="/tmp")
         try:
             r = subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
-                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=240)
+                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=90)
             vals = []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
