@@ -1855,7 +1855,25 @@ void launch_tail2(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, cons
    static const uint32_t direct_limit = [] { const char *e = getenv("MMOORE_DIRECT_PUBLISH"); return (uint32_t)(e && *e ? atol(e) : MM_DIRECT_PUBLISH); }();
    a.direct_limit = direct_limit;
    a.has_edge = 0;
-   launch_timed(mm_scan_tail2<8>, dim3(tail_blocks ? tail_blocks : tuning().tail_blocks), dim3(64 * MM_WAVES), st, nullptr, stop, a);
+   // Several candidates per wave (mm_resolve_sub): two for keywords of up to 16 symbols, four up to 13, eight up to 4
+   // (profiles/r04_candidate_density.log; 64 / 48 more registers than one per wave: 6 / 5 waves per SIMD instead of 8,
+   // which costs nothing -- with 7 the compiler spills and every row of the log was slower).
+   // MMOORE_TAIL_SUB=1: one, as before (2, 4: at most that many); MMOORE_TAIL_QUAD_MAXL: the longest keyword that gets four
+   static const int sub = [] { const char *e = getenv("MMOORE_TAIL_SUB"); return e && *e ? atoi(e) : 8; }();
+   static const int quad_maxl = [] { const char *e = getenv("MMOORE_TAIL_QUAD_MAXL"); const int v = e && *e ? atoi(e) : 13; return v > 13 ? 13 : v; }();
+   const dim3 grid(tail_blocks ? tail_blocks : tuning().tail_blocks), block(64 * MM_WAVES);
+   if (sub >= 8 && pl.L <= 4) {
+      launch_timed(mm_scan_tail2<5, 8>, grid, block, st, nullptr, stop, a);    // (96 registers: with 80 it spills, and is slower)
+   }
+   else if (sub >= 4 && (int)pl.L <= quad_maxl) {
+      launch_timed(mm_scan_tail2<6, 16>, grid, block, st, nullptr, stop, a);
+   }
+   else if (sub >= 2 && pl.L <= 16) {
+      launch_timed(mm_scan_tail2<6, 32>, grid, block, st, nullptr, stop, a);
+   }
+   else {
+      launch_timed(mm_scan_tail2<8, 64>, grid, block, st, nullptr, stop, a);
+   }
 }
 
 static MmTileArgs tile_args(const MmGeom &g, const mmh_plan_desc &pl)

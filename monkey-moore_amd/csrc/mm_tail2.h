@@ -30,7 +30,125 @@ struct MmTail2Lds {
    int last_block;
 };
 
-template <int OCC>
+// ---- several candidates per wave (round 4) --------------------------------------------------------------------------
+// The tail is bound by the latency of a wave's chain per candidate, not by instruction issue (profiles/
+// r04_tail_kernel_counters.txt: 0.26 instructions per cycle and SIMD; the cold loads are a third of the time, the
+// instructions + LDS chain of the window 40 %).  A true match settles within two keyword lengths in front of it, so a
+// window of 32 positions is enough for keywords of up to 16 symbols -- and then HALF a wave is enough for a candidate
+// (a quarter and 16 positions for keywords of up to 8): SUBW lanes per candidate, 64 / SUBW candidates per wave, one
+// instruction stream, their cold loads in flight at once.  What a part of the wave cannot settle (its SUBW positions leave
+// the phase set mixed, the domain's first alignments, survivors that are no alignment) is left to the caller, who resolves
+// that candidate the old way: verdict MM_SUB_AGAIN.
+constexpr int MM_SUB_AGAIN = -3;
+
+// The verdicts (1 reported, 0 not, MM_SUB_AGAIN) of the wave's 64 / SUBW candidates in v[] (wave uniform).  o: the
+// candidate of this lane's part of the wave; have: there is one.
+template <int SUBW, class A>
+__device__ __forceinline__ void mm_resolve_sub(const A &a, const MmPlanLds &P, MmWaveLdsShort &W, uint64_t o, bool have, int lane,
+                                               int (&verdicts)[64 / SUBW])
+{
+   constexpr int NSUB = 64 / SUBW;
+   constexpr int STRIDE = SUBW + 8;                                       // dwords of tile / bytes of jumps per part
+   static_assert(sizeof(W.tile) >= NSUB * STRIDE * 4 && sizeof(W.jump) >= NSUB * STRIDE, "the parts share the wave's LDS");
+   const uint32_t D = a.t.plan.L - 1;
+   const uint32_t full = (1u << D) - 1u;                                  // (D <= 15 here)
+   const int L = (int)a.t.plan.L, S = (int)a.t.g.S;
+   const bool be = a.t.g.big_endian != 0;
+   const int part = lane / SUBW, hl = lane % SUBW;
+   constexpr int npos = SUBW;
+   uint64_t b = 0; uint32_t p = 0; int64_t jc = 0;
+   const bool mine = have && mm_locate_fast(a.t, o, &b, &p, &jc) && jc >= npos;            // (else: the old way)
+   const uint64_t start = mm_domain_start(a.t.g, b, p);
+   const int64_t lo = jc - npos;
+   const uint32_t lo_mod = mine ? mm_modd64(a.t, (uint64_t)lo) : 0u;
+   // stage positions [lo, jc] + the keyword's reach: LDS byte (k + mis) of the part's tile <-> ROM byte src0 + k
+   const uint64_t src0 = start + (uint64_t)(mine ? lo : 0) * S;
+   int nstage = (npos + L) * S;                                           // (+ 6 <= 4 SUBW: L <= 29 / 13 / 5 for 32 / 16 / 8 lanes)
+   if (mine && src0 + (uint64_t)nstage > a.t.g.nbytes) {
+      nstage = (int)(a.t.g.nbytes - src0);
+   }
+   const int mis = (int)(((uintptr_t)(a.t.g.rom + src0)) & 3);
+   const int nw = (nstage + mis + 3) >> 2;                                // <= SUBW dwords
+   uint32_t *part_tile = W.tile + STRIDE * part;
+   uint32_t v0 = 0;
+   if (mine && hl < nw) {
+      v0 = reinterpret_cast<const uint32_t *>(a.t.g.rom + src0 - mis)[hl];
+   }
+   part_tile[hl] = v0;
+   mm_wave_sync();
+   const uint8_t *tile = reinterpret_cast<const uint8_t *>(part_tile) + mis;
+   uint8_t *jump = W.jump + STRIDE * part;
+   // the jump of every position of the window (one lane each), as mm_tile_jumps computes it
+   {
+      const int e1 = a.t.plan.expected[L - 1], b1 = a.t.plan.bridge[L - 1], w1 = a.t.plan.wst[L - 1];
+      const uint32_t m1 = a.t.plan.cmp_mask[L - 1];
+      const int q = hl;
+      int J = 1;
+      bool deep = false;
+      if (mine) {
+         const int c = mm_tile_elem(tile, q + L - 1, S, be);
+         const int pv = mm_tile_elem(tile, q + L - 1 + b1, S, be);
+         const int d = c - pv;
+         deep = ((uint32_t)(d ^ e1) & m1) == 0;
+         const int s = mm_tile_skip(a.t, P, d);
+         J = s < w1 ? s : w1;
+      }
+      if (__ballot(deep) != 0) {
+         if (deep) {
+            J = (int)a.t.plan.match_jump | MM_JUMP_MATCH;
+            for (int i = L - 2; i >= 0; --i) {
+               const int ci = mm_tile_elem(tile, q + i, S, be);
+               const int pi = mm_tile_elem(tile, q + i + P.bridge[i], S, be);
+               const int di = ci - pi;
+               if (((uint32_t)(di ^ P.expected[i]) & P.cmp_mask[i]) != 0) {
+                  const int s = mm_tile_skip(a.t, P, di);
+                  const int w = P.wst[i];
+                  J = s < w ? s : w;
+                  break;
+               }
+            }
+         }
+      }
+      jump[q] = (uint8_t)((J & (MM_JUMP_MATCH - 1)) == 0 ? 1 : J);
+   }
+   mm_wave_sync();
+   // lane hl < D follows the chain of entry phase hl through the part's jumps
+   uint32_t v = (uint32_t)hl;
+   if (mine && (uint32_t)hl < D) {
+      uint32_t q = (uint32_t)hl + D - lo_mod;
+      q = q >= D ? q - D : q;
+      while (q < (uint32_t)npos) {
+         q += jump[q] & (MM_JUMP_MATCH - 1);
+      }
+      v = mm_modd(a.t, lo_mod + (uint32_t)npos) + (q - (uint32_t)npos);
+      v = v >= D ? v - D : v;
+   }
+   // does the compare loop match AT the candidate?  (every lane of the part works it out)
+   const bool is_match = mine && mm_tile_matches(a.t, P, tile, npos);
+   const uint32_t Sset = mine ? 1u << mm_modd64(a.t, (uint64_t)jc) : 0u;
+   const unsigned long long pulled = __ballot(mine && (uint32_t)hl < D && ((Sset >> v) & 1u) != 0);
+   const unsigned long long mine_mask = __ballot(mine), match_mask = __ballot(is_match);
+   mm_wave_sync();                                                        // the wave's LDS may be restaged now
+#pragma unroll
+   for (int h = 0; h < NSUB; h++) {
+      const uint32_t set = (uint32_t)(pulled >> (SUBW * h)) & (uint32_t)((1ull << SUBW) - 1ull);
+      int verdict = MM_SUB_AGAIN;
+      if ((mine_mask >> (SUBW * h)) & 1ull) {
+         if (!((match_mask >> (SUBW * h)) & 1ull)) {
+            verdict = 0;                                                   // survived the SWAR conditions only
+         }
+         else if (set == full) {
+            verdict = 1;
+         }
+         else if (set == 0) {
+            verdict = 0;
+         }
+      }
+      verdicts[h] = verdict;
+   }
+}
+
+template <int OCC, int SUBW>
 __global__ __launch_bounds__(64 * MM_WAVES, OCC) void mm_scan_tail2(MmFusedArgs a)
 {
    __shared__ MmPlanLds P;
@@ -80,7 +198,127 @@ __global__ __launch_bounds__(64 * MM_WAVES, OCC) void mm_scan_tail2(MmFusedArgs 
    const bool direct = ncand <= a.direct_limit;                           // slots go to pinned host memory as well
    unsigned long long walked = 0;
    unsigned int holes = 0;
-   if (resolvable) {
+   const uint64_t nwaves_all = (uint64_t)gridDim.x * MM_WAVES;
+   bool grouped = false;
+   if constexpr (SUBW < 64) {
+   if (resolvable && ncand > nwaves_all) {
+      grouped = true;
+      // Waves take 64 / SUBW NEIGHBOURS of the ascending numbering: mostly members of one bucket, so one walk to the bucket
+      // and one pass over its members serve all of them.
+      constexpr int NSUB = 64 / SUBW;
+      constexpr int SW = SUBW;
+      const uint64_t nwaves = nwaves_all;
+      auto super_of = [&](uint64_t ci) { return 63u - (uint32_t)__builtin_clzll(__ballot(T.super_excl[lane] <= ci)); };
+      uint64_t ci = ((uint64_t)blockIdx.x * MM_WAVES + wave) * NSUB;
+      uint32_t s_next = ci < ncand ? super_of(ci) : 0u;
+      unsigned int n_next = ci < ncand ? a.bcount[s_next * MM_SUPER + (uint32_t)lane] : 0u;
+      for (; ci < ncand; ci += nwaves * NSUB) {
+         const uint32_t s0 = s_next;
+         const unsigned int n0 = n_next;
+         if (ci + nwaves * NSUB < ncand) {
+            s_next = super_of(ci + nwaves * NSUB);
+            n_next = a.bcount[s_next * MM_SUPER + (uint32_t)lane];
+         }
+         uint64_t o[NSUB];
+         uint32_t rank[NSUB];
+         bool have[NSUB], placed[NSUB];
+#pragma unroll
+         for (int k = 0; k < NSUB; k++) {
+            have[k] = ci + k < ncand;
+            placed[k] = false;
+            o[k] = 0;
+            rank[k] = 0;
+         }
+         // candidate number cn: the bucket it lives in, then it and the neighbours of the group that share the bucket
+         auto lookup = [&](int k_first, uint32_t s, unsigned int n_lane) {
+            const uint64_t cn = ci + k_first;
+            const uint32_t in_super = (uint32_t)(cn - T.super_excl[s]);
+            unsigned int incl = n_lane;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+               const unsigned int up = (unsigned int)__shfl_up((int)incl, d);
+               incl += lane >= d ? up : 0u;
+            }
+            const unsigned int excl = incl - n_lane;
+            const unsigned long long starts = __ballot(excl <= in_super && n_lane != 0);
+            const int bl = starts ? 63 - __builtin_clzll(starts) : 0;
+            const uint32_t bucket = s * MM_SUPER + (uint32_t)bl;
+            const uint32_t before = (uint32_t)T.super_excl[s] + (uint32_t)__shfl((int)excl, bl);
+            const uint32_t members = (uint32_t)__shfl((int)n_lane, bl);
+            const uint32_t slot = in_super - (uint32_t)__shfl((int)excl, bl);
+            const unsigned long long *mem = reinterpret_cast<const unsigned long long *>(a.bcand) + (uint64_t)bucket * MM_BUCKET_CAP;
+            // (numbers cn, cn + 1, ... are slots slot, slot + 1, ... of this bucket -- in arrival order; each gets its place in
+            // the ascending list by counting the members in front of it, as ever)
+#pragma unroll
+            for (int k = 0; k < NSUB; k++) {
+               if (k >= k_first && have[k] && !placed[k] && slot + (uint32_t)(k - k_first) < members) {
+                  o[k] = mm_uniform64(mem[slot + (uint32_t)(k - k_first)]);
+                  rank[k] = before;
+               }
+            }
+            for (uint32_t k0 = 0; k0 < members; k0 += 64) {
+               const uint32_t kk = k0 + (uint32_t)lane;
+               const unsigned long long mk = kk < members ? mem[kk] : ~0ull;
+#pragma unroll
+               for (int k = 0; k < NSUB; k++) {
+                  if (k >= k_first && have[k] && !placed[k] && slot + (uint32_t)(k - k_first) < members) {
+                     rank[k] += (uint32_t)__popcll(__ballot(mk < o[k]));
+                  }
+               }
+            }
+#pragma unroll
+            for (int k = 0; k < NSUB; k++) {
+               if (k >= k_first && have[k] && !placed[k] && slot + (uint32_t)(k - k_first) < members) {
+                  placed[k] = true;
+               }
+            }
+         };
+         lookup(0, s0, n0);
+#pragma unroll
+         for (int k = 1; k < NSUB; k++) {
+            if (have[k] && !placed[k]) {                                  // (the group straddles buckets: seldom)
+               const uint32_t sk = super_of(ci + k);
+               lookup(k, sk, a.bcount[sk * MM_SUPER + (uint32_t)lane]);
+            }
+         }
+         uint64_t o_lane = o[0];
+         bool have_lane = have[0];
+#pragma unroll
+         for (int k = 1; k < NSUB; k++) {
+            o_lane = lane / SW == k ? o[k] : o_lane;
+            have_lane = lane / SW == k ? have[k] : have_lane;
+         }
+         int verdicts[NSUB];
+         mm_resolve_sub<SW>(a, P, Wv[wave], o_lane, have_lane, lane, verdicts);
+#pragma unroll
+         for (int k = 0; k < NSUB; k++) {
+            if (!have[k]) {
+               break;
+            }
+            walked++;
+            int verdict = verdicts[k];
+            int64_t hi = 0; uint32_t set = 0; uint64_t dom = 0;
+            if (verdict == MM_SUB_AGAIN) {
+               verdict = mm_resolve_candidate(a, P, Wv[wave], o[k], lane, &walked, &hi, &set, &dom);
+            }
+            if (lane == 0) {
+               const uint64_t value = verdict == 1 ? mm_report_value(a.t.g, o[k], a.base_offset) : MM_NO_MATCH;
+               a.out[ci + k] = value;
+               if (direct) {
+                  __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.host_result) + MM_RESULT_HEADER_WORDS + rank[k],
+                                     (unsigned long long)value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+               }
+               a.dev_result[MM_RESULT_HEADER_WORDS + rank[k]] = value;
+               holes += verdict != 1 ? 1u : 0u;
+               if (verdict == -1) {
+                  mm_resolve_hand_over(a, o[k], ci + k, hi, set, dom);
+               }
+            }
+         }
+      }
+   }
+   }
+   if (resolvable && !grouped) {
       const uint64_t nwaves = (uint64_t)gridDim.x * MM_WAVES;
       // (the 64 bucket counters of the NEXT candidate's super-bucket are fetched while this one is resolved: one of the
       // three dependent loads in front of a candidate off the critical path)
@@ -88,7 +326,8 @@ __global__ __launch_bounds__(64 * MM_WAVES, OCC) void mm_scan_tail2(MmFusedArgs 
       // (candidate ci, ci + nwaves, ...: round 4 measured RUNS of consecutive candidates per wave instead -- neighbours in the
       // ROM, three of a candidate's four dependent loads from lines just touched -- and it was slower, `water` 1.01 ->
       // 1.03 ms, `th*s` 1.69 -> 1.92: what a run wins in cache hits it loses to the waves that draw a run of expensive
-      // candidates; striding spreads those)
+      // candidates; striding spreads those.  The grouped loop above does take neighbours -- 2 to 8 of them, side by side in
+      // one wave, sharing the walk to their bucket: a different trade)
       uint64_t ci = (uint64_t)blockIdx.x * MM_WAVES + wave;
       uint32_t s = ci < ncand ? super_of(ci) : 0u;
       unsigned int n_next = ci < ncand ? a.bcount[s * MM_SUPER + (uint32_t)lane] : 0u;
