@@ -4,7 +4,7 @@
 #
 #   tools/soak_fuzz.sh TAG [PROCESSES] [SEEDS] [MEDIUM] [LONG]
 #
-# Runs PROCESSES fresh python processes of tests/test_gpu_fuzz.py, one after the other, each with -x --tb=short, the
+# Runs PROCESSES fresh python processes of tests/test_gpu_fuzz.py (and the grouped-candidates cases of test_gpu_tail_groups.py), one after the other, each with -x --tb=short, the
 # library's self-test trace on and tests/_diag.py's route differential on a mismatch (same ROM + plan scanned again in
 # the same process through every route, header words, health counters, ROM dumped under gpurun_out/fuzz_failures/).
 # Everything a process prints is kept in gpurun_out/soak/TAG_pN.log; one line per process goes to
@@ -24,8 +24,8 @@ for p in $(seq 1 "$PROCS"); do
    LOG="$OUT/${TAG}_p${p}.log"
    T0=$(date +%s)
    MM_FUZZ_SEEDS=$SEEDS MM_FUZZ_MEDIUM=$MEDIUM MM_FUZZ_LONG=$LONG MMOORE_SELFTEST_TRACE=1 \
-      timeout 3000 python3 -m pytest tests/test_gpu_fuzz.py -m gpu -x --tb=short -q -p no:cacheprovider -s \
-      -k "against_oracle or medium_roms or long_keywords or left_the_routes" >"$LOG" 2>&1
+      timeout 3000 python3 -m pytest tests/test_gpu_tail_groups.py tests/test_gpu_fuzz.py -m gpu -x --tb=short -q -p no:cacheprovider -s \
+      -k "grouped_candidates or against_oracle or medium_roms or long_keywords or left_the_routes" >"$LOG" 2>&1
    RC=$?
    T1=$(date +%s)
    LAST=$(grep -E "passed|failed|error" "$LOG" | tail -1 | tr '\t' ' ')
