@@ -80,6 +80,7 @@ struct MmFusedArgs {
    uint64_t *host_result;              // pinned: [8 header words][slots]
    uint64_t *dev_result;               // the same block in HBM, for the multi-GPU gather
    uint32_t max_rank;                  // slots the published block holds
+   uint32_t group_min;                 // mm_scan_tail2: more candidates than this are taken several to a wave
    uint32_t ctrl_words;
    uint64_t seq;                       // raised in host_result[MM_HDR_FLAG_WORD] when everything is published
    uint64_t timeout_ticks;             // wall_clock64() ticks (100 MHz) a barrier may take

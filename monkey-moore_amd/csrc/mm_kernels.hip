@@ -1862,6 +1862,12 @@ void launch_tail2(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, cons
    static const int sub = [] { const char *e = getenv("MMOORE_TAIL_SUB"); return e && *e ? atoi(e) : 8; }();
    static const int quad_maxl = [] { const char *e = getenv("MMOORE_TAIL_QUAD_MAXL"); const int v = e && *e ? atoi(e) : 13; return v > 13 ? 13 : v; }();
    const dim3 grid(tail_blocks ? tail_blocks : tuning().tail_blocks), block(64 * MM_WAVES);
+   static const long group_min = [] { const char *e = getenv("MMOORE_TAIL_GROUP_MIN"); return e && *e ? atol(e) : -1L; }();
+   // (grouped from an eighth of the grid's waves on: at the bench's 4223 candidates the tail takes 24 us instead of 29 and a
+   // synchronous scan 0.768 ms instead of 0.79 -- fewer walks to the buckets; any threshold between 0 and 4096 measures
+   // the same, profiles/r04_tail_blocks_sweep.log.  Below that a wave's candidates would only wait for each other where
+   // they fall back to the one-per-wave resolver)
+   a.group_min = group_min >= 0 ? (uint32_t)group_min : grid.x * MM_WAVES / 8;
    if (sub >= 8 && pl.L <= 4) {
       launch_timed(mm_scan_tail2<5, 8>, grid, block, st, nullptr, stop, a);    // (96 registers: with 80 it spills, and is slower)
    }

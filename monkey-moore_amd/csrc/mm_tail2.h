@@ -35,7 +35,7 @@ struct MmTail2Lds {
 // r04_tail_kernel_counters.txt: 0.26 instructions per cycle and SIMD; the cold loads are a third of the time, the
 // instructions + LDS chain of the window 40 %).  A true match settles within two keyword lengths in front of it, so a
 // window of 32 positions is enough for keywords of up to 16 symbols -- and then HALF a wave is enough for a candidate
-// (a quarter and 16 positions for keywords of up to 8): SUBW lanes per candidate, 64 / SUBW candidates per wave, one
+// (a quarter and 16 positions for keywords of up to 13, an eighth and 8 positions up to 4): SUBW lanes per candidate, 64 / SUBW candidates per wave, one
 // instruction stream, their cold loads in flight at once.  What a part of the wave cannot settle (its SUBW positions leave
 // the phase set mixed, the domain's first alignments, survivors that are no alignment) is left to the caller, who resolves
 // that candidate the old way: verdict MM_SUB_AGAIN.
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(64 * MM_WAVES, OCC) void mm_scan_tail2(MmFusedArgs 
    const uint64_t nwaves_all = (uint64_t)gridDim.x * MM_WAVES;
    bool grouped = false;
    if constexpr (SUBW < 64) {
-   if (resolvable && ncand > nwaves_all) {
+   if (resolvable && ncand > a.group_min) {
       grouped = true;
       // Waves take 64 / SUBW NEIGHBOURS of the ascending numbering: mostly members of one bucket, so one walk to the bucket
       // and one pass over its members serve all of them.

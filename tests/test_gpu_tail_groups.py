@@ -1,6 +1,6 @@
 # SPDX-License-Identifier: GPL-3.0-or-later
 """The tail kernel's grouped candidates (mm_tail2.h, mm_resolve_sub: eight / four / two candidates per wave for keywords
-of up to 4 / 13 / 16 symbols, once there are more candidates than waves) against the oracle: ROMs of 12 MiB -- beyond the
+of up to 4 / 13 / 16 symbols, once there are more candidates than an eighth of the grid has waves) against the oracle: ROMs of 12 MiB -- beyond the
 single-launch kernel -- with tens of thousands of planted matches (every one a candidate), near-misses, a low-entropy
 stretch whose candidates a short window cannot settle (those go back to the one-per-wave resolver), matches in the
 first positions of blocks and at the ROM's end.  Every group width is run (the widths are chosen per process:
