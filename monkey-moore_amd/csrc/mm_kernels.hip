@@ -1429,7 +1429,10 @@ const Tuning &tuning()
       k.tail_blocks = (unsigned)std::min<long>(number("MMOORE_TAIL_BLOCKS", 2048), (long)MM_ARRIVE_FAN * (MM_ARRIVE_LINES - 1));
       // (scans in flight: a small tail grid beside the next scan's streaming kernel -- 512 workgroups: 0.687-0.689 ms per 4 GiB
       // scan in the steady state against 0.695-0.696 with 2048, profiles/r03_lane_gate_and_span_tickets.log)
-      k.lane_tail_blocks = (unsigned)std::min<long>(number("MMOORE_LANE_TAIL_BLOCKS", 512), (long)MM_ARRIVE_FAN * (MM_ARRIVE_LINES - 1));
+      // (round 4, grouped candidates: between 512 and 1536 workgroups the sparse steady state is the same 0.689-0.691 ms, and
+      // dense searches in flight like 1024 best -- `water` 0.775 -> 0.757 ms, `th*s` 0.934 -> 0.91; 2048 costs the split
+      // pipeline's synchronous caller 0.09 ms: profiles/r04_lane_tail_blocks_sweep.log, r04_candidate_density_lane_tail.log)
+      k.lane_tail_blocks = (unsigned)std::min<long>(number("MMOORE_LANE_TAIL_BLOCKS", 1024), (long)MM_ARRIVE_FAN * (MM_ARRIVE_LINES - 1));
       k.max_candidates = (uint32_t)number("MMOORE_MAX_CANDIDATES", 1048576);
       k.list_candidates = (uint32_t)number("MMOORE_LIST_CANDIDATES", 262144);
       return k;
