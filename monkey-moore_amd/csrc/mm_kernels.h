@@ -14,7 +14,7 @@ struct Tuning {
    uint64_t filter_blocks;           // MMOORE_FILTER_BLOCKS    (1536 workgroups: 6 of the 8 workgroup slots of a CU)
    uint32_t filter_groups_per_span;  // MMOORE_FILTER_GPS       (7 groups of 4 KiB)
    unsigned resolve_blocks;          // MMOORE_RESOLVE_BLOCKS   (4096 workgroups)
-   unsigned tail_blocks;             // MMOORE_TAIL_BLOCKS      (2048 workgroups of mm_scan_tail / mm_scan_tail2)
+   unsigned tail_blocks;             // MMOORE_TAIL_BLOCKS      (2048 workgroups of mm_scan_tail; mm_scan_tail2: 1280 - 2048 by variant unless set)
    unsigned lane_tail_blocks;        // MMOORE_LANE_TAIL_BLOCKS (workgroups of mm_scan_tail2 behind a scan of the submit lanes)
    uint32_t max_candidates;          // MMOORE_MAX_CANDIDATES   (1048576 per scan: the bucketed store, csrc/mm_tail2.h)
    uint32_t list_candidates;         // MMOORE_LIST_CANDIDATES  (262144 per scan: the list-based kernels)
@@ -86,7 +86,7 @@ bool launch_fused(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, cons
 // does the single-launch kernel suit this ROM (small enough) and this device?
 bool fused_applies(const MmGeom &g);
 // Big ROMs: the streaming kernel filling the bucketed store of rb, and mm_scan_tail2 (mm_tail2.h) behind it: results,
-// header and `seq` as launch_fused; tail_blocks = 0: the default grid (one wave per candidate for up to 8 K of them)
+// header and `seq` as launch_fused; tail_blocks = 0: the default grid (every workgroup resident at once: 256 CUs x the variant's occupancy)
 void launch_filter_buckets(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc, const ResolveBuffers &rb,
                            hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 void launch_tail2(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc, const ResolveBuffers &rb,

@@ -1864,7 +1864,14 @@ void launch_tail2(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, cons
    // MMOORE_TAIL_SUB=1: one, as before (2, 4: at most that many); MMOORE_TAIL_QUAD_MAXL: the longest keyword that gets four
    static const int sub = [] { const char *e = getenv("MMOORE_TAIL_SUB"); return e && *e ? atoi(e) : 8; }();
    static const int quad_maxl = [] { const char *e = getenv("MMOORE_TAIL_QUAD_MAXL"); const int v = e && *e ? atoi(e) : 13; return v > 13 ? 13 : v; }();
-   const dim3 grid(tail_blocks ? tail_blocks : tuning().tail_blocks), block(64 * MM_WAVES);
+   // The grid of a scan with the device to itself: as many workgroups as are resident at once at the variant's waves per
+   // SIMD (256 CUs x occupancy) -- with 2048 for all of them a quarter of the 6-per-SIMD variants' waves started when the
+   // first ones ended and a dense search's tail took half as long again (`water`, 90 K candidates in one launch: 96 -> 61 us;
+   // `and` 126 -> 73 with 1280 for the 5-per-SIMD variant; profiles/r04_candidate_density_tail_grid.log).
+   // MMOORE_TAIL_BLOCKS overrides.
+   const int occ = (sub >= 8 && pl.L <= 4) ? 5 : (sub >= 2 && pl.L <= 16) ? 6 : 8;
+   static const bool grid_set = [] { const char *e = getenv("MMOORE_TAIL_BLOCKS"); return e && *e; }();
+   const dim3 grid(tail_blocks ? tail_blocks : grid_set ? tuning().tail_blocks : 256u * (unsigned)occ), block(64 * MM_WAVES);
    static const long group_min = [] { const char *e = getenv("MMOORE_TAIL_GROUP_MIN"); return e && *e ? atol(e) : -1L; }();
    // (grouped from an eighth of the grid's waves on: at the bench's 4223 candidates the tail takes 24 us instead of 29 and a
    // synchronous scan 0.768 ms instead of 0.79 -- fewer walks to the buckets; any threshold between 0 and 4096 measures
