@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 import _diag
 
 NBYTES = 12 << 20
-LENGTHS = [3, 4, 5, 8, 9, 13, 16]
+LENGTHS = [2, 3, 4, 5, 8, 9, 13, 14, 16]
 LETTERS = "etaoinshrdlucmfw"
 
 
@@ -61,8 +61,15 @@ def _case(rng, L, elem, be, wild):
 def test_grouped_candidates_against_oracle(mm, gpu_engine, oracle, L, elem, be):
     rng = np.random.default_rng(4400 + 10 * L + elem + be)
     for wild in (False, True):
-        kw, wc, rom = _case(rng, L, elem, be, wild)
-        oplan = oracle.plan(elem, kw, wc, None)
+        for _ in range(20):
+            kw, wc, rom = _case(rng, L, elem, be, wild)
+            try:
+                oplan = oracle.plan(elem, kw, wc, None)      # (what the reference rejects -- "aa" -- is drawn again)
+                break
+            except RuntimeError:
+                continue
+        else:
+            pytest.skip("no acceptable keyword")
         plan = mm.plan_relative(elem, kw, wc, None)
         gpu_engine.upload(rom)
         for block in (524288, 65536):
