@@ -345,12 +345,13 @@ def other_config(mm, torch, dev, name, scans, steps):
         # longer than a fixed 0.2 s covers on some boxes: round 3's driver line had C3's kernel 5 % above its profile),
         # the lanes' streams and workspaces created.  Condition until the streaming kernel's own duration has settled:
         # three consecutive scans within 0.5 % of each other (at most 1.5 s).
-        conditioning = condition_device(eng, lambda: eng.scan(plan, block_bytes=BLOCK, big_endian=be))
-        offs = eng.scan(plan, block_bytes=BLOCK, big_endian=be)
+        # (the lanes first: creating their streams and workspaces -- allocations, pinned memory, memsets -- leaves the device
+        # idle for milliseconds, and a conditioning in FRONT of that had the synchronous scans behind it start on dropped
+        # clocks again: round 4's lines had C3's kernel at 0.710 ms in the conditioning and 0.742 in the scans that counted)
         for t in [eng.submit(plan, block_bytes=BLOCK, big_endian=be) for _ in range(3)]:
             eng.collect(t)
-        for _ in range(3):
-            eng.scan(plan, block_bytes=BLOCK, big_endian=be)
+        conditioning = condition_device(eng, lambda: eng.scan(plan, block_bytes=BLOCK, big_endian=be))
+        offs = eng.scan(plan, block_bytes=BLOCK, big_endian=be)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(scans):
