@@ -2008,7 +2008,7 @@ int submit_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int
       // through its rounds (0.725-0.76); a gate in front of the second scan of a burst (above: no measurable difference).
       // What did help in round 3: a tail kernel that fits beside a streaming kernel (mm_scan_tail2, 61 VGPRs) on a
       // small grid (512 workgroups) -- 0.71-0.735 ms per scan over the first 20 scans from an empty pipeline over
-      // boxes and runs (round 2: 0.745-0.76).
+      // boxes and runs (round 2: 0.745-0.76).  Round 4: the grouped tail (80 / 96 VGPRs) on 1024 workgroups, 0.698-0.707.
       settle_lane_timing(c, lane);             // (before the lane's events are recorded again)
       for (auto &e : c->lane_ev[lane]) {
          if (!e) {

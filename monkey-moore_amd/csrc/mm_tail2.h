@@ -12,7 +12,8 @@
 //     the bucket's members (one per lane and round)          -> the candidate itself and how many members are smaller
 // (the candidates in front of the super-bucket: every workgroup sums the 4096 bucket counters once, 16 KiB from L2).
 // No workgroup-wide step is left inside the candidate loop: waves run on their own, with 20 .. 40 registers fewer
-// than mm_scan_tail -- the kernel fits beside the streaming kernel of the NEXT scan (scans in flight).
+// than mm_scan_tail (one candidate per wave: 64; the grouped variants below: 80 / 96) -- the kernel fits beside the
+// streaming kernel of the NEXT scan (scans in flight).
 //
 // Everything else is mm_scan_tail's: the reference's compare loop + chain membership through the two look-back windows
 // (mm_resolve_candidate), the verdict stored in slot `rank` of the published block, left-overs handed to the second
@@ -35,8 +36,9 @@ struct MmTail2Lds {
 // r04_tail_kernel_counters.txt: 0.26 instructions per cycle and SIMD; the cold loads are a third of the time, the
 // instructions + LDS chain of the window 40 %).  A true match settles within two keyword lengths in front of it, so a
 // window of 32 positions is enough for keywords of up to 16 symbols -- and then HALF a wave is enough for a candidate
-// (a quarter and 16 positions for keywords of up to 13, an eighth and 8 positions up to 4): SUBW lanes per candidate, 64 / SUBW candidates per wave, one
-// instruction stream, their cold loads in flight at once.  What a part of the wave cannot settle (its SUBW positions leave
+// (a quarter and 16 positions for keywords of up to 13, an eighth and 8 positions up to 4): SUBW lanes per candidate,
+// 64 / SUBW candidates per wave, one instruction stream, their cold loads in flight at once (profiles/
+// r04_tail_kernel_counters_grouped.txt: 400 wave instructions per candidate instead of 1170).  What a part of the wave cannot settle (its SUBW positions leave
 // the phase set mixed, the domain's first alignments, survivors that are no alignment) is left to the caller, who resolves
 // that candidate the old way: verdict MM_SUB_AGAIN.
 constexpr int MM_SUB_AGAIN = -3;
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(64 * MM_WAVES, OCC) void mm_scan_tail2(MmFusedArgs 
    if constexpr (SUBW < 64) {
    if (resolvable && ncand > a.group_min) {
       grouped = true;
-      // Waves take 64 / SUBW NEIGHBOURS of the ascending numbering: mostly members of one bucket, so one walk to the bucket
+      // Waves take 64 / SUBW NEIGHBOURS of the compact numbering: mostly members of one bucket, so one walk to the bucket
       // and one pass over its members serve all of them.
       constexpr int NSUB = 64 / SUBW;
       constexpr int SW = SUBW;
