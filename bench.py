@@ -59,7 +59,16 @@ CONFIGS = {
 OTHER_CONFIGS = ("C3", "C4", "C4BE")   # measured behind the timed region of the default (C2, N = 1) run
 
 
-def launch_ranks(n, argv, dry):
+def rccl_stand_in_loaded():
+    """True when tests/shim/libfake_rccl.so (the TEST-ONLY stand-in for RCCL, LD_PRELOADed) serves this process."""
+    import ctypes
+    try:
+        return ctypes.CDLL(None).fake_rccl_loaded() == 1
+    except (AttributeError, OSError):
+        return False
+
+
+def launch_ranks(n, argv, dry, shared_device=False):
     """--gpus N > 1 outside a launcher: start the N ranks as children of THIS process -- which has neither
     imported torch nor touched the GPU (a process that has must not start another program in its place) --
     and hand their exit code back.  Rank 0's JSON line reaches stdout through the inherited descriptor."""
@@ -70,7 +79,7 @@ def launch_ranks(n, argv, dry):
         probe = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
                                stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
         have = int(probe.stdout.strip() or 0) if probe.returncode == 0 else 0
-        if have < n:
+        if have < (1 if shared_device else n):
             sys.stderr.write("bench.py --gpus %d: only %d GPU(s) visible on this node -- refusing to run (one rank per GPU, "
                              "no oversubscription, no CPU fallback)\n" % (n, have))
             return 2
@@ -427,6 +436,10 @@ def main():
                          "never used for a reported figure")
     ap.add_argument("--force-gather", action="store_true",
                     help="N = 1 only (tests): take the N > 1 path anyway -- process group, communicator and gather of ONE rank")
+    ap.add_argument("--allow-shared-device", action="store_true",
+                    help="TESTS ONLY: the N ranks share GPU 0 through the RCCL stand-in of tests/shim (LD_PRELOAD; RCCL itself refuses "
+                         "ranks that share a device).  The line says so (`shared_device`) and its value is NOT a multi-GPU figure; "
+                         "without this flag a process the stand-in is loaded into refuses to run")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak (default): N x the config's ROM, one partition per GPU -- `value`; the line also carries `strong`: "
                          "ONE ROM of the config's size dealt over the N GPUs.  strong: that figure becomes `value`")
@@ -443,7 +456,7 @@ def main():
 
     in_launcher = "RANK" in os.environ or "WORLD_SIZE" in os.environ
     if args.gpus > 1 and not in_launcher:
-        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], args.dry_launch))
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], args.dry_launch, args.allow_shared_device))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -481,6 +494,14 @@ def main():
     import torch
     import torch.distributed as dist
 
+    # The RCCL stand-in of tests/shim only ever serves a run that asks for it: a figure measured through it is not RCCL's.
+    shared = bool(args.allow_shared_device)
+    if rccl_stand_in_loaded() != shared:
+        raise SystemExit("bench.py: %s" % ("the test-only RCCL stand-in (tests/shim/libfake_rccl.so) is loaded into this process "
+                                           "without --allow-shared-device: refusing to time it as RCCL" if not shared else
+                                           "--allow-shared-device needs LD_PRELOAD=tests/shim/libfake_rccl.so (RCCL refuses ranks that share a device)"))
+    if shared:
+        local_rank = 0                                       # every rank on GPU 0
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit("bench.py: rank %d needs GPU %d, %d visible: the engine has no CPU fallback" % (rank, local_rank,
                                                                                                          torch.cuda.device_count()))
@@ -488,13 +509,17 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if shared else dev            # where the rendezvous' own tensors live (gloo when ranks share a device)
     multi = world > 1 or args.force_gather
     banner = c_stdout_to_stderr() if multi else None     # (RCCL's version banner: until both communicators are up)
     if multi:
         banner.__enter__()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if shared:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from __graft_entry__ import load_package
     mm = load_package()
@@ -543,7 +568,7 @@ def main():
                 gather_note = "NATIVE RCCL COMMUNICATOR FAILED on rank %d (%s: %s)" % (rank, type(e).__name__, e)
                 sys.stderr.write("rank %d: %s\n" % (rank, gather_note))
         # all ranks must take the same path
-        ok = torch.tensor([1 if (gather_backend or args.torch_gather) else 0], device=dev)
+        ok = torch.tensor([1 if (gather_backend or args.torch_gather) else 0], device=cdev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         all_up = int(ok.item())
         banner.__exit__()                                     # both communicators have made their first calls
@@ -561,7 +586,9 @@ def main():
             dist.destroy_process_group()
             raise SystemExit(3)
         if args.torch_gather:
-            gatherer = mm.partition.OffsetGather(rank, world, dev, dist)
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import _gather_double                             # (the torch.distributed double: diagnosis only, never a reported figure)
+            gatherer = _gather_double.OffsetGather(rank, world, cdev, dist)
     native = multi and gather_backend is not None
     if multi and not native:
         gather_backend = "torch.distributed all_gather (test double, --torch-gather: NOT the product path)"
@@ -677,7 +704,9 @@ def main():
         local = eng.scan(plan, block_bytes=BLOCK, big_endian=BE, base_offset=base)
         eng.gather_start(None, want_list=(rank == 0))
         mine = eng.gather_finish(want_list=(rank == 0))
-        theirs = mm.partition.gather_offsets(local, rank, world, dev, dist)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import _gather_double                                 # the checker: torch.distributed's gather of the same lists
+        theirs = _gather_double.gather_offsets(local, rank, world, cdev, dist)
         if rank == 0:
             same = np.array_equal(np.asarray(mine, dtype=np.uint64), np.asarray(theirs, dtype=np.uint64))
             gather_check = ("%d offsets of %d ranks identical to the torch.distributed gather" % (len(mine), world) if same
@@ -685,7 +714,7 @@ def main():
             if not same:
                 sys.stderr.write("bench.py: NATIVE GATHER " + gather_check + "\n")
     if multi:
-        tmax = torch.tensor([elapsed, elapsed_other], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed, elapsed_other], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed, elapsed_other = float(tmax[0].item()), float(tmax[1].item())
 
@@ -693,7 +722,7 @@ def main():
         """every rank's x, as a list on every rank"""
         if not multi:
             return [float(x)]
-        t = torch.zeros(world, dtype=torch.float64, device=dev)
+        t = torch.zeros(world, dtype=torch.float64, device=cdev)
         t[rank] = float(x)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return [float(v) for v in t.tolist()]
@@ -758,7 +787,7 @@ def main():
         selapsed1 = time.perf_counter() - t1
         sfilt1, _ = eng.timing_history(min(args.steps, 64))
         if multi:
-            tm = torch.tensor([selapsed, selapsed1], dtype=torch.float64, device=dev)
+            tm = torch.tensor([selapsed, selapsed1], dtype=torch.float64, device=cdev)
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             selapsed, selapsed1 = float(tm[0].item()), float(tm[1].item())
         s_kernel_ranks = over_ranks(float(np.mean(sfilt1)))
@@ -833,7 +862,7 @@ def main():
                 "matches": int(len(offs)),
                 "candidates_rank0": ctr["candidates"],
                 "parallelism": "%d partition(s) on block boundaries%s" % (
-                    world, "" if not multi else ", offset gather: " + gather_backend +
+                    world, "" if not multi else ", offset gather: " + gather_backend + (" [RCCL STAND-IN, ranks share GPU 0]" if shared else "") +
                     (" (synchronous)" if args.sync_gather else ", overlapped with the next scan")),
                 "scans_in_flight": args.depth,
                 "step": ("mmh_scan_submit + mmh_scan_collect of an earlier ticket: K scans submitted and K results delivered "
@@ -884,6 +913,9 @@ def main():
                                    **({"all": kernel_ms_ranks} if world > 1 else {})},
             "health_rank0": eng.health(),
         }
+        if shared:
+            res["shared_device"] = ("TEST RUN: the %d ranks share GPU 0 and the library's RCCL calls are served by tests/shim/libfake_rccl.so "
+                                    "(shared memory): the gather path is exercised, the value is NOT a multi-GPU figure" % world)
         if world > 1:
             res["roofline"]["measured_read_ceiling_per_rank_GBps"] = {"min": min(probe_ranks), "max": max(probe_ranks)}
         if strong is not None:

@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 from . import build as _build
-from . import build, partition, synth  # noqa: F401
+from . import build, synth  # noqa: F401
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = _build.CAPI_SO

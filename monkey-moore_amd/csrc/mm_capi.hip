@@ -223,6 +223,7 @@ void begin_scan_events(mmh_ctx *c, bool has_filter)
 void release_rom(mmh_ctx *c)
 {
    (void)mm_ingest_drain(c);                // (copies of an aborted file load may still be writing the ROM)
+   mm_rom_changed(c);
    if (c->rom_own) {
       (void)hipFree(c->rom_own);
    }
@@ -437,6 +438,7 @@ extern "C" int mmh_rom_alloc(mmh_ctx *c, uint64_t nbytes)
          return rc;
       }
    }
+   mm_rom_changed(c);
    uint64_t need = ((nbytes + 15) / 16) * 16 + 16;
    if (!(c->rom_own && c->rom_alloc >= need)) {
       release_rom(c);
@@ -473,6 +475,7 @@ extern "C" int mmh_rom_upload(mmh_ctx *c, const void *host, uint64_t nbytes)
          c->rom_host = static_cast<uint8_t *>(p);
       }
       // (nothing of an earlier scan still reads the buffer: scans are synchronous, lanes are collected before the ROM may change)
+      mm_rom_changed(c);
       std::memcpy(c->rom_host, host, nbytes);
       std::memset(c->rom_host + nbytes, 0, 32 + (16 - nbytes % 16) % 16);     // the padding behind the ROM stays defined
       c->rom = c->rom_host;
@@ -535,6 +538,7 @@ extern "C" int mmh_rom_synth(mmh_ctx *c, uint64_t seed, uint64_t rom_base_offset
          return rc;
       }
    }
+   mm_rom_changed(c);
    mm::launch_synth(c->stream, c->rom, c->rom_bytes, seed, rom_base_offset);
    HIP_TRY(hipGetLastError());
    return MMH_OK;
@@ -553,6 +557,7 @@ extern "C" int mmh_rom_poke(mmh_ctx *c, uint64_t first_byte, const void *host, u
          return rc;
       }
    }
+   mm_rom_changed(c);
    HIP_TRY(hipMemcpyAsync(c->rom + first_byte, host, nbytes, hipMemcpyDefault, c->stream));
    HIP_TRY(hipStreamSynchronize(c->stream));
    return MMH_OK;
@@ -571,6 +576,7 @@ extern "C" int mmh_rom_fill(mmh_ctx *c, uint64_t first_byte, uint64_t nbytes, in
          return rc;
       }
    }
+   mm_rom_changed(c);
    mm::launch_pattern_fill(c->stream, c->rom, first_byte, nbytes, value, ramp);
    HIP_TRY(hipGetLastError());
    return MMH_OK;
@@ -1003,6 +1009,8 @@ int finish_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev, 
       if (violation) {
          note_violation(c, violation, w, what);
          HIP_TRY(hipEventSynchronize(ev[2]));     // (whatever published that block has retired)
+         // (the rejected scan's slots: whatever it wrote goes back to the poison before the next polled launch)
+         note_dirty_slots(w, std::min<uint64_t>(w.h_result[0], w.max_rank));
          mm::FilterChoice fc;
          mm::choose_filter(pl, &fc);
          w.ctrl_clean = false;
@@ -1825,7 +1833,9 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
       c->mg.last_list.clear();
       c->mg.last_end = nullptr;
    }
-   if (c && plan && out_count && (out || !cap) && split_applies(c, plan, block_bytes, big_endian)) {
+   // (the memo keys hash plan->L entries of the plan's tables: a malformed plan is turned away by scan_impl, not read here)
+   if (c && plan && out_count && (out || !cap) && c->rom && check_scan_args(c, plan, "mmh_scan") == MMH_OK &&
+       split_applies(c, plan, block_bytes, big_endian)) {
       bool settled = false;
       const int rc = scan_split(c, plan, block_bytes, big_endian, base_offset, out, cap, out_count, &settled);
       if (settled) {
@@ -2145,8 +2155,9 @@ namespace {
 bool split_applies(const mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian)
 {
    static const bool on = [] { const char *e = getenv("MMOORE_DENSE_SPLIT"); return !(e && *e == '0'); }();
-   if (!on || c->engine != 0 || block_bytes == 0 || !c->rom || c->rom == c->rom_host || c->rom_bytes < kSplitMinBytes || c->dense_key == 0 ||
-       (block_bytes & 15) != 0) {
+   static const bool always = [] { const char *e = getenv("MMOORE_SPLIT_ALWAYS"); return e && *e == '1'; }();   // (development knob)
+   if (!on || c->engine != 0 || block_bytes == 0 || !c->rom || c->rom == c->rom_host || c->rom_bytes < kSplitMinBytes ||
+       (c->dense_key == 0 && !always) || (block_bytes & 15) != 0) {
       return false;
    }
    for (const MmPending &q : c->pending) {
@@ -2154,7 +2165,7 @@ bool split_applies(const mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_b
          return false;                              // the caller has tickets of its own outstanding
       }
    }
-   return c->dense_key == search_key(c, plan, block_bytes, big_endian);
+   return always || c->dense_key == search_key(c, plan, block_bytes, big_endian);
 }
 
 int scan_split(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian, uint64_t base_offset, uint64_t *out,
@@ -2164,7 +2175,8 @@ int scan_split(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int 
    *out_count = 0;
    const uint64_t N = c->rom_bytes, S = plan->elem_bytes;
    const uint64_t nblocks = (N + block_bytes - 1) / block_bytes;
-   const uint64_t parts = std::min<uint64_t>(std::min<uint64_t>(8, std::max<uint64_t>(2, N >> 30)), nblocks);
+   static const uint64_t forced_parts = [] { const char *e = getenv("MMOORE_SPLIT_PARTS"); return (uint64_t)(e && *e ? atoi(e) : 0); }();
+   const uint64_t parts = std::min<uint64_t>(forced_parts ? forced_parts : std::min<uint64_t>(8, std::max<uint64_t>(2, N >> 30)), nblocks);
    const uint64_t overlap = (uint64_t)(plan->L - 1) * S;
    int tickets[mmh_ctx::kLanes];
    int outstanding = 0;

@@ -223,6 +223,16 @@ struct mmh_ctx {
    MmComm mg;
 };
 
+// The ROM's bytes (or the ROM itself) are about to change: what the context remembers about earlier searches of it --
+// "this search floods" (flood_key), "this search is dense" (dense_key) -- is keyed on plan + ROM pointer + size, not on
+// the contents, and must not outlive them (every mmh_rom_* entry point that writes the ROM calls this).
+inline void mm_rom_changed(mmh_ctx *c)
+{
+   c->flood_key = 0;
+   c->dense_key = 0;
+   c->flood_uses = 0;
+}
+
 // defined in mm_capi.hip
 int mmh_workspace(mmh_ctx *c);
 // defined in mm_ingest.hip: waits for the copies an aborted mmh_rom_load_file_watched left in flight (no-op otherwise)

@@ -715,11 +715,19 @@ __device__ __forceinline__ void mm_load_group(uint4 (&w)[4], const uint8_t *rom,
    const uint64_t base = reinterpret_cast<uint64_t>(rom) + group * 4096;
    uint32_t lo = (uint32_t)base, hi = (uint32_t)(base >> 32);
    asm volatile("" : "+s"(lo), "+s"(hi));
-   const uint8_t *sb = reinterpret_cast<const uint8_t *>(((uint64_t)hi << 32) | lo);
-   w[0] = *reinterpret_cast<const uint4 *>(sb + lane16);
-   w[1] = *reinterpret_cast<const uint4 *>(sb + lane16 + 1024u);
-   w[2] = *reinterpret_cast<const uint4 *>(sb + lane16 + 2048u);
-   w[3] = *reinterpret_cast<const uint4 *>(sb + lane16 + 3072u);
+   // (a GLOBAL pointer: rebuilt from integers it would be a generic one, and round 4's kernels streamed through flat_load --
+   // which counts on vmcnt AND lgkmcnt, so that the compiler drained every load in flight, s_waitcnt vmcnt(0) lgkmcnt(0),
+   // once per ring turn instead of waiting for the oldest group only (vmcnt(8)): the 1.5 % the streaming kernel lost
+   // between rounds 3 and 4, profiles/r05_filter_ab.log)
+   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+   typedef const __attribute__((address_space(1))) uint8_t *global_bytes;
+   typedef const __attribute__((address_space(1))) u32x4 *global_u32x4;
+   const global_bytes sb = reinterpret_cast<global_bytes>(((uint64_t)hi << 32) | lo);
+#pragma unroll
+   for (int k = 0; k < 4; k++) {
+      const u32x4 v = *reinterpret_cast<global_u32x4>(sb + lane16 + 1024u * k);
+      w[k] = make_uint4(v.x, v.y, v.z, v.w);
+   }
 }
 
 // The hot kernel.  The ROM is cut into 4 KiB groups; a wave owns SPANS of
@@ -748,6 +756,11 @@ __device__ __forceinline__ void mm_stream_u8(const A &a)
 
    const uint64_t nspans = (a.ngroups + gps - 1) / gps;
    MmSpanCursor cursor = mm_span_cursor(a, wave, nwaves, nspans);
+   // The stage-1 constants in VECTOR registers: on gfx950 a two-source integer instruction with both sources in VGPRs
+   // issues a wave64 in ~2.4 cycles, the same instruction with an SGPR source in ~4.3 (tools/valu_probe.hip,
+   // profiles/r05_valu_probe.log) -- and the streaming loop's VALU is busy 65 % of the time (r05_filter_sq_counters.txt).
+   uint32_t vpat[4] = {a.pat[0], a.pat[1], a.pat[2], a.pat[3]};
+   asm volatile("" : "+v"(vpat[0]), "+v"(vpat[1]));
    // the wave's survivor queue (bucketed scans only: see mm_queue_flush)
    __shared__ MmSurvivorQueue Q;
    if ((threadIdx.x & 63) == 0) {
@@ -779,7 +792,7 @@ __device__ __forceinline__ void mm_stream_u8(const A &a)
                   // last dword of the previous 16 bytes: lane l-1's w.w; lane 0 keeps c
                   const uint32_t c = u == 0 ? carry : __builtin_amdgcn_readlane(w[s][u - 1].w, 63);
                   const uint32_t back = __builtin_amdgcn_update_dpp(c, w[s][u].w, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-                  const uint32_t any = mm_f8_chunk_any<SHAPE>(w[s][u], back, a.pat, a.sh);
+                  const uint32_t any = mm_f8_chunk_any<SHAPE>(w[s][u], back, vpat, a.sh);
                   pending |= __ballot(any != 0) != 0 ? 1u << (4 * s + u) : 0u;
                }
                carry = __builtin_amdgcn_readlane(w[s][3].w, 63);
@@ -1712,6 +1725,21 @@ static void launch_loud(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl
 // (MI355X_MICROARCH.md, correctness boundaries), so one is taken off, and never more than 5 per CU
 // (16 waves per CU already stream at the full read bandwidth: 1024 x 8 measured like 2048 x 8;
 // 1280 workgroups = 5120 waves resolve the bench ROM's 4223 candidates in one round).
+// compute units of the current device (cached per device: the attribute query costs a few hundred nanoseconds)
+static unsigned device_cus()
+{
+   static int cached[64] = {};
+   int device = 0;
+   if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) {
+      return 256;
+   }
+   if (cached[device] == 0) {
+      int cus = 0;
+      cached[device] = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0 ? cus : 256;
+   }
+   return (unsigned)cached[device];
+}
+
 static unsigned fused_resident_blocks()
 {
    static const unsigned blocks = [] {
@@ -1855,7 +1883,12 @@ void launch_tail2(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, cons
    fill_tail_args(a, rb, base_offset, max_candidates, host_result, dev_result, MM_MAX_PUBLISH, seq);
    fill_bucket_args(a, g, rb);
    a.nbuckets = bucket_geom(g.nbytes).nb;
-   static const uint32_t direct_limit = [] { const char *e = getenv("MMOORE_DIRECT_PUBLISH"); return (uint32_t)(e && *e ? atol(e) : MM_DIRECT_PUBLISH); }();
+   // (never beyond what the host re-poisons between scans, note_dirty_slots in mm_capi.hip: a direct slot above that
+   // could pass for an offset after a late PCIe write)
+   static const uint32_t direct_limit = [] {
+      const char *e = getenv("MMOORE_DIRECT_PUBLISH");
+      return std::min<uint32_t>((uint32_t)(e && *e ? atol(e) : MM_DIRECT_PUBLISH), MM_MAX_RANK_SORT);
+   }();
    a.direct_limit = direct_limit;
    a.has_edge = 0;
    // Several candidates per wave (mm_resolve_sub): two for keywords of up to 16 symbols, four up to 13, eight up to 4
@@ -1865,13 +1898,13 @@ void launch_tail2(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, cons
    static const int sub = [] { const char *e = getenv("MMOORE_TAIL_SUB"); return e && *e ? atoi(e) : 8; }();
    static const int quad_maxl = [] { const char *e = getenv("MMOORE_TAIL_QUAD_MAXL"); const int v = e && *e ? atoi(e) : 13; return v > 13 ? 13 : v; }();
    // The grid of a scan with the device to itself: as many workgroups as are resident at once at the variant's waves per
-   // SIMD (256 CUs x occupancy) -- with 2048 for all of them a quarter of the 6-per-SIMD variants' waves started when the
+   // SIMD (the device's CUs x occupancy; 256 CUs on the MI355X) -- with 2048 for all of them a quarter of the 6-per-SIMD variants' waves started when the
    // first ones ended and a dense search's tail took half as long again (`water`, 90 K candidates in one launch: 96 -> 61 us;
    // `and` 126 -> 73 with 1280 for the 5-per-SIMD variant; profiles/r04_candidate_density_tail_grid.log).
    // MMOORE_TAIL_BLOCKS overrides.
    const int occ = (sub >= 8 && pl.L <= 4) ? 5 : (sub >= 2 && pl.L <= 16) ? 6 : 8;
    static const bool grid_set = [] { const char *e = getenv("MMOORE_TAIL_BLOCKS"); return e && *e; }();
-   const dim3 grid(tail_blocks ? tail_blocks : grid_set ? tuning().tail_blocks : 256u * (unsigned)occ), block(64 * MM_WAVES);
+   const dim3 grid(tail_blocks ? tail_blocks : grid_set ? tuning().tail_blocks : device_cus() * (unsigned)occ), block(64 * MM_WAVES);
    static const long group_min = [] { const char *e = getenv("MMOORE_TAIL_GROUP_MIN"); return e && *e ? atol(e) : -1L; }();
    // (grouped from an eighth of the grid's waves on: at the bench's 4223 candidates the tail takes 24 us instead of 29 and a
    // synchronous scan 0.768 ms instead of 0.79 -- fewer walks to the buckets; any threshold between 0 and 4096 measures

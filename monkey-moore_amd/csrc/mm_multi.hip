@@ -318,16 +318,22 @@ extern "C" int mmh_comm_init_all(mmh_ctx *const *ctxs, int n)
          return MMH_E_ARG;
       }
       devices[i] = ctxs[i]->device;
-      for (int k = 0; k < i; k++) {
-         if (devices[k] == devices[i]) {
-            mmh_set_error("mmh_comm_init_all: contexts %d and %d are on the same device", k, i);
-            return MMH_E_ARG;
-         }
-      }
       comm_release(ctxs[i]);
    }
    std::vector<ncclComm_t> comms(n, nullptr);
-   NCCL_TRY(ncclCommInitAll(comms.data(), n, devices.data()));
+   // (one context per device: RCCL itself refuses a device that appears twice -- "invalid usage")
+   const ncclResult_t made = ncclCommInitAll(comms.data(), n, devices.data());
+   if (made != ncclSuccess) {
+      bool twice = false;
+      for (int i = 0; i < n; i++) {
+         for (int k = 0; k < i; k++) {
+            twice = twice || devices[k] == devices[i];
+         }
+      }
+      mmh_set_error("ncclCommInitAll over %d contexts: %s%s", n, ncclGetErrorString(made),
+                    twice ? " (two of the contexts are on the same device: one rank per GPU)" : "");
+      return made == ncclInvalidUsage || made == ncclInvalidArgument ? MMH_E_ARG : MMH_E_DEVICE;
+   }
    for (int i = 0; i < n; i++) {
       ctxs[i]->mg.comm = comms[i];
       ctxs[i]->mg.rank = i;
@@ -384,6 +390,7 @@ int gather_prepare(mmh_ctx *c, const uint64_t *offsets, uint64_t n, const uint64
    HIP_TRY(hipSetDevice(c->device));
    const double t0 = now_s();
    s.from_host = true;
+   s.kept = false;                                  // (of the slot's previous gather)
    if (!offsets && n == 0) {
       if (m.last_src) {
          s.from_host = false;
@@ -488,7 +495,10 @@ int long_prepare(mmh_ctx *c, MmGatherSlot &s, uint64_t longest)
       m.long_table_cap = need;
    }
    if (s.local_count) {
-      if (s.from_host) {
+      // (a host list that fitted its record -- ANOTHER rank's list is the long one -- was not kept on the host: it sits in
+      // this rank's record of the gathered table like a short device list.  Found by the first run with two ranks:
+      // round 4 kept no such list and failed here with "lost its host list".)
+      if (s.from_host && s.local_count > MM_MAX_RANK_SORT) {
          if (s.host_list.size() != s.local_count) {
             mmh_set_error("mmh_gather_finish: the gather slot lost its host list (internal error)");
             return MMH_E_STATE;

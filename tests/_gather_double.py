@@ -1,10 +1,10 @@
 # SPDX-License-Identifier: GPL-3.0-or-later
-"""Test double of the multi-GPU plumbing.  The product path is in the C ABI (csrc/mm_multi.hip:
-mmh_partition, mmh_comm_*, mmh_gather_start / _finish, mmh_scan_multi -- RCCL called from the
-library itself, lists sent from HBM).  This module restates the same protocol on top of
-torch.distributed so that the CPU suite can run it with "gloo" and two processes
-(tests/test_multi_gpu_host.py), and bench.py keeps it as a loudly flagged fallback should the
-native communicator fail to come up on a box the builder could not test on."""
+"""Test double of the multi-GPU plumbing (test infrastructure: nothing under monkey-moore_amd/ imports it).  The product
+path is in the C ABI (csrc/mm_multi.hip: mmh_partition, mmh_comm_*, mmh_gather_start / _finish, mmh_scan_multi -- RCCL
+called from the library itself, lists sent from HBM).  This module restates the same protocol on top of torch.distributed
+so that the CPU suite can run it with "gloo" and two processes (tests/test_multi_gpu_host.py); bench.py uses it as the
+CHECKER of the library's gather behind its timed region (`gather_check`) and, under --torch-gather, for diagnosis only
+(never for a reported figure: a run whose native communicator does not come up prints `value: null` and exits 3)."""
 import numpy as np
 
 GATHER_WIDTH = 8192     # int64 words per rank in the fixed-width record: [count, offsets...]

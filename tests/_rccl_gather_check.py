@@ -16,16 +16,17 @@ dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 from conftest import load_package  # noqa: E402
+import _gather_double  # noqa: E402
 
 mm = load_package()
 try:
     rng = np.random.default_rng(3)
-    for n in (0, 1, 4223, mm.partition.GATHER_WIDTH - 1, mm.partition.GATHER_WIDTH + 5000):
+    for n in (0, 1, 4223, _gather_double.GATHER_WIDTH - 1, _gather_double.GATHER_WIDTH + 5000):
         offs = np.sort(rng.choice(1 << 40, size=n, replace=False)).astype(np.uint64)
-        got = mm.partition.gather_offsets(offs, 0, 1, dev, dist)
+        got = _gather_double.gather_offsets(offs, 0, 1, dev, dist)
         assert got.dtype == np.uint64 and got.tolist() == offs.tolist(), n
     # the overlapped form bench.py uses at N > 1: start k, finish k-1
-    g = mm.partition.OffsetGather(0, 1, dev, dist)
+    g = _gather_double.OffsetGather(0, 1, dev, dist)
     lists = [np.sort(rng.choice(1 << 40, size=n, replace=False)).astype(np.uint64) for n in (4223, 0, 9000, 17, 4223)]
     done, pending = [], None
     for l in lists:

@@ -36,6 +36,19 @@ def load_tiny():
     return search, engine
 
 
+def build_fake_rccl():
+    """tests/shim/libfake_rccl.so: the TEST-ONLY stand-in for the RCCL entry points the library calls, so that two ranks
+    can share the one GPU a test box has (tests/shim/fake_rccl.cpp).  Plain g++: it links against neither HIP nor RCCL."""
+    import subprocess
+    src = os.path.join(HERE, "shim", "fake_rccl.cpp")
+    so = os.path.join(HERE, "shim", "libfake_rccl.so")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-I" + os.path.join(rocm, "include"), src, "-o", so,
+                               "-ldl", "-lrt", "-pthread"])
+    return so
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from _oracle import Oracle

@@ -249,6 +249,72 @@ def test_native_gather_next_to_torch_nccl():
     assert "native gather ok" in r.stdout
 
 
+def _run_ranks(script, nranks, extra_env=None, timeout=420):
+    """nranks processes of a tests/_*.py script on GPU 0 under the RCCL stand-in; every one must exit 0.  Returns their output."""
+    import glob
+    import tempfile
+    from conftest import build_fake_rccl
+    shim = build_fake_rccl()
+    rdv = tempfile.mkdtemp(prefix="mm_rdv_")
+    env = dict(os.environ, LD_PRELOAD=shim, MMOORE_GATHER_TIMEOUT_S="60", **(extra_env or {}))
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", script), str(r), str(nranks), rdv], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True, env=env, cwd=ROOT) for r in range(nranks)]
+    outs, failed = [], False
+    import time
+    deadline = time.time() + timeout
+    try:
+        for p in procs:
+            try:
+                outs.append(p.communicate(timeout=max(1.0, deadline - time.time()))[0])
+            except subprocess.TimeoutExpired:
+                failed = True
+                break
+            failed = failed or p.returncode != 0
+            if failed:
+                break                                  # (its peers wait for it in a collective: end them)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()                               # exactly the processes started here
+                outs.append(p.communicate()[0])
+        for f in glob.glob(os.path.join(rdv, "*")):
+            os.unlink(f)
+        os.rmdir(rdv)
+        for f in glob.glob("/dev/shm/fake-rccl-*"):
+            try:
+                os.unlink(f)
+            except OSError:
+                pass
+    text = "\n".join("---- rank %d (rc %s)\n%s" % (i, procs[i].returncode, o[-3000:]) for i, o in enumerate(outs))
+    assert not failed and all(p.returncode == 0 for p in procs), text
+    return outs
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_native_gather_two_ranks_one_gpu(mm, nranks):
+    """The library's own communicator and gather (csrc/mm_multi.hip) with MORE THAN ONE RANK: nranks processes on the one
+    GPU, RCCL's nine entry points served by tests/shim/fake_rccl.cpp (stream-ordered, asynchronous, shared memory; RCCL
+    itself refuses ranks that share a device).  Every rank scans its mmh_partition; gathers in bench.py's order (three
+    tickets outstanding, two gathers in flight), scans between a gather's start and finish, lists beyond a record on one
+    rank (device-side copy kept; host list), callers' host lists, ranks with empty lists and with nothing to scan --
+    every merged list against the oracle on the WHOLE ROM, on every rank."""
+    outs = _run_ranks("_two_rank_gather.py", nranks)
+    for r, o in enumerate(outs):
+        assert "rank %d of %d ok: rccl_ranks %d" % (r, nranks, nranks) in o, o[-2000:]
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_scan_multi_two_contexts_one_gpu(mm, n):
+    """mmh_comm_init_all + mmh_scan_multi with n > 1 contexts (one process, one host thread per context, the collective
+    inside ncclGroupStart / ncclGroupEnd, the padded second phase inside the group) -- on one GPU through the stand-in."""
+    from conftest import build_fake_rccl
+    env = dict(os.environ, LD_PRELOAD=build_fake_rccl())
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_two_contexts_one_gpu.py"), str(n)], capture_output=True, text=True,
+                       timeout=420, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "scan_multi over %d contexts on one GPU ok" % n in r.stdout
+
+
 def test_search_engine_run_multi_device_path(mm):
     # SearchEngine<T>::run through mmh_comm_init_all + mmh_scan_multi (MMOORE_HIP_MULTI=1 takes that
     # path with the one device there is): the reference's own engine vectors, previews, progress, abort
@@ -288,3 +354,29 @@ def test_bench_multi_rank_path_with_one_rank(extra):
         assert res["gather_ms"]["device_collective_and_pack"] > 0
     other = res["in_flight" if depth == 1 else "synchronous"]
     assert other["same_offsets"] is True
+
+
+def test_bench_two_ranks_one_gpu_through_the_stand_in():
+    """`bench.py --gpus 2` end to end with two REAL ranks (torch.distributed.run, gloo for the rendezvous, the library's own
+    communicator + gathers over the RCCL stand-in, both on GPU 0): weak and strong legs, gather_check against the
+    torch.distributed double, rccl_ranks == 2 on both ranks.  And: the stand-in is refused where it was not asked for."""
+    import json
+    from conftest import build_fake_rccl
+    env = dict(os.environ, LD_PRELOAD=build_fake_rccl())
+    common = ["--gib-per-gpu", "0.25", "--steps", "6", "--warmup", "2", "--prewarm-s", "0.02", "--no-cpu-baseline"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--allow-shared-device"] + common,
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, r.stdout[-2000:]
+    res = json.loads(line[0])
+    assert res["n_gpus"] == 2 and res["value"] > 0 and "shared_device" in res
+    assert res["rccl_ranks"] == {"min": 2, "max": 2, "expected": 2}
+    assert "identical" in res["gather_check"] and "2 ranks" in res["gather_check"]
+    assert res["config"]["matches"] > 500                                   # both partitions' plants in rank 0's merged list
+    assert res["gather_ms"]["device_collective_and_pack"] > 0
+    assert res["strong"]["n_gpus"] == 2 and res["strong"]["matches"] > 250 and res["strong"]["gather_ms"]["device_collective_and_pack"] > 0
+    # one rank, stand-in loaded, not asked for: refused before anything is timed
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-pmc"] + common[:2] + common[6:],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "stand-in" in (r.stderr + r.stdout) and not [l for l in r.stdout.splitlines() if l.startswith("{")]

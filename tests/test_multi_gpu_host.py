@@ -1,6 +1,6 @@
 # SPDX-License-Identifier: GPL-3.0-or-later
 """The N > 1 path on CPU: 2 processes, gloo.  Each rank takes its block-aligned partition
-(monkey-moore_amd/partition.py, the code bench.py uses), produces its offsets (with the
+(mmh_partition's rule restated in tests/_gather_double.py, the torch.distributed double of the library's gather), produces its offsets (with the
 oracle here -- there is no GPU in this suite) and the lists are gathered to rank 0, which
 must hold exactly the offsets of the whole ROM, ascending."""
 import os
@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 from conftest import ROOT, load_package
+import _gather_double
 
 
 def _worker(rank, world, port, total, block, kw, elem, be, q, width=None):
@@ -20,9 +21,10 @@ def _worker(rank, world, port, total, block, kw, elem, be, q, width=None):
     import torch.distributed as dist
     from _oracle import Oracle
     from conftest import load_package as lp
+    import _gather_double
     mm = lp()
     if width:
-        mm.partition.GATHER_WIDTH = width            # force the long-list (two collective) path
+        _gather_double.GATHER_WIDTH = width            # force the long-list (two collective) path
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -30,12 +32,12 @@ def _worker(rank, world, port, total, block, kw, elem, be, q, width=None):
         orc = Oracle()
         plan = orc.plan(elem, kw)
         spec_all = mm.synth.RomSpec(42, total, kw, elem, None, be, block, partitions=world, runs=False)
-        first, nbytes = mm.partition.shard_range(total, block, len(kw), elem, rank, world)
+        first, nbytes = _gather_double.shard_range(total, block, len(kw), elem, rank, world)
         spec = mm.synth.RomSpec(42, total, kw, elem, None, be, block, base=first, nbytes=nbytes, partitions=world, runs=False)
         rom = spec.host_rom()
         assert (rom == spec_all.host_rom()[first:first + nbytes]).all()       # shard generation == slice of the whole
         local = orc.engine(plan, rom, block, be) + np.uint64(first)
-        merged = mm.partition.gather_offsets(local, rank, world, torch.device("cpu"), dist)
+        merged = _gather_double.gather_offsets(local, rank, world, torch.device("cpu"), dist)
         if rank == 0:
             want = orc.engine(plan, spec_all.host_rom(), block, be)
             q.put((merged.tolist(), want.tolist()))
@@ -71,12 +73,13 @@ def _pipelined_worker(rank, world, port, q):
     import torch
     import torch.distributed as dist
     from conftest import load_package as lp
+    import _gather_double
     mm = lp()
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        g = mm.partition.OffsetGather(rank, world, torch.device("cpu"), dist, width=64)
+        g = _gather_double.OffsetGather(rank, world, torch.device("cpu"), dist, width=64)
         rng = np.random.default_rng(5)                      # same stream on both ranks: both know every list
         rounds = []
         for k in range(9):
@@ -127,9 +130,9 @@ def test_shard_ranges_tile_the_rom():
     for world in (1, 2, 4, 8):
         covered = 0
         for r in range(world):
-            first, n = mm.partition.shard_range(total, block, L, 1, r, world)
+            first, n = _gather_double.shard_range(total, block, L, 1, r, world)
             assert first % block == 0 and first == covered
-            nxt = mm.partition.shard_range(total, block, L, 1, r + 1, world)[0] if r + 1 < world else total
+            nxt = _gather_double.shard_range(total, block, L, 1, r + 1, world)[0] if r + 1 < world else total
             assert first + n == min(nxt + L - 1, total)
             covered = nxt
         assert covered == total
@@ -146,7 +149,7 @@ def test_c_abi_partition_matches_the_double_and_tiles_the_rom():
                     covered = 0
                     for r in range(world):
                         first, n = mm.partition_range(total, block, L, S, r, world)
-                        assert (first, n) == mm.partition.shard_range(total, block, L, S, r, world)
+                        assert (first, n) == _gather_double.shard_range(total, block, L, S, r, world)
                         assert first % block == 0 and first == covered
                         nxt = mm.partition_range(total, block, L, S, r + 1, world)[0] if r + 1 < world else total
                         assert first + n == min(nxt + (L - 1) * S, total) or (n == 0 and nxt == first)

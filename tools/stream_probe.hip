@@ -77,6 +77,91 @@ __global__ __launch_bounds__(256) void read_gridstride_work(const uint4 *p, uint
    if (acc == k * 7u) sink[0] = acc;
 }
 
+// pattern C ("sweep", round 5): the whole grid sweeps the ROM front to back -- in round k wave v takes the LOADS adjacent
+// 1 KiB pieces at piece (k nwaves + v) LOADS, so that what is in flight at any time is DEPTH contiguous windows of
+// nwaves x LOADS KiB instead of one 28 KiB span per wave all over the ROM.  With the filter's VALU work per dword when WORK.
+template <int LOADS, int DEPTH, bool WORK>
+__global__ __launch_bounds__(256) void read_sweep(const uint4 *p, uint64_t nchunks, uint32_t *sink, uint32_t k)
+{
+   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+   const uint32_t lane = threadIdx.x & 63;
+   const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+   const uint64_t ngroups = nchunks / (64 * LOADS);
+   uint32_t acc = 0;
+   uint4 w[DEPTH][LOADS];
+   uint64_t g = wave;
+#pragma unroll
+   for (int d = 0; d < DEPTH; d++) {
+      const uint64_t gg = g + d * nwaves < ngroups ? g + d * nwaves : wave;
+#pragma unroll
+      for (int u = 0; u < LOADS; u++) w[d][u] = p[(gg * LOADS + u) * 64 + lane];
+   }
+   for (; g < ngroups; g += nwaves * DEPTH) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; d++) {
+         uint4 cur[LOADS];
+#pragma unroll
+         for (int u = 0; u < LOADS; u++) cur[u] = w[d][u];
+         const uint64_t gn = g + (uint64_t)(d + DEPTH) * nwaves;
+         const uint64_t gg = gn < ngroups ? gn : wave;
+#pragma unroll
+         for (int u = 0; u < LOADS; u++) w[d][u] = p[(gg * LOADS + u) * 64 + lane];
+         if (g + (uint64_t)d * nwaves < ngroups) {
+#pragma unroll
+            for (int u = 0; u < LOADS; u++) {
+               if (WORK) {
+                  const uint32_t back = __builtin_amdgcn_update_dpp(k, cur[u].w, 0x138, 0xf, 0xf, false);
+                  acc |= busy14(cur[u].x, back, k) | busy14(cur[u].y, cur[u].x, k) | busy14(cur[u].z, cur[u].y, k) | busy14(cur[u].w, cur[u].z, k);
+               }
+               else {
+                  acc ^= cur[u].x ^ cur[u].y ^ cur[u].z ^ cur[u].w;
+               }
+            }
+         }
+      }
+   }
+   if (acc == k * 7u) sink[0] = acc;
+}
+
+// pattern B with the filter's work: a wave streams spans of SPAN_GROUPS 4 KiB groups, DEPTH groups ahead in flight
+template <int DEPTH>
+__global__ __launch_bounds__(256) void read_wavespan_work(const uint4 *p, uint64_t nchunks, uint64_t span_groups, uint32_t *sink, uint32_t k)
+{
+   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+   const uint32_t lane = threadIdx.x & 63;
+   const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+   const uint64_t ngroups = nchunks / 256;
+   uint32_t acc = 0;
+   for (uint64_t g0 = wave * span_groups; g0 < ngroups; g0 += nwaves * span_groups) {
+      const uint64_t g1 = g0 + span_groups < ngroups ? g0 + span_groups : ngroups;
+      uint4 w[DEPTH + 1][4];
+#pragma unroll
+      for (int d = 0; d < DEPTH; d++) {
+         const uint64_t gg = g0 + d < g1 ? g0 + d : g1 - 1;
+#pragma unroll
+         for (int u = 0; u < 4; u++) w[d][u] = p[(gg * 4 + u) * 64 + lane];
+      }
+      for (uint64_t g = g0; g < g1; g += DEPTH + 1) {
+#pragma unroll
+         for (int s = 0; s <= DEPTH; s++) {
+            const int slot_new = (s + DEPTH) % (DEPTH + 1);
+            const uint64_t gn = g + s + DEPTH < g1 ? g + s + DEPTH : g1 - 1;
+#pragma unroll
+            for (int u = 0; u < 4; u++) w[slot_new][u] = p[(gn * 4 + u) * 64 + lane];
+            if (g + s < g1) {
+#pragma unroll
+               for (int u = 0; u < 4; u++) {
+                  const uint4 cur = w[s][u];
+                  const uint32_t back = __builtin_amdgcn_update_dpp(k, cur.w, 0x138, 0xf, 0xf, false);
+                  acc |= busy14(cur.x, back, k) | busy14(cur.y, cur.x, k) | busy14(cur.z, cur.y, k) | busy14(cur.w, cur.z, k);
+               }
+            }
+         }
+      }
+   }
+   if (acc == k * 7u) sink[0] = acc;
+}
+
 // pattern A plus the 4-byte look-back load the v1 filter does
 template <int UNROLL>
 __global__ __launch_bounds__(256) void read_gridstride_back(const uint4 *p, uint64_t nchunks, uint32_t *sink)
@@ -125,8 +210,18 @@ int main(int argc, char **argv)
    CK(hipMalloc(&p, bytes)); CK(hipMalloc(&sink, 64));
    hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, p, nchunks);
    CK(hipDeviceSynchronize());
-   for (int grid : {1536, 1792, 2048}) {
+   const uint32_t kk = (uint32_t)argc * 0x01020304u;
+   for (int grid : {1280, 1536, 1792, 2048}) {
       char nm[128];
+#define SWEEP(L, D, W)                                                                                                              \
+      snprintf(nm, sizeof nm, "sweep %d KiB per wave and round, %d rounds in flight%s, grid %d", L, D, W ? " + 14 VALU/dword" : "", grid); \
+      timeit(nm, bytes, [&] { hipLaunchKernelGGL((read_sweep<L, D, W>), dim3(grid), dim3(256), 0, 0, p, nchunks, sink, kk); });
+      SWEEP(1, 1, false) SWEEP(1, 2, false) SWEEP(1, 4, false) SWEEP(4, 1, false) SWEEP(4, 2, false) SWEEP(4, 3, false) SWEEP(2, 2, false)
+      SWEEP(1, 2, true) SWEEP(1, 4, true) SWEEP(1, 8, true) SWEEP(4, 1, true) SWEEP(4, 2, true) SWEEP(4, 3, true) SWEEP(2, 2, true) SWEEP(2, 4, true)
+      snprintf(nm, sizeof nm, "wavespan 28K + 14 VALU/dword, 2 groups ahead, grid %d", grid);
+      timeit(nm, bytes, [&] { hipLaunchKernelGGL(read_wavespan_work<2>, dim3(grid), dim3(256), 0, 0, p, nchunks, (uint64_t)7, sink, kk); });
+      snprintf(nm, sizeof nm, "wavespan 64K + 14 VALU/dword, 2 groups ahead, grid %d", grid);
+      timeit(nm, bytes, [&] { hipLaunchKernelGGL(read_wavespan_work<2>, dim3(grid), dim3(256), 0, 0, p, nchunks, (uint64_t)16, sink, kk); });
       snprintf(nm, sizeof nm, "gridstride u1 grid %d", grid);
       timeit(nm, bytes, [&] { hipLaunchKernelGGL(read_gridstride<1>, dim3(grid), dim3(256), 0, 0, p, nchunks, sink); });
       snprintf(nm, sizeof nm, "gridstride u4 grid %d", grid);
