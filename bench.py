@@ -359,15 +359,23 @@ def other_config(mm, torch, dev, name, scans, steps):
         # clocks again: round 4's lines had C3's kernel at 0.710 ms in the conditioning and 0.742 in the scans that counted)
         for t in [eng.submit(plan, block_bytes=BLOCK, big_endian=be) for _ in range(3)]:
             eng.collect(t)
+        # the kernel with the device to itself: ONE launch over the whole ROM per scan (MMH_ROUTE_NO_SPLIT)
+        eng.set_route(mm.ROUTE_NO_SPLIT)
         conditioning = condition_device(eng, lambda: eng.scan(plan, block_bytes=BLOCK, big_endian=be))
-        offs = eng.scan(plan, block_bytes=BLOCK, big_endian=be)
+        for _ in range(scans):
+            offs = eng.scan(plan, block_bytes=BLOCK, big_endian=be)
+        filt, tot = eng.timing_history(min(scans, 64))
+        ctr = eng.counters()
+        eng.set_route(0)
+        # what a caller of the synchronous API gets (a pipeline of parts on ROMs of this size)
+        for _ in range(4):
+            offs = eng.scan(plan, block_bytes=BLOCK, big_endian=be)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(scans):
             offs = eng.scan(plan, block_bytes=BLOCK, big_endian=be)
         sync_s = time.perf_counter() - t0
-        filt, tot = eng.timing_history(min(scans, 64))
-        ctr = eng.counters()
+        sync_parts = eng.timings().get("parts", 0)
         tickets, last = [], None
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -390,10 +398,10 @@ def other_config(mm, torch, dev, name, scans, steps):
             "workload": "%s: %s, engine semantics, 512 KiB blocks, %.1f GiB splitmix64 ROM resident in HBM" % (name, cfg["what"], cfg["gib"]),
             "kernel": "mm_filter_u%d<%d>" % (8 * elem, mm.filter_shape(plan)["shape"]),
             "kernel_ms": k, "kernel_ms_mean": float(np.mean(filt)), "kernel_ms_min": float(np.min(filt)),
-            "kernel_ms_is": "median over the synchronous scans", "conditioning": conditioning,
+            "kernel_ms_is": "median over %d synchronous scans of ONE launch each (MMH_ROUTE_NO_SPLIT)" % scans, "conditioning": conditioning,
             "scan_device_ms": float(np.median(tot)),
             "achieved_GBps": nbytes / (k * 1e-3) / 1e9, "frac": nbytes / (k * 1e-3) / 1e9 / PEAK_HBM_GBS,
-            "synchronous": {"scans": scans, "ms_per_scan": sync_s / scans * 1e3, "GBps": nbytes * scans / sync_s / 1e9},
+            "synchronous": {"scans": scans, "ms_per_scan": sync_s / scans * 1e3, "GBps": nbytes * scans / sync_s / 1e9, "parts": sync_parts},
             "in_flight": {"steps": steps, "ms_per_step": flight_s / steps * 1e3, "GBps": nbytes * steps / flight_s / 1e9},
             "matches": int(len(offs)), "candidates": ctr["candidates"], "path": ctr["path"],
             "parity": "first %d MiB: %d offsets identical to the oracle (C restatement, all host cores)" % (lim >> 20, len(g)),
@@ -450,6 +458,9 @@ def main():
                     help="do not count the dominant kernel's HBM traffic in this run (two rocprofv3 --pmc child runs of this script "
                          "before the GPU is touched: ~12 s); `roofline.traffic` then comes from profiles/ when the device code matches")
     ap.add_argument("--no-read-probe", action="store_true", help="skip the pure-read probe (`roofline.measured_read_ceiling_GBps`)")
+    ap.add_argument("--no-split", action="store_true",
+                    help="every synchronous scan is ONE streaming launch over the whole ROM (MMH_ROUTE_NO_SPLIT) instead of the pipeline of "
+                         "parts mmh_scan runs on ROMs of >= 1 GiB: for rocprofv3 kernel statistics of the whole-ROM launch")
     ap.add_argument("--no-other-depth", action="store_true",
                     help="skip the extra K steps at the other depth after the timed region (the 'synchronous' / 'in_flight' object)")
     args = ap.parse_args()
@@ -543,6 +554,8 @@ def main():
     eng = mm.Engine(local_rank)
     eng.attach(buf.data_ptr(), shard)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    if args.no_split:
+        eng.set_route(mm.ROUTE_NO_SPLIT)
     spec = mm.synth.RomSpec(SEED, total, KEYWORD, ELEM, WC, BE, BLOCK, base=base, nbytes=shard, partitions=8)
     spec.apply_device(eng)
     torch.cuda.synchronize()
@@ -697,6 +710,20 @@ def main():
         fence()
         elapsed_other = time.perf_counter() - t1
         filt_other, tot_other = eng.timing_history(min(args.steps, 64))
+    # The dominant kernel with the device to itself, ONE launch over the whole shard (MMH_ROUTE_NO_SPLIT: a synchronous scan
+    # of a ROM of >= 1 GiB otherwise runs as a pipeline of parts whose kernels overlap): what `roofline` prices.
+    def alone_scans(k, at=None):
+        eng.set_route(mm.ROUTE_NO_SPLIT)
+        for _ in range(4):
+            eng.scan(plan, block_bytes=BLOCK, big_endian=BE, base_offset=base if at is None else at)
+        for _ in range(k):
+            eng.scan(plan, block_bytes=BLOCK, big_endian=BE, base_offset=base if at is None else at)
+        f, t = eng.timing_history(min(k, 64))
+        eng.set_route(mm.ROUTE_NO_SPLIT if args.no_split else 0)
+        return f, t
+    fence()
+    kernel_alone_filt, kernel_alone_tot = alone_scans(min(max(args.steps, 16), 64))
+    fence()
     # N > 1, after the timed region: the library's gather against the torch.distributed double on one more
     # scan of every rank -- the first place the native collective meets a real second rank
     gather_check = None
@@ -730,8 +757,7 @@ def main():
     # what RCCL saw: the size of the library's own communicator on every rank (0: none -- N = 1 without --force-gather)
     rccl_ranks = over_ranks(eng.comm_info()[1] if native else 0)
     # the streaming kernel's own duration on every rank (launches that overlap nothing where the run has them)
-    own_filt = filt_other if (args.depth > 1 and not args.no_other_depth) else filt_ms
-    kernel_ms_ranks = over_ranks(float(np.mean(own_filt)))
+    kernel_ms_ranks = over_ranks(float(np.mean(kernel_alone_filt)))
 
     # The box's measured read ceiling beside the data-sheet peak: a pure-read kernel over this rank's ROM, <= 50 ms
     read_probe = None
@@ -785,7 +811,8 @@ def main():
         soffs1 = run_steps(args.steps, 1, at=sbase)
         fence()
         selapsed1 = time.perf_counter() - t1
-        sfilt1, _ = eng.timing_history(min(args.steps, 64))
+        sfilt1, _ = alone_scans(8, at=sbase) if sshard else (np.zeros(1), None)   # (one launch over this rank's partition, no gather)
+        fence()
         if multi:
             tm = torch.tensor([selapsed, selapsed1], dtype=torch.float64, device=cdev)
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
@@ -823,13 +850,9 @@ def main():
         # depth 1.  With two scans in flight the streaming kernels of consecutive scans overlap (the next one
         # starts while the last waves of this one drain), so a launch there lasts longer than its share of the
         # device -- those durations are reported beside it, not used.
-        if args.depth == 1:
-            alone_filt, alone_tot, alone_src = filt_ms, tot_ms, "the K timed steps (mmh_scan, one scan at a time)"
-        elif not args.no_other_depth:
-            alone_filt, alone_tot, alone_src = filt_other, tot_other, (
-                "the K synchronous steps behind the timed region (mmh_scan, one scan at a time: launches that overlap nothing)")
-        else:
-            alone_filt, alone_tot, alone_src = filt_ms, tot_ms, "the K timed steps, scans in flight: launches OVERLAP (--no-other-depth)"
+        alone_filt, alone_tot, alone_src = kernel_alone_filt, kernel_alone_tot, (
+            "%d synchronous scans behind the timed region, ONE launch over the whole shard each (MMH_ROUTE_NO_SPLIT): launches that "
+            "overlap nothing" % len(kernel_alone_filt))
         filt = float(np.mean(alone_filt))
         assert filt > 0, "the library reported no streaming-phase timing"
         assert float(np.mean(filt_ms)) > 0
@@ -948,6 +971,10 @@ def main():
             res["in_flight" if other_depth > 1 else "synchronous"] = {
                 "value": total * args.steps / elapsed_other / 1e9, "unit": "GB/s", "ms_per_step": elapsed_other / args.steps * 1e3,
                 "kernel_ms": float(np.mean(filt_other)), "scan_device_ms": float(np.mean(tot_other)),
+                "parts": eng.timings().get("parts", 0) if other_depth == 1 else 0,
+                "kernel_ms_is": ("the streaming kernels of the scan's parts SUMMED (they overlap: mmh_scan runs a ROM of >= 1 GiB as a pipeline "
+                                 "of parts), scan_device_ms = the pipeline's wall time on the host" if other_depth == 1 and not args.no_split and shard >= (1 << 30)
+                                 else "HIP events on the scan's own launches"),
                 "same_offsets": same,
                 "note": "not the headline value: the same K steps " + (
                     "through mmh_scan_submit / mmh_scan_collect, %d tickets outstanding" % other_depth if other_depth > 1 else

@@ -235,7 +235,10 @@ int mmh_set_engine(mmh_ctx *ctx, int engine);
 
 /* Device timings of the last mmh_scan, in milliseconds (HIP events on the scan's
  * stream): [0] streaming filter kernel(s), [1] everything behind it (resolvers, ordering,
- * publication of the results), [2] unused (0), [3] total. */
+ * publication of the results), [2] 0, [3] total.
+ * A synchronous scan of a ROM of >= 1 GiB runs as a pipeline of block-aligned parts whose kernels overlap (mm_capi.hip:
+ * scan_split; MMH_ROUTE_NO_SPLIT switches it off): then [2] = the number of parts, [0] = the parts' streaming kernels
+ * SUMMED (more than their share of the wall time), [3] = the pipeline's wall time on the host, [1] = 0. */
 int mmh_last_timings(mmh_ctx *ctx, float *ms4);
 /* The same for the most recent scans (up to 64 are kept), oldest first: streaming-kernel
  * and total device time of each.  Elapsed times are computed here, not during the scans. */
@@ -266,7 +269,9 @@ enum {
    MMH_ROUTE_NO_SINGLE_LAUNCH = 1,   /* ROMs of <= 4 MiB: streaming kernel + tail kernel instead of mm_scan_fused */
    MMH_ROUTE_NO_ZERO_COPY = 2,       /* uploads of <= 512 KiB are copied to HBM like any other */
    MMH_ROUTE_NO_BUCKETS = 4,         /* the 64 candidate lists + mm_scan_tail instead of the bucketed store + mm_scan_tail2 */
-   MMH_ROUTE_NO_POLLED = 8           /* mm_resolve + rank kernels, the scan's end waited for on a HIP event */
+   MMH_ROUTE_NO_POLLED = 8,          /* mm_resolve + rank kernels, the scan's end waited for on a HIP event */
+   MMH_ROUTE_NO_SPLIT = 16           /* ROMs of >= 1 GiB: ONE streaming launch over the whole ROM instead of the pipeline of parts
+                                        (measurements of the kernel itself: bench.py's roofline figure, rocprofv3 profiles) */
 };
 enum {
    MMH_FB_NONE = 0,

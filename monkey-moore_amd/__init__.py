@@ -33,7 +33,7 @@ EXPORTS = [
     "mmh_gather_start", "mmh_gather_finish", "mmh_last_gather_timings", "mmh_scan_multi", "mmh_selftest_gather_pack",
     "mmh_set_route", "mmh_health", "mmh_selftest_kat", "mmh_selftest_run", "mmh_debug_inject", "mmh_selftest_read_probe",
 ]
-ROUTE_NO_SINGLE_LAUNCH, ROUTE_NO_ZERO_COPY, ROUTE_NO_BUCKETS, ROUTE_NO_POLLED = 1, 2, 4, 8
+ROUTE_NO_SINGLE_LAUNCH, ROUTE_NO_ZERO_COPY, ROUTE_NO_BUCKETS, ROUTE_NO_POLLED, ROUTE_NO_SPLIT = 1, 2, 4, 8, 16
 FB_NONE, FB_HEADER, FB_CAPACITY, FB_STALE_SLOT, FB_ORDER, FB_RANGE, FB_SELFTEST = range(7)
 MMH_GATHER_RECORD_WORDS = 8 + 16384
 MMH_MAX_IN_FLIGHT = 3
@@ -433,7 +433,9 @@ class Engine:
     def timings(self):
         t = (C.c_float * 4)()
         _check(lib().mmh_last_timings(self._h, t))
-        return dict(filter_ms=t[0], post_filter_ms=t[1], total_ms=t[3])
+        # (parts > 0: the scan ran as a pipeline of that many parts; filter_ms is then the SUM of their overlapping streaming kernels
+        # and total_ms the pipeline's wall time, see include/mmoore_hip.h)
+        return dict(filter_ms=t[0], post_filter_ms=t[1], total_ms=t[3], parts=int(t[2]))
 
     def timing_history(self, n=64):
         """(filter_ms, total_ms) arrays of the last <= n scans, oldest first."""

@@ -32,8 +32,8 @@ thread_local std::string g_error;
 constexpr uint64_t kHeaderWords = MM_RESULT_HEADER_WORDS;   // counters in front of the ordered list (pinned host memory)
 constexpr uint32_t kMaxRankSort = MM_MAX_RANK_SORT;         // longest list the device orders
 constexpr uint64_t kInitialCap = 1u << 20;
-constexpr uint64_t kDenseCandidates = 32768;                // candidates per scan from which a search counts as dense (scan_split)
-constexpr uint64_t kSplitMinBytes = 1ull << 30;             // ... on a ROM of at least this size
+constexpr uint64_t kSplitMinBytes = 1ull << 30;             // ROMs from this size on are scanned as a pipeline of parts (scan_split)
+constexpr uint64_t kSplitUnitMin = 256ull << 20;            // ... of at least this many bytes each
 
 bool hip_ok(hipError_t e, const char *what)
 {
@@ -218,6 +218,7 @@ void begin_scan_events(mmh_ctx *c, bool has_filter)
    c->ev = c->ring[slot];
    c->ring_has_filter[slot] = has_filter;
    c->ring_is_ms[slot] = false;
+   c->ring_parts[slot] = 0;
 }
 
 void release_rom(mmh_ctx *c)
@@ -592,6 +593,7 @@ struct Outcome {
    uint32_t hard = 0;
    bool hard_overflow = false;
    bool sorted_on_device = false;
+   bool bucket_overflow = false;    // (tickets of scan_split only) the bucketed store overflowed and nothing was run again
    uint32_t limit = 0;              // the candidate limit of the kernels that ran (bucketed store: 2^20, list-based kernels: 2^18)
 };
 
@@ -930,7 +932,7 @@ int wait_fused(MmWorkspace &w, hipEvent_t done)
 }
 
 int finish_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev, const MmGeom &g, const mmh_plan_desc &pl,
-                    uint64_t base_offset, uint32_t max_candidates, bool sequential, Outcome *oc)
+                    uint64_t base_offset, uint32_t max_candidates, bool sequential, Outcome *oc, bool part_of_split = false)
 {
    max_candidates = oc->limit = w.limit;        // (what enqueue_pipeline settled on)
    if (w.polled) {
@@ -1025,6 +1027,16 @@ int finish_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev, 
       }
       else if (flags & 1) {
          // (left-overs: fall through to the second phase)
+      }
+      else if (was_bucketed && part_of_split) {
+         // (a part of scan_split: the pipeline is given up and the caller decides what to do about the flood -- finer
+         // parts, whose buckets are narrower, or the whole ROM the usual way; running the list-based kernels over this
+         // part would be another pass over it for a list nobody reads)
+         HIP_TRY(hipEventSynchronize(ev[2]));
+         oc->candidates = ~0ull;
+         oc->bucket_overflow = true;
+         w.ctrl_clean = false;
+         return MMH_OK;
       }
       else if (was_bucketed) {
          // a bucket overflowed (a flood of candidates in one ROM neighbourhood) or there are more candidates than the
@@ -1786,15 +1798,6 @@ int scan_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int b
       else if (c->flood_key == key) {
          c->flood_key = 0;
       }
-      // a dense search that the candidate path settled on a big ROM in HBM, engine semantics: the next scan of it is split
-      const bool dense = c->counters[3] == 0 && !g.whole && c->counters[0] >= kDenseCandidates && c->rom_bytes >= kSplitMinBytes &&
-                         c->rom != c->rom_host;
-      if (dense) {
-         c->dense_key = key;
-      }
-      else if (c->dense_key == key) {
-         c->dense_key = 0;
-      }
    }
    (void)hinted;
 
@@ -2039,7 +2042,7 @@ int submit_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int
    return MMH_OK;
 }
 
-int collect_impl(mmh_ctx *c, int ticket, uint64_t *out, uint64_t cap, uint64_t *out_count, bool *unsettled);
+int collect_impl(mmh_ctx *c, int ticket, uint64_t *out, uint64_t cap, uint64_t *out_count, bool *unsettled, bool *overflow = nullptr);
 } // namespace
 
 extern "C" int mmh_scan_collect(mmh_ctx *c, int ticket, uint64_t *out, uint64_t cap, uint64_t *out_count)
@@ -2048,8 +2051,9 @@ extern "C" int mmh_scan_collect(mmh_ctx *c, int ticket, uint64_t *out, uint64_t 
 }
 
 namespace {
-// unsettled (tickets of scan_split only): set when the lane could not settle its part -- nothing is rescanned here then
-int collect_impl(mmh_ctx *c, int ticket, uint64_t *out, uint64_t cap, uint64_t *out_count, bool *unsettled)
+// unsettled (tickets of scan_split only): set when the lane could not settle its part -- nothing is rescanned here then;
+// *overflow: ... because the part's bucketed store overflowed (narrower buckets = smaller parts may still do)
+int collect_impl(mmh_ctx *c, int ticket, uint64_t *out, uint64_t cap, uint64_t *out_count, bool *unsettled, bool *overflow)
 {
    if (!c || !out_count || (!out && cap)) {
       mmh_set_error("mmh_scan_collect: bad argument");
@@ -2071,10 +2075,13 @@ int collect_impl(mmh_ctx *c, int ticket, uint64_t *out, uint64_t cap, uint64_t *
       // (a second phase, if any, goes behind whatever later scans have been enqueued on the ticket's stream: it
       // works on this ticket's own workspace)
       const hipStream_t lane_st = c->pending_tail_stream[lane];
-      int rc = finish_pipeline(c, w, lane_st, p.ev, g, p.plan, p.base_offset, p.max_candidates, false, &oc);
+      int rc = finish_pipeline(c, w, lane_st, p.ev, g, p.plan, p.base_offset, p.max_candidates, false, &oc, p.view);
       if (rc != MMH_OK) {
          p.active = false;
          return rc;
+      }
+      if (overflow) {
+         *overflow = oc.bucket_overflow;
       }
       rescan = oc.candidates > w.out_cap || oc.candidates > oc.limit || oc.hard_overflow || !oc.sorted_on_device;
       static const bool lane_trace = getenv("MMOORE_LANE_TRACE") != nullptr;     // development: where the lanes' kernels lie in time
@@ -2096,6 +2103,7 @@ int collect_impl(mmh_ctx *c, int ticket, uint64_t *out, uint64_t cap, uint64_t *
       // the lane's timings enter the history: now when its last event has completed, else a little later
       const int slot = (int)(c->scans_recorded % mmh_ctx::kRing);
       c->ring_is_ms[slot] = true;
+      c->ring_parts[slot] = 0;
       c->ring_ms[slot][0] = c->ring_ms[slot][1] = 0;
       c->lane_timing_owed[lane] = (int64_t)c->scans_recorded;
       c->scans_recorded++;
@@ -2142,22 +2150,32 @@ int collect_impl(mmh_ctx *c, int ticket, uint64_t *out, uint64_t cap, uint64_t *
 
 namespace {
 
-// ---- dense searches: one synchronous scan as a pipeline of parts ---------------------------------------------------------
+// ---- big ROMs: one synchronous scan as a pipeline of parts ------------------------------------------------------------
 //
-// A scan with tens of thousands of candidates spends a fifth of its time behind the streaming kernel: the tail kernel
-// (0.16 ms at 90 K candidates) and the host's share -- reading 720 KB of freshly written pinned memory, validating,
-// copying out: 0.1 ms -- all of it while the device streams nothing.  When the previous scan of the same search was like
-// that (mmh_ctx::dense_key), mmh_scan cuts the ROM into block-aligned parts (the multi-GPU partition rule: whole blocks
-// plus (L - 1) S bytes of overlap, so the concatenated lists ARE the whole ROM's list) and sends them through the submit
-// lanes three at a time: part k's tail kernel and host work run while part k + 1 streams; what is left in the open is
-// the last part's.  'water' on the text-like 4 GiB ROM: 1.02 -> ~0.87 ms one at a time.  A part its lane cannot settle
-// (a flood, left-overs beyond the second phase) abandons the pipeline: the whole ROM is scanned the usual way.
+// A synchronous scan of a big ROM spends its last tens of microseconds -- hundreds with tens of thousands of candidates --
+// behind the streaming kernel: the tail kernel (20 us at 4 K candidates, 0.16 ms at 250 K) and the host's share (reading
+// freshly written pinned memory, validating, copying out), all of it while the device streams nothing.  So mmh_scan
+// cuts a ROM of >= 1 GiB in HBM (engine semantics) into block-aligned parts -- the multi-GPU partition rule: whole blocks
+// plus (L - 1) S bytes of overlap, so the concatenated lists ARE the whole ROM's list -- and sends them through the
+// submit lanes: part k's tail kernel and host work run while part k + 1 streams, consecutive streaming kernels overlap
+// on the lanes' two streams, and what is left in the open is the last part's tail.
+//
+// Round 4 only did this from the SECOND scan of a search it had seen to be dense (a memo keyed on plan + ROM); a ROM
+// hacker scans a keyword once.  Now the first scan decides by itself: the first two parts are an eighth of the ROM each
+// (0.09 ms of streaming at 4 GiB); by the time the first one is collected its candidate count tells what the search is
+// like, and the rest goes as ONE part (sparse: C2's 4223 candidates -- every part costs ~10 us of launches and ramp), as
+// two (tens of thousands of candidates) or in eighths (hundreds of thousands: th*s, 251 K candidates per 4 GiB, 1.33 ->
+// 1.06 ms).  Measured per part count on first scans, profiles/r05_first_scan_knobs.log.
+//
+// A part whose bucketed store overflows (a flood: more than 4096 candidates in one bucket -- 1 MiB of a 4 GiB part) gives
+// the pipeline up; the scan starts over in parts of a sixteenth of the unit (narrower buckets: 'the' on the text-like ROM,
+// 0.76 M matches, 6.3 -> 1.8 ms through the candidate path instead of the flood path), and only when that overflows as
+// well does the whole ROM go the usual way (scan_impl: list-based kernels, flood paths, forward engine).
 bool split_applies(const mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian)
 {
    static const bool on = [] { const char *e = getenv("MMOORE_DENSE_SPLIT"); return !(e && *e == '0'); }();
-   static const bool always = [] { const char *e = getenv("MMOORE_SPLIT_ALWAYS"); return e && *e == '1'; }();   // (development knob)
-   if (!on || c->engine != 0 || block_bytes == 0 || !c->rom || c->rom == c->rom_host || c->rom_bytes < kSplitMinBytes ||
-       (c->dense_key == 0 && !always) || (block_bytes & 15) != 0) {
+   if (!on || (routes_off(c) & MMH_ROUTE_NO_SPLIT) || c->engine != 0 || block_bytes == 0 || !c->rom || c->rom == c->rom_host ||
+       c->rom_bytes < kSplitMinBytes || (block_bytes & 15) != 0 || block_bytes > kSplitUnitMin || plan->L > MM_RESOLVER_MAX_KEYWORD) {
       return false;
    }
    for (const MmPending &q : c->pending) {
@@ -2165,30 +2183,45 @@ bool split_applies(const mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_b
          return false;                              // the caller has tickets of its own outstanding
       }
    }
-   return always || c->dense_key == search_key(c, plan, block_bytes, big_endian);
+   mm::FilterChoice fc;
+   if (!mm::choose_filter(*plan, &fc)) {
+      return false;                                 // no SWAR key: the forward engine's
+   }
+   // (a search known to flood goes straight to the forward engine: scan_impl's hint)
+   return !(c->flood_key != 0 && c->flood_key == search_key(c, plan, block_bytes, big_endian));
 }
 
-int scan_split(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian, uint64_t base_offset, uint64_t *out,
-               uint64_t cap, uint64_t *out_count, bool *settled)
+// one attempt at the pipeline with parts of `unit` blocks (adaptive: see above); *overflowed: it was given up because a
+// part's bucketed store overflowed
+int scan_split_try(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian, uint64_t base_offset, uint64_t *out,
+                   uint64_t cap, uint64_t *out_count, bool *settled, uint64_t unit, bool adaptive, bool *overflowed, uint32_t *parts_run,
+                   bool *sparse)
 {
    *settled = false;
+   *overflowed = false;
    *out_count = 0;
    const uint64_t N = c->rom_bytes, S = plan->elem_bytes;
    const uint64_t nblocks = (N + block_bytes - 1) / block_bytes;
-   static const uint64_t forced_parts = [] { const char *e = getenv("MMOORE_SPLIT_PARTS"); return (uint64_t)(e && *e ? atoi(e) : 0); }();
-   const uint64_t parts = std::min<uint64_t>(forced_parts ? forced_parts : std::min<uint64_t>(8, std::max<uint64_t>(2, N >> 30)), nblocks);
    const uint64_t overlap = (uint64_t)(plan->L - 1) * S;
+   static const uint64_t forced_parts = [] { const char *e = getenv("MMOORE_SPLIT_PARTS"); return (uint64_t)(e && *e ? atoi(e) : 0); }();
+   if (forced_parts) {                              // (development knob: equal parts, nothing adaptive)
+      unit = std::max<uint64_t>(1, (nblocks + forced_parts - 1) / forced_parts);
+      adaptive = false;
+   }
    int tickets[mmh_ctx::kLanes];
    int outstanding = 0;
    uint64_t total = 0, candidates = 0, tiles = 0;
+   uint64_t next_block = 0, step = unit, collected = 0, submitted = 0;
    bool failed = false, hard = false;
    int error = MMH_OK;
+   const uint64_t first_recorded = c->scans_recorded;
+   const auto t_start = std::chrono::steady_clock::now();
    auto collect_oldest = [&]() {
       uint64_t n = 0;
-      bool unsettled = false;
+      bool unsettled = false, overflow = false;
       const uint64_t room = total <= cap ? cap - total : 0;
       uint64_t nowhere = 0;                         // (no room left: the part is only counted)
-      int rc = collect_impl(c, tickets[0], room ? out + total : &nowhere, room, &n, &unsettled);
+      int rc = collect_impl(c, tickets[0], room ? out + total : &nowhere, room, &n, &unsettled, &overflow);
       if (rc == MMH_E_CAPACITY) {
          // (the part's list is in its lane's block; only the count matters now: the caller comes back with more room)
          c->pending[((tickets[0] % mmh_ctx::kLanes) + mmh_ctx::kLanes) % mmh_ctx::kLanes].active = false;
@@ -2204,6 +2237,7 @@ int scan_split(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int 
          return;
       }
       if (unsettled) {
+         *overflowed = *overflowed || overflow;
          failed = true;
          return;
       }
@@ -2211,20 +2245,30 @@ int scan_split(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int 
       candidates += c->counters[0];
       tiles += c->counters[2];
       hard = hard || c->counters[3] == 2;
-   };
-   for (uint64_t i = 0; i < parts && !failed; i++) {
-      const uint64_t b0 = nblocks * i / parts, b1 = nblocks * (i + 1) / parts;
-      if (b1 == b0) {
-         continue;
+      if (adaptive && collected++ == 0) {
+         // What the search is like, from the first eighth: the second half of the ROM in one part, in two, or in eighths.
+         // (thresholds in candidates per unit; 4 GiB: < 2 K = 16 K per ROM: one; < 25 K = 200 K per ROM: two)
+         const uint64_t per_unit = c->counters[0];
+         const uint64_t left = nblocks > next_block ? nblocks - next_block : 0;
+         step = per_unit < 2048 ? left : per_unit < 25600 ? (left + 1) / 2 : unit;
+         step = std::max<uint64_t>(step, 1);
+         *sparse = per_unit < 2048;
       }
-      const uint64_t first = b0 * block_bytes;
-      const uint64_t bytes = std::min((b1 - b0) * block_bytes + overlap, N - first);
-      if (outstanding == mmh_ctx::kLanes) {
-         collect_oldest();
+   };
+   while (next_block < nblocks && !failed) {
+      if (outstanding == mmh_ctx::kLanes || (adaptive && collected == 0 && outstanding == 2)) {
+         collect_oldest();                          // (adaptive: the third part waits for the first one's verdict)
          if (failed) {
             break;
          }
       }
+      // adaptive: an eighth first (its verdict comes early: the second part has six of a CU's seven wave slots only once
+      // the first has ended), three eighths beside it (the device is busy while the host reads the verdict and decides)
+      const uint64_t width = !adaptive ? step : submitted == 0 ? unit : submitted == 1 ? 3 * unit : step;
+      submitted++;
+      const uint64_t b0 = next_block, b1 = std::min(nblocks, next_block + width);
+      const uint64_t first = b0 * block_bytes;
+      const uint64_t bytes = std::min((b1 - b0) * block_bytes + overlap, N - first);
       int t = 0;
       const int rc = submit_impl(c, plan, block_bytes, big_endian, base_offset + first, &t, true, first, bytes);
       if (rc != MMH_OK) {
@@ -2233,16 +2277,36 @@ int scan_split(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int 
          break;
       }
       tickets[outstanding++] = t;
+      next_block = b1;
+      (*parts_run)++;
    }
    while (outstanding) {
       collect_oldest();                             // (also behind a failure: no ticket stays outstanding)
+   }
+   // The parts' timings as ONE entry of the history: [streaming kernels of all parts, summed -- they overlap, so the sum
+   // exceeds their share of the wall time --, the pipeline's wall time on the host].  (Each collected part left an entry
+   // of its own: mmh_last_timings after a split scan described one eighth of the ROM)
+   for (int lane = 0; lane < mmh_ctx::kLanes; lane++) {
+      settle_lane_timing(c, lane);
+   }
+   if (c->scans_recorded > first_recorded && c->scans_recorded - first_recorded <= mmh_ctx::kRing) {
+      float filter_sum = 0;
+      for (uint64_t k = first_recorded; k < c->scans_recorded; k++) {
+         const int slot = (int)(k % mmh_ctx::kRing);
+         filter_sum += c->ring_is_ms[slot] ? c->ring_ms[slot][0] : 0.0f;
+      }
+      const int slot = (int)(first_recorded % mmh_ctx::kRing);
+      c->ring_is_ms[slot] = true;
+      c->ring_ms[slot][0] = filter_sum;
+      c->ring_ms[slot][1] = (float)(std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() * 1e3);
+      c->ring_parts[slot] = *parts_run;
+      c->scans_recorded = first_recorded + 1;
    }
    if (error != MMH_OK) {
       *settled = true;
       return error;
    }
    if (failed) {
-      c->dense_key = 0;                             // (the search is not what it was: find out again the usual way)
       return MMH_OK;
    }
    *settled = true;
@@ -2251,9 +2315,6 @@ int scan_split(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int 
    c->counters[1] = total;
    c->counters[2] = tiles;
    c->counters[3] = hard ? 2 : 0;
-   if (candidates < kDenseCandidates) {
-      c->dense_key = 0;
-   }
    // the list exists in the caller's buffer only (a gather that wants it: from the host)
    c->mg.last_src = nullptr;
    c->mg.last_end = nullptr;
@@ -2268,6 +2329,48 @@ int scan_split(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int 
       c->mg.last_list.assign(out, out + total);
    }
    return MMH_OK;
+}
+
+int scan_split(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian, uint64_t base_offset, uint64_t *out,
+               uint64_t cap, uint64_t *out_count, bool *settled)
+{
+   const uint64_t nblocks = (c->rom_bytes + block_bytes - 1) / block_bytes;
+   // an eighth of the ROM, but no less than 256 MiB (a 1 GiB ROM: quarters)
+   const uint64_t unit = std::max<uint64_t>(std::max<uint64_t>((nblocks + 7) / 8, (kSplitUnitMin + block_bytes - 1) / block_bytes), 1);
+   bool overflowed = false, sparse = false;
+   uint32_t parts = 0;
+   int rc = MMH_OK;
+   const uint64_t key = search_key(c, plan, block_bytes, big_endian);
+   if (c->fine_key == key) {
+      overflowed = true;                            // (known to flood parts of the usual width: the finer ones at once)
+   }
+   else if (c->sparse_key == key) {
+      // known to be sparse (the verdict of its first scan, until the ROM changes): two halves -- nothing to find out, and
+      // every further part costs ~10 us of launches and ramp (profiles/r05_first_scan_adaptive.log: 0.743 against 0.760 ms)
+      rc = scan_split_try(c, plan, block_bytes, big_endian, base_offset, out, cap, out_count, settled, (nblocks + 1) / 2, false, &overflowed,
+                          &parts, &sparse);
+   }
+   else {
+      rc = scan_split_try(c, plan, block_bytes, big_endian, base_offset, out, cap, out_count, settled, unit, true, &overflowed, &parts, &sparse);
+      if (*settled && sparse) {
+         c->sparse_key = key;
+      }
+   }
+   if (*settled || !overflowed) {
+      return rc;
+   }
+   // a flood for buckets of this width: equal parts of half a unit (a sixteenth of the ROM, at least 64 MiB: a part's
+   // buckets are a 4096th of it wide), remembered for this search until the ROM changes
+   const uint64_t fine = std::max<uint64_t>(unit / 2, ((64ull << 20) + block_bytes - 1) / block_bytes);
+   if (fine >= unit) {
+      return rc;
+   }
+   parts = 0;
+   rc = scan_split_try(c, plan, block_bytes, big_endian, base_offset, out, cap, out_count, settled, fine, false, &overflowed, &parts, &sparse);
+   if (*settled && rc == MMH_OK) {
+      c->fine_key = key;
+   }
+   return rc;
 }
 
 } // namespace
@@ -2302,6 +2405,10 @@ void scan_timings(mmh_ctx *c, uint64_t k, float *ms4)
       }
    }
    ms4[1] = ms4[3] - ms4[0];                    // everything behind the streaming kernel
+   if (c->ring_parts[slot]) {
+      ms4[1] = 0;                               // (a split scan: the parts' kernels overlap, see include/mmoore_hip.h)
+      ms4[2] = (float)c->ring_parts[slot];
+   }
 }
 } // namespace
 
@@ -2376,7 +2483,7 @@ extern "C" int mmh_last_counters(mmh_ctx *c, uint64_t *c4)
 
 extern "C" int mmh_set_route(mmh_ctx *c, uint32_t mask)
 {
-   if (!c || (mask & ~15u)) {
+   if (!c || (mask & ~31u)) {
       mmh_set_error("mmh_set_route: bad argument");
       return MMH_E_ARG;
    }

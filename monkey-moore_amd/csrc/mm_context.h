@@ -190,6 +190,7 @@ struct mmh_ctx {
    float ring_filter_ms[kRing] = {};   // streaming phase of a fused scan (no event marks it inside the one launch)
    bool ring_is_ms[kRing] = {};
    float ring_ms[kRing][2] = {};    // {streaming kernel, whole scan}
+   uint32_t ring_parts[kRing] = {}; // parts a scan ran as when it went through the split pipeline (0: one launch)
    uint64_t scans_recorded = 0;     // slot of scan k is k % kRing
    hipEvent_t *ev = nullptr;        // the current scan's triple
    // The lanes' kernels go to TWO streams, scan t to stream t % 2: scan t then runs behind scan t-2 by stream
@@ -209,12 +210,10 @@ struct mmh_ctx {
    // ticket submitted for the same search is not put on a lane at all -- its streaming + tail kernels would be thrown
    // away and collect would scan again synchronously (round 3 measured floods SLOWER in flight than one at a time).
    uint64_t flood_key = 0;
-   // ... and of the last one that stayed on the candidate path with tens of thousands of candidates on a big ROM in HBM
-   // (engine semantics): the next synchronous scan of that search is cut into block-aligned parts that go through the
-   // lanes, so that the tail kernel and the host's share of a part (validation, copy-out: 0.1 ms at 90 K matches) run
-   // while the next part streams (scan_split)
-   uint64_t dense_key = 0;
    uint32_t flood_uses = 0;         // synchronous scans that took the hint since (every 16th tries the candidate path again)
+   uint64_t sparse_key = 0;         // the last search the split pipeline's first part found sparse: scanned again in two halves
+   uint64_t fine_key = 0;           // the last search whose candidates overflowed the buckets of the split pipeline's usual parts
+                                    // and were settled by narrower ones (scan_split): the next scan of it starts with those
    bool fused_ok = true;            // cleared for good when a fused scan's grid barrier ever timed out on this context
    uint32_t route_off = 0;          // MMH_ROUTE_* bits switched off on this context (mmh_set_route); the process-wide ones come on top
    MmHealth health;
@@ -224,13 +223,14 @@ struct mmh_ctx {
 };
 
 // The ROM's bytes (or the ROM itself) are about to change: what the context remembers about earlier searches of it --
-// "this search floods" (flood_key), "this search is dense" (dense_key) -- is keyed on plan + ROM pointer + size, not on
-// the contents, and must not outlive them (every mmh_rom_* entry point that writes the ROM calls this).
+// "this search floods" (flood_key) -- is keyed on plan + ROM pointer + size, not on the contents, and must not outlive
+// them (every mmh_rom_* entry point that writes the ROM calls this).
 inline void mm_rom_changed(mmh_ctx *c)
 {
    c->flood_key = 0;
-   c->dense_key = 0;
    c->flood_uses = 0;
+   c->fine_key = 0;
+   c->sparse_key = 0;
 }
 
 // defined in mm_capi.hip

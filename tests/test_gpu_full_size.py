@@ -142,50 +142,90 @@ def test_forward_engine_4gib(mm, gpu_engine, oracle, kw, wc):
     assert whole.tolist() == oracle.search(oplan, rom).tolist()
 
 
-def test_dense_search_split_pipeline(mm, oracle):
-    """mmh_scan on a search that the previous scan found dense (tens of thousands of candidates, ROM of a GiB or more in
-    HBM, engine semantics) runs as a pipeline of block-aligned parts through the submit lanes (csrc/mm_capi.hip:
-    scan_split): the same list as one scan of the whole ROM -- plants at the parts' edges, 16-bit with both alignments,
-    a buffer that is too small, a base offset, then a sparse search that must leave the pipeline again."""
+def test_big_rom_split_pipeline(mm, oracle):
+    """mmh_scan on a ROM of a GiB or more in HBM (engine semantics) runs as a pipeline of block-aligned parts through the
+    submit lanes from the FIRST scan on (csrc/mm_capi.hip: scan_split) -- an eighth of the ROM (at least 256 MiB) and three
+    eighths beside it, then, by the first part's candidate count, the rest in one part, in two, or in eighths: the same list as one
+    scan of the whole ROM -- plants at every edge a part can have, 16-bit with both alignments, a buffer that is too small,
+    a base offset, the caller's own tickets in between, sparse and dense keywords, and MMH_ROUTE_NO_SPLIT."""
     rng = np.random.default_rng(77)
-    for elem, kw, nbytes, be in ((1, "monkeybars", (2 << 30) + 524288 * 3 + 77, False), (2, "texts", (1 << 30) + 4098, True)):
-        n_el = nbytes // elem
+    for elem, kw, nbytes, be, nplants in ((1, "monkeybars", (2 << 30) + 524288 * 3 + 77, False, 60000), (2, "texts", (1 << 30) + 4098, True, 60000),
+                                          (1, "monkeybars", (3 << 30) + 99, False, 900000)):
         rom = rng.integers(0, 256, nbytes, dtype=np.uint8)
-        # ~60 K plants, among them some straddling the boundaries the pipeline cuts at (multiples of nblocks / parts blocks)
-        pos = np.sort(rng.choice((nbytes - 64) // 32, size=60000, replace=False)) * 32 + rng.integers(0, 16, 60000)
+        pos = np.sort(rng.choice((nbytes - 64) // 32, size=nplants, replace=False)) * 32 + rng.integers(0, 16, nplants)
         nblocks = -(-nbytes // BLOCK)
-        parts = max(2, nbytes >> 30)
-        edges = [nblocks * i // parts * BLOCK for i in range(1, parts)]
+        unit = max(-(-nblocks // 8), (256 << 20) // BLOCK)
+        left = max(nblocks - 4 * unit, 0)
+        cuts = {unit * i for i in range(1, 9)} | {4 * unit + -(-left // 2)}
+        edges = [b * BLOCK for b in sorted(cuts) if 0 < b < nblocks]
         pos = np.concatenate([pos, [e - 4 * elem for e in edges], [e - 1 - elem for e in edges], [e + elem for e in edges]]).astype(np.int64)
         vals = np.array([ord(c) for c in kw], np.int64)
-        for p in pos:
-            shift = int(rng.integers(0, 100))
-            for j, v in enumerate(vals):
-                x = int(v) + shift
-                if elem == 1:
-                    rom[p + j] = x
-                else:
-                    b = x.to_bytes(2, "big" if be else "little")
-                    rom[p + 2 * j], rom[p + 2 * j + 1] = b[0], b[1]
+        shift = rng.integers(0, 100, len(pos))
+        for j, v in enumerate(vals):
+            x = (int(v) + shift).astype(np.int64)
+            if elem == 1:
+                rom[pos + j] = x.astype(np.uint8)
+            else:
+                hi, lo = (x >> 8).astype(np.uint8), (x & 0xFF).astype(np.uint8)
+                rom[pos + 2 * j], rom[pos + 2 * j + 1] = (hi, lo) if be else (lo, hi)
         want = oracle_engine_parallel(oracle, oracle.plan(elem, kw), rom, BLOCK, be)
+        assert len(want) > nplants // 2
         plan = mm.plan_relative(elem, kw)
         with mm.Engine(0) as eng:
             eng.upload(rom)
-            first = eng.scan(plan, block_bytes=BLOCK, big_endian=be, cap=1 << 18)
-            assert first.tolist() == want.tolist() and eng.counters()["candidates"] >= 32768 and eng.counters()["path"] == 0, eng.counters()
             v0 = eng.health()["validated"]
-            again = eng.scan(plan, block_bytes=BLOCK, big_endian=be, cap=1 << 18)           # the split pipeline
-            assert again.tolist() == want.tolist()
-            assert eng.health()["validated"] - v0 == parts, (eng.health(), parts)          # one validated block per part
+            first = eng.scan(plan, block_bytes=BLOCK, big_endian=be, cap=1 << 20)             # the pipeline, from the first scan on
+            parts = eng.timings()["parts"]
+            assert first.tolist() == want.tolist() and eng.counters()["path"] == 0, eng.counters()
             assert eng.counters()["matches"] == len(want) and eng.counters()["candidates"] >= len(want)
+            expect = {(2 << 30) + 524288 * 3 + 77: 4, (1 << 30) + 4098: 3, (3 << 30) + 99: 6}[nbytes]   # 1 + 3 + two halves / 1 + 3 of 4 units + the rest / 1 + 3 + four eighths
+            assert parts == expect, eng.timings()
+            assert eng.health()["validated"] - v0 == parts, (eng.health(), parts)             # one validated block per part
+            eng.set_route(mm.ROUTE_NO_SPLIT)
+            assert eng.scan(plan, block_bytes=BLOCK, big_endian=be, cap=1 << 20).tolist() == want.tolist() and eng.timings()["parts"] == 0
+            eng.set_route(0)
             based = eng.scan(plan, block_bytes=BLOCK, big_endian=be, base_offset=1 << 40, cap=16)   # too small a buffer: twice through it
             assert (based - np.uint64(1 << 40)).tolist() == want.tolist()
             # tickets of the caller's own in between: the pipeline steps aside
             t = eng.submit(plan, block_bytes=BLOCK, big_endian=be)
-            assert eng.scan(plan, block_bytes=BLOCK, big_endian=be, cap=1 << 18).tolist() == want.tolist()
-            assert eng.collect(t, cap=1 << 18).tolist() == want.tolist()
-            # another keyword on the same ROM: sparse, scanned the usual way
+            assert eng.scan(plan, block_bytes=BLOCK, big_endian=be, cap=1 << 20).tolist() == want.tolist() and eng.timings()["parts"] == 0
+            assert eng.collect(t, cap=1 << 20).tolist() == want.tolist()
+            # another keyword on the same ROM: sparse -- two eighths, then the rest in one part
             other = mm.plan_relative(elem, "zqxjkvbwpy"[: len(kw)])
             sparse = eng.scan(other, block_bytes=BLOCK, big_endian=be)
             assert sparse.tolist() == oracle_engine_parallel(oracle, oracle.plan(elem, "zqxjkvbwpy"[: len(kw)]), rom, BLOCK, be).tolist()
+            assert eng.timings()["parts"] == 3, eng.timings()
+            # ... and scanned again: known to be sparse, two halves -- until the ROM changes
+            assert eng.scan(other, block_bytes=BLOCK, big_endian=be).tolist() == sparse.tolist() and eng.timings()["parts"] == 2, eng.timings()
+            eng.poke(5, rom[5:6])
+            assert eng.scan(other, block_bytes=BLOCK, big_endian=be).tolist() == sparse.tolist() and eng.timings()["parts"] == 3, eng.timings()
             assert eng.health()["fallbacks"] == 0
+
+
+def test_flood_in_a_part_takes_finer_parts_then_the_flood_paths(mm, oracle):
+    """A part of the pipeline whose bucketed store overflows gives the pipeline up: the scan starts over in parts a
+    sixteenth as wide (narrower buckets: the candidate path still does it), and a search that floods those as well goes the
+    whole-ROM way (list-based kernels, flood paths, forward engine) -- and is remembered, until the ROM changes."""
+    rng = np.random.default_rng(5)
+    nbytes = (1 << 30) + 524288 * 5
+    rom = rng.integers(0, 256, nbytes, dtype=np.uint8)
+    # script-like stretches: 'the' every 24 bytes in 40 stretches of 256 KiB (5461 candidates per 128 KiB, the bucket width of
+    # the first attempt's 256 MiB parts: too many; 2731 per 64 KiB: fine), and 2 MiB of constant padding ('aaa' floods anything)
+    text = np.frombuffer((b"the cat sat on a red mat" * (262144 // 24 + 1))[:262144], np.uint8)
+    for at in rng.choice((nbytes - (1 << 20)) // 262144, size=40, replace=False):
+        rom[at * 262144: at * 262144 + 262144] = text
+    rom[700 << 20: 702 << 20] = 0x41
+    with mm.Engine(0) as eng:
+        eng.upload(rom)
+        for kw, path_set in (("the", (0, 2)), ("aaa", (0, 2, 3, 4, 5))):
+            want = oracle_engine_parallel(oracle, oracle.plan(1, kw), rom, BLOCK)
+            got = eng.scan(mm.plan_relative(1, kw), block_bytes=BLOCK, cap=1 << 22)
+            assert got.tolist() == want.tolist() and len(want) > 100000
+            assert eng.counters()["path"] in path_set, (kw, eng.counters(), eng.timings())
+            if kw == "the":
+                assert eng.timings()["parts"] > 8, eng.timings()                            # the finer parts settled it
+            again = eng.scan(mm.plan_relative(1, kw), block_bytes=BLOCK, cap=1 << 22)       # (a flood: remembered, straight to the forward engine)
+            assert again.tolist() == want.tolist()
+        eng.poke(0, rom[:1])                                                                 # the ROM "changed": nothing is remembered
+        assert eng.scan(mm.plan_relative(1, "aaa"), block_bytes=BLOCK, cap=1 << 22).tolist() == want.tolist()
+        assert eng.health()["fallbacks"] == 0

@@ -21,6 +21,9 @@ eng = mm.Engine(0)
 eng.alloc(nbytes)
 mm.synth.RomSpec(42, nbytes, kw, elem, wc or None, be, 524288).apply_device(eng)
 plan = mm.plan_relative(elem, kw, wc)
+import numpy as np  # noqa: E402
+f = []
 for _ in range(scans):
     offs = eng.scan(plan, block_bytes=524288, big_endian=be)
-print(name, len(offs), "matches", eng.timings())
+    f.append(eng.timings()["filter_ms"])
+print(name, "%.2f GiB" % gib, len(offs), "matches; streaming kernel median %.4f ms over the last %d scans" % (float(np.median(f[len(f) // 2:])), len(f) - len(f) // 2), eng.timings())
