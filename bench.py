@@ -268,7 +268,7 @@ def measure_pmc_traffic(kernel):
     if not os.path.exists(exe):
         return None, "rocprofv3 not found: not measured in this run"
     child = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--depth", "1", "--no-cpu-baseline",
-             "--no-other-depth", "--no-other-configs", "--no-strong", "--no-read-probe", "--no-pmc", "--prewarm-s", "0.05"]
+             "--no-other-depth", "--no-other-configs", "--no-strong", "--no-read-probe", "--no-pmc", "--no-split", "--prewarm-s", "0.05"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     env["TMPDIR"] = "/tmp"
     got = {}
@@ -294,13 +294,14 @@ def measure_pmc_traffic(kernel):
     return 2 * fetch[0] + write[0], (
         "counted in this run: rocprofv3 --pmc FETCH_SIZE (%d launches of %s, %.0f bytes each, doubled per the gfx950 rule) and "
         "--pmc WRITE_SIZE (%d launches, %.0f bytes each) around two child runs of this script (--steps 3 --depth 1, the same "
-        "4 GiB ROM and keyword), started before this process touched the GPU" % (fetch[1], kernel, fetch[0], write[1], write[0]))
+        "4 GiB ROM and keyword, --no-split: every launch covers the whole ROM), started before this process touched the GPU" % (
+            fetch[1], kernel, fetch[0], write[1], write[0]))
 
 
 def pmc_traffic(mm, shard):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes -- only when they were taken
     with THIS device code (the summary carries the hash of the library's sources), else null."""
-    for name in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
+    for name in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -676,6 +677,13 @@ def main():
     # needs a few tens of ms of sustained load before its memory/fabric clocks are back up --
     # the first ~20 scans run ~12 % slower than steady state.  Scan until PREWARM_S have
     # passed, then do the W warm-up steps and the K timed steps of the contract.
+    launches_by_phase = []                                  # (phase, launches of the streaming kernel): tools/summarize_profiles.py cuts the kernel trace by it
+
+    def phase(name, _seen=[0]):
+        v = eng.health()["validated"]                        # one validated block per polled launch pair (streaming + tail kernel)
+        launches_by_phase.append((name, v - _seen[0]))
+        _seen[0] = v
+    phase("set-up")
     t_pre = time.perf_counter()
     prewarm_scans = 0
     while time.perf_counter() - t_pre < args.prewarm_s:
@@ -686,13 +694,16 @@ def main():
         # measured with one rank, the first ~10 gathered steps cost 0.1 ms more each than the steady state)
         run_steps(max(12, args.warmup), args.depth)
         prewarm_scans += max(12, args.warmup)
+    phase("pre-warm")
     run_steps(args.warmup, args.depth)
     fence()
+    phase("warm-up, %d ticket(s) outstanding" % args.depth)
     del gather_dev_ms[:], gather_host_ms[:]
     t0 = time.perf_counter()
     offs = run_steps(args.steps, args.depth)             # the last collect / gather belongs to the timed region
     fence()
     elapsed = time.perf_counter() - t0
+    phase("TIMED steps, %d ticket(s) outstanding" % args.depth)
     # HIP-event timings of the timed steps: recorded on the scan's stream during the steps,
     # read back afterwards (the library keeps the timings of the last 64 scans)
     filt_ms, tot_ms = eng.timing_history(min(args.steps, 64))
@@ -706,10 +717,13 @@ def main():
         run_steps(max(args.warmup, 4), other_depth)
         fence()
         t1 = time.perf_counter()
+        phase("warm-up of the other leg")
         offs_other = run_steps(args.steps, other_depth)
         fence()
         elapsed_other = time.perf_counter() - t1
         filt_other, tot_other = eng.timing_history(min(args.steps, 64))
+        other_parts = eng.timings().get("parts", 0)
+        phase("other leg, %d ticket(s) outstanding" % other_depth)
     # The dominant kernel with the device to itself, ONE launch over the whole shard (MMH_ROUTE_NO_SPLIT: a synchronous scan
     # of a ROM of >= 1 GiB otherwise runs as a pipeline of parts whose kernels overlap): what `roofline` prices.
     def alone_scans(k, at=None):
@@ -724,6 +738,7 @@ def main():
     fence()
     kernel_alone_filt, kernel_alone_tot = alone_scans(min(max(args.steps, 16), 64))
     fence()
+    phase("the kernel alone: one launch over the whole shard per scan")
     # N > 1, after the timed region: the library's gather against the torch.distributed double on one more
     # scan of every rank -- the first place the native collective meets a real second rank
     gather_check = None
@@ -892,6 +907,7 @@ def main():
                          "inside the timed region, %d tickets outstanding (two scans at work on the device)" % args.depth
                          if args.depth > 1 else "mmh_scan: every step waits for its own result"),
                 "prewarm_scans": prewarm_scans,
+                "launches_by_phase": launches_by_phase,
                 **({"host_delay_us": args.host_delay_us} if args.host_delay_us > 0 else {}),
             },
             "roofline": {
@@ -971,7 +987,7 @@ def main():
             res["in_flight" if other_depth > 1 else "synchronous"] = {
                 "value": total * args.steps / elapsed_other / 1e9, "unit": "GB/s", "ms_per_step": elapsed_other / args.steps * 1e3,
                 "kernel_ms": float(np.mean(filt_other)), "scan_device_ms": float(np.mean(tot_other)),
-                "parts": eng.timings().get("parts", 0) if other_depth == 1 else 0,
+                "parts": other_parts if other_depth == 1 else 0,
                 "kernel_ms_is": ("the streaming kernels of the scan's parts SUMMED (they overlap: mmh_scan runs a ROM of >= 1 GiB as a pipeline "
                                  "of parts), scan_device_ms = the pipeline's wall time on the host" if other_depth == 1 and not args.no_split and shard >= (1 << 30)
                                  else "HIP events on the scan's own launches"),

@@ -91,6 +91,8 @@ struct MmGatherSlot {
    uint64_t merged_cap = 0;         // offsets h_merged has room for
    hipEvent_t begin = nullptr, end = nullptr;
    bool busy = false;
+   uint32_t limit = 0;              // offsets (or slots) a record of THIS gather holds: 1016 (8 KiB per rank) or 16384 (128 KiB)
+   uint64_t last_longest = ~0ull;   // the longest extent over all ranks the slot's previous gather saw (~0: none yet)
    bool from_host = false;          // the local list came from host memory (long lists, forward engine)
    const uint64_t *src = nullptr;   // else: the device-side result copy (of the scan's workspace) it sends
    uint64_t local_count = 0;        // this rank's list length

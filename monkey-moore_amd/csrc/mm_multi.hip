@@ -44,7 +44,15 @@
 
 namespace {
 
-constexpr uint64_t kRecordWords = MM_RESULT_HEADER_WORDS + MM_MAX_RANK_SORT;   // what a scan leaves in HBM, sent as it is
+constexpr uint64_t kRecordWords = MM_RESULT_HEADER_WORDS + MM_MAX_RANK_SORT;   // the widest record: what a scan leaves in HBM, sent as it is
+// The record's width follows the lists (round 5): every rank learns every rank's extent from the table a gather
+// delivers, and a gather slot is only reused once its previous gather has been finished ON EVERY RANK (two slots, at most
+// two gathers outstanding, finished oldest first) -- so "the longest extent this slot saw last time" is a number all ranks
+// agree on without further traffic.  While it stays below four fifths of a narrow record the next gather of the slot sends
+// 8 KiB per rank instead of 128 KiB (one ROM dealt over eight GPUs: ~530 offsets per rank, 64 KiB instead of 1 MiB received
+// per rank and gather over xGMI); a list that does not fit the width in use takes the second, padded phase as ever.
+constexpr uint32_t kNarrowSlots = 1024 - MM_RESULT_HEADER_WORDS;            // 1016 offsets, 8 KiB per rank
+constexpr uint32_t kNarrowKeep = kNarrowSlots * 4 / 5;
 constexpr int kMaxRanks = 64;
 constexpr uint64_t kMergedHeader = 8 + kMaxRanks;     // [total, longest, nranks, long flag, ...][count of every rank]
 
@@ -234,6 +242,8 @@ int comm_buffers(mmh_ctx *c)
          HIP_TRY(hipEventCreate(&s.end));
       }
       s.busy = false;
+      s.limit = MM_MAX_RANK_SORT;
+      s.last_longest = ~0ull;                         // (nothing seen yet: the wide record)
    }
    m.turn = m.oldest = 0;
    return MMH_OK;
@@ -389,6 +399,8 @@ int gather_prepare(mmh_ctx *c, const uint64_t *offsets, uint64_t n, const uint64
    }
    HIP_TRY(hipSetDevice(c->device));
    const double t0 = now_s();
+   static const bool adaptive = [] { const char *e = getenv("MMOORE_GATHER_NARROW"); return !(e && *e == '0'); }();
+   s.limit = adaptive && s.last_longest <= kNarrowKeep ? kNarrowSlots : (uint32_t)MM_MAX_RANK_SORT;
    s.from_host = true;
    s.kept = false;                                  // (of the slot's previous gather)
    if (!offsets && n == 0) {
@@ -406,7 +418,7 @@ int gather_prepare(mmh_ctx *c, const uint64_t *offsets, uint64_t n, const uint64
          // (wait_for_gather_reading in mm_capi.hip), and a scan that retries, the scan after next or a second
          // outstanding gather publish into it again before this gather is finished.
          const uint64_t extent = std::max(m.last_count, m.last_slots);
-         s.kept = extent > MM_MAX_RANK_SORT;
+         s.kept = extent > s.limit;
          if (s.kept) {
             const uint64_t words = MM_RESULT_HEADER_WORDS + std::min<uint64_t>(extent, MM_MAX_PUBLISH);
             if (words > s.keep_cap) {
@@ -429,12 +441,12 @@ int gather_prepare(mmh_ctx *c, const uint64_t *offsets, uint64_t n, const uint64
    HIP_TRY(hipEventRecord(s.begin, m.stream));
    if (s.from_host) {
       s.local_count = n;
-      if (n && n <= MM_MAX_RANK_SORT) {
+      if (n && n <= s.limit) {
          HIP_TRY(hipMemcpyAsync(m.d_send + MM_RESULT_HEADER_WORDS, offsets, n * sizeof(uint64_t), hipMemcpyHostToDevice, m.stream));
       }
       hipLaunchKernelGGL(mm_gather_stamp, dim3(1), dim3(64), 0, m.stream, m.d_send, n);
       HIP_TRY(hipGetLastError());
-      if (n > MM_MAX_RANK_SORT) {
+      if (n > s.limit) {
          s.host_list.assign(offsets, offsets + n);      // the second phase sends it from here, whatever scans run in between
       }
       else {
@@ -451,7 +463,7 @@ int gather_collective(mmh_ctx *c, const uint64_t *send)
 {
    MmComm &m = c->mg;
    MmGatherSlot &s = m.slot[m.turn];
-   NCCL_TRY(ncclAllGather(send, s.d_table, kRecordWords, ncclUint64, static_cast<ncclComm_t>(m.comm), m.stream));
+   NCCL_TRY(ncclAllGather(send, s.d_table, MM_RESULT_HEADER_WORDS + (uint64_t)s.limit, ncclUint64, static_cast<ncclComm_t>(m.comm), m.stream));
    return MMH_OK;
 }
 
@@ -462,8 +474,8 @@ int gather_pack(mmh_ctx *c, int want_list)
    MmGatherSlot &s = m.slot[m.turn];
    HIP_TRY(hipSetDevice(c->device));
    const double t0 = now_s();
-   hipLaunchKernelGGL(mm_gather_pack, dim3((unsigned)m.nranks), dim3(256), 0, m.stream, s.d_table, (uint32_t)m.nranks, kRecordWords,
-                      s.h_merged, s.merged_cap, want_list ? 1u : 0u, (uint32_t)MM_MAX_RANK_SORT);
+   hipLaunchKernelGGL(mm_gather_pack, dim3((unsigned)m.nranks), dim3(256), 0, m.stream, s.d_table, (uint32_t)m.nranks,
+                      MM_RESULT_HEADER_WORDS + (uint64_t)s.limit, s.h_merged, s.merged_cap, want_list ? 1u : 0u, s.limit);
    HIP_TRY(hipGetLastError());
    HIP_TRY(hipEventRecord(s.end, m.stream));
    s.busy = true;
@@ -498,7 +510,7 @@ int long_prepare(mmh_ctx *c, MmGatherSlot &s, uint64_t longest)
       // (a host list that fitted its record -- ANOTHER rank's list is the long one -- was not kept on the host: it sits in
       // this rank's record of the gathered table like a short device list.  Found by the first run with two ranks:
       // round 4 kept no such list and failed here with "lost its host list".)
-      if (s.from_host && s.local_count > MM_MAX_RANK_SORT) {
+      if (s.from_host && s.local_count > s.limit) {
          if (s.host_list.size() != s.local_count) {
             mmh_set_error("mmh_gather_finish: the gather slot lost its host list (internal error)");
             return MMH_E_STATE;
@@ -511,7 +523,7 @@ int long_prepare(mmh_ctx *c, MmGatherSlot &s, uint64_t longest)
          // scans may have published into since the first phase ended: a long list was copied to the slot's own buffer
          // then, a short one sits intact in this rank's record of the table the first phase gathered.  It may have
          // holes (one slot per candidate): the packing kernel on that one block leaves the list behind a header nobody reads.
-         const uint64_t *block = s.kept ? s.d_keep : s.d_table + (uint64_t)m.rank * kRecordWords;
+         const uint64_t *block = s.kept ? s.d_keep : s.d_table + (uint64_t)m.rank * (MM_RESULT_HEADER_WORDS + (uint64_t)s.limit);
          hipLaunchKernelGGL(mm_gather_pack, dim3(1), dim3(256), 0, m.stream, block, 1u, (uint64_t)MM_RESULT_BLOCK_WORDS,
                             m.d_long, longest, 1u, (uint32_t)MM_MAX_PUBLISH);
          HIP_TRY(hipGetLastError());
@@ -573,7 +585,7 @@ int wait_collective(MmComm &m, hipEvent_t done)
    }
 }
 
-// wait for the first phase of the oldest gather; *longest > MM_MAX_RANK_SORT: second phase needed
+// wait for the first phase of the oldest gather; *longest > the slot's record limit: second phase needed
 int gather_wait(mmh_ctx *c, uint64_t *total, uint64_t *longest)
 {
    MmComm &m = c->mg;
@@ -589,6 +601,7 @@ int gather_wait(mmh_ctx *c, uint64_t *total, uint64_t *longest)
    }
    *total = s.h_merged[0];
    *longest = s.h_merged[1];
+   s.last_longest = *longest;                       // (what the slot's NEXT gather sizes its record by: the same on every rank)
    return MMH_OK;
 }
 
@@ -604,7 +617,7 @@ int gather_deliver(mmh_ctx *c, uint64_t *out, uint64_t cap, uint64_t *out_count,
                     (unsigned long long)total, (unsigned long long)cap);
       return MMH_E_CAPACITY;                         // the gather stays outstanding
    }
-   if (longest > MM_MAX_RANK_SORT) {
+   if (longest > s.limit) {
       if (out) {
          uint64_t at = 0;
          for (int r = 0; r < m.nranks; r++) {
@@ -668,7 +681,7 @@ extern "C" int mmh_gather_finish(mmh_ctx *c, uint64_t *out, uint64_t cap, uint64
       return rc;
    }
    MmGatherSlot &s = c->mg.slot[c->mg.oldest];
-   if (longest > MM_MAX_RANK_SORT && !(out && total > cap)) {
+   if (longest > s.limit && !(out && total > cap)) {
       // some rank's list did not fit its record: every rank saw that in the table it received,
       // so all of them are here now -- the whole lists, padded to the longest
       rc = long_prepare(c, s, longest);
@@ -827,7 +840,7 @@ extern "C" int mmh_scan_multi(mmh_ctx *const *ctxs, int n, const mmh_plan_desc *
       }
    }
    const bool fits = !(out && total > cap);
-   if (longest > MM_MAX_RANK_SORT && fits) {
+   if (longest > ctxs[0]->mg.slot[ctxs[0]->mg.oldest].limit && fits) {
       for (int i = 0; i < n; i++) {
          int rc = long_prepare(ctxs[i], ctxs[i]->mg.slot[ctxs[i]->mg.oldest], longest);
          if (rc != MMH_OK) {

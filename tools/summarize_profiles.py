@@ -55,6 +55,10 @@ def by_phase():
     phases = [("prewarm, one scan at a time", pre), ("warm-up, %d ticket(s) outstanding" % depth, W),
               ("TIMED steps, %d ticket(s) outstanding" % depth, K),
               ("warm-up of the other leg", max(W, 4)), ("other leg, %d ticket(s) outstanding" % (1 if depth > 1 else 3), K)]
+    if b["config"].get("launches_by_phase"):
+        # round 5: bench.py counts the streaming launches of every phase itself (a synchronous scan of a big ROM is a
+        # pipeline of parts: more than one launch per scan)
+        phases = [(name, int(n)) for name, n in b["config"]["launches_by_phase"]]
     res, at = {"launches_of_the_streaming_kernel": len(filt), "phases": []}, 0
     for name, n in phases:
         f, t = filt[at:at + n], tail[at:at + n]
@@ -107,8 +111,8 @@ summary = {
     # bench.py reports `roofline.traffic` from this file only while the library's sources are THESE
     "device_source_sha16": device_source_sha16(),
     "library_sha16": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16],
-    "command_fetch": "rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 3 --warmup 1 --depth 1 --no-cpu-baseline --no-other-depth --no-other-configs --no-strong --no-read-probe --prewarm-s 0.05",
-    "command_write": "rocprofv3 --pmc WRITE_SIZE --output-format csv -- python3 bench.py --steps 3 --warmup 1 --depth 1 --no-cpu-baseline --no-other-depth --no-other-configs --no-strong --no-read-probe --prewarm-s 0.05",
+    "command_fetch": "rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 3 --warmup 1 --depth 1 --no-split --no-cpu-baseline --no-other-depth --no-other-configs --no-strong --no-read-probe --prewarm-s 0.05",
+    "command_write": "rocprofv3 --pmc WRITE_SIZE --output-format csv -- python3 bench.py --steps 3 --warmup 1 --depth 1 --no-split --no-cpu-baseline --no-other-depth --no-other-configs --no-strong --no-read-probe --prewarm-s 0.05",
     "note": "separate --pmc passes; counters are in KiB; per MI355X_MICROARCH.md gfx950 FETCH_SIZE reports half of the bytes of a "
             "wide coalesced (16 B/lane) streaming read, so the read side is doubled; WRITE_SIZE is exact "
             "(calibration: mm_synth_fill writes the whole ROM and reports exactly its size)",
