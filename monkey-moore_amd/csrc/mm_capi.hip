@@ -145,11 +145,11 @@ int ensure_workspace(mmh_ctx *c, MmWorkspace &w, uint64_t out_cap)
       HIP_TRY(hipMalloc(&w.d_ctrl, mm::ctrl_bytes()));
       HIP_TRY(hipMalloc(&w.d_mid_off, mm::mid_cap() * sizeof(uint64_t)));
       HIP_TRY(hipMalloc(&w.d_mid_hi, mm::mid_cap() * sizeof(uint64_t)));
-      HIP_TRY(hipMalloc(&w.d_mid_set, mm::mid_cap() * sizeof(uint32_t)));
+      HIP_TRY(hipMalloc(&w.d_mid_set, mm::mid_cap() * sizeof(uint64_t)));
       HIP_TRY(hipMalloc(&w.d_mid_slot, mm::mid_cap() * sizeof(uint32_t)));
       HIP_TRY(hipMalloc(&w.d_hard_off, mm::hard_cap() * sizeof(uint64_t)));
       HIP_TRY(hipMalloc(&w.d_hard_hi, mm::hard_cap() * sizeof(uint64_t)));
-      HIP_TRY(hipMalloc(&w.d_hard_set, mm::hard_cap() * sizeof(uint32_t)));
+      HIP_TRY(hipMalloc(&w.d_hard_set, mm::hard_cap() * sizeof(uint64_t)));
       HIP_TRY(hipMalloc(&w.d_hard_slot, mm::hard_cap() * sizeof(uint32_t)));
       HIP_TRY(hipMalloc(&w.d_scratch, mm::hard_scratch_bytes()));
       HIP_TRY(hipMalloc(&w.d_partials, mm::rank_partials_bytes(kMaxRankSort)));

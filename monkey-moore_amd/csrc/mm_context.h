@@ -39,11 +39,11 @@ struct MmWorkspace {
    unsigned long long *d_ctrl = nullptr;   // counters + arrival tickets, zeroed per scan (mm::ResolveBuffers)
    uint64_t *d_mid_off = nullptr;   // hand-over list mm_resolve -> mm_resolve2
    uint64_t *d_mid_hi = nullptr;
-   uint32_t *d_mid_set = nullptr;
+   uint64_t *d_mid_set = nullptr;
    uint32_t *d_mid_slot = nullptr;
    uint64_t *d_hard_off = nullptr;
    uint64_t *d_hard_hi = nullptr;
-   uint32_t *d_hard_set = nullptr;
+   uint64_t *d_hard_set = nullptr;
    uint32_t *d_hard_slot = nullptr;
    uint8_t *d_scratch = nullptr;    // tile maps of hard candidates
    uint32_t *d_partials = nullptr;  // rank sort partial counts

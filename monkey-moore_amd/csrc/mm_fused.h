@@ -71,7 +71,7 @@ struct MmFusedArgs {
    uint32_t max_candidates;
    uint64_t *mid_off;
    uint64_t *mid_hi;
-   uint32_t *mid_set;
+   mm_set_t *mid_set;
    uint32_t *mid_slot;
    unsigned int *mid_count;
    uint32_t *flag_bits;                // always null here
@@ -260,7 +260,7 @@ __device__ __forceinline__ void mm_scan_tail_phase(const MmFusedArgs &a, const M
             T.smaller[wave] = 0;
          }
          int verdict = 0;
-         int64_t hi = 0; uint32_t set = 0; uint64_t dom = 0;
+         int64_t hi = 0; mm_set_t set = 0; uint64_t dom = 0;
          if (live) {
             verdict = mm_resolve_candidate(a, P, Wv[wave], o, lane, &walked, &hi, &set, &dom);
          }

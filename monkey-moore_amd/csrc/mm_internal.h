@@ -37,8 +37,9 @@ struct MmGeom {
 };
 
 // keywords longer than this never take the streaming filter + per-candidate resolvers (their phase
-// sets are one 32-bit word, their stored phase maps 32 bytes): they run on the forward engine
-constexpr uint32_t MM_RESOLVER_MAX_KEYWORD = 32;
+// sets are one 64-bit word -- one bit per lane of a wave --, their stored phase maps 64 bytes): they run on the forward
+// engine.  (32 until round 5: 32-bit sets, although a map always had a lane per phase.)
+constexpr uint32_t MM_RESOLVER_MAX_KEYWORD = 64;
 
 // layout of the block a scan publishes (pinned host memory and its device-side copies):
 // MM_RESULT_HEADER_WORDS counters, then the ordered matches.  Header words: [0] candidates (= result

@@ -54,11 +54,11 @@ struct ResolveBuffers {
    unsigned long long *ctrl;
    uint64_t *mid_off;        // [mid_cap()] hand-over list mm_resolve -> mm_resolve2
    uint64_t *mid_hi;
-   uint32_t *mid_set;
+   uint64_t *mid_set;                         // (mm_set_t: 64-bit phase sets)
    uint32_t *mid_slot;
    uint64_t *hard_off;       // [hard_cap()] hand-over list mm_resolve2 -> mm_hard_resolve
    uint64_t *hard_hi;
-   uint32_t *hard_set;
+   uint64_t *hard_set;
    uint32_t *hard_slot;
    uint8_t *scratch;
    // bucketed candidate store (mm_internal.h MM_BUCKET_*), zeroed by mm_scan_tail2's last workgroup

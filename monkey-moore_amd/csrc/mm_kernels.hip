@@ -222,7 +222,7 @@ __device__ __forceinline__ bool mm_is_candidate(const MmGeom &g, const mmh_plan_
 struct MmTileArgs {
    MmGeom g;
    mmh_plan_desc plan;
-   uint32_t inv_d;          // ceil(65536 / D): x / D == (x * inv_d) >> 16 for x < 2100
+   uint32_t inv_d;          // ceil(2^20 / D): x / D == (x * inv_d) >> 20 for x < 4096
    uint32_t inv_d32;        // floor(2^32 / D) + 1: quotient estimate for 32-bit x, at most one too big
    uint32_t block_shift;    // log2(block_bytes) when that is a power of two, else ~0
    uint64_t skip_bloom;     // bit (d & 63) set for every listed bad-character diff
@@ -1930,7 +1930,7 @@ static MmTileArgs tile_args(const MmGeom &g, const mmh_plan_desc &pl)
    MmTileArgs t{};
    t.g = g; t.plan = pl;
    const uint32_t D = pl.L - 1;
-   t.inv_d = (65536u + D - 1) / D;
+   t.inv_d = ((1u << 20) + D - 1) / D;
    t.inv_d32 = (uint32_t)((1ull << 32) / D) + 1u;
    t.block_shift = ~0u;
    if (g.block_bytes && (g.block_bytes & (g.block_bytes - 1)) == 0) {
@@ -1987,7 +1987,7 @@ void launch_leftovers(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, 
    hipLaunchKernelGGL(mm_hard_resolve, dim3(MM_HARD_PARTS, MM_HARD_CAP), dim3(64 * MM_WAVES), 0, st, h);
 }
 
-size_t hard_scratch_bytes() { return (size_t)MM_HARD_CAP * MM_HARD_MAX_TILES * MM_MAXD; }
+size_t hard_scratch_bytes() { return (size_t)MM_HARD_CAP * MM_HARD_MAX_TILES * MM_RMAXD; }
 size_t hard_cap() { return MM_HARD_CAP; }
 size_t mid_cap() { return MM_MID_CAP; }
 size_t ctrl_bytes() { return MM_CTRL_WORDS * sizeof(uint64_t); }

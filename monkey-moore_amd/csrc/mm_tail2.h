@@ -299,7 +299,7 @@ __global__ __launch_bounds__(64 * MM_WAVES, OCC) void mm_scan_tail2(MmFusedArgs 
             }
             walked++;
             int verdict = verdicts[k];
-            int64_t hi = 0; uint32_t set = 0; uint64_t dom = 0;
+            int64_t hi = 0; mm_set_t set = 0; uint64_t dom = 0;
             if (verdict == MM_SUB_AGAIN) {
                verdict = mm_resolve_candidate(a, P, Wv[wave], o[k], lane, &walked, &hi, &set, &dom);
             }
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(64 * MM_WAVES, OCC) void mm_scan_tail2(MmFusedArgs 
             const unsigned long long mk = k < members ? mem[k] : ~0ull;
             rank += (uint32_t)__popcll(__ballot(mk < o));
          }
-         int64_t hi = 0; uint32_t set = 0; uint64_t dom = 0;
+         int64_t hi = 0; mm_set_t set = 0; uint64_t dom = 0;
          const int verdict = mm_resolve_candidate(a, P, Wv[wave], o, lane, &walked, &hi, &set, &dom);
          if (lane == 0) {
             const uint64_t value = verdict == 1 ? mm_report_value(a.t.g, o, a.base_offset) : MM_NO_MATCH;

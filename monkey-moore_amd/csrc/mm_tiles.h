@@ -43,8 +43,10 @@
 
 constexpr int MM_TILE = 2048;                 // positions per tile
 constexpr int MM_WAVES = 4;                   // waves per workgroup in the tile kernels
-constexpr int MM_MAXD = MM_RESOLVER_MAX_KEYWORD;   // bytes of a stored phase map in the per-candidate machinery: keywords of up to 32
-                                              // symbols (D <= 31, phase sets in one 32-bit word); longer ones go to the forward engine
+constexpr int MM_MAXD = 32;                   // bytes of a stored phase map of the forward engine's narrow instantiation (keywords of up to 32 symbols)
+constexpr int MM_RMAXD = MM_RESOLVER_MAX_KEYWORD;   // ... and in the per-candidate machinery: keywords of up to 64 symbols (D <= 63, a phase
+                                              // set is one 64-bit word = a ballot over the map's lanes); longer ones go to the forward engine
+typedef uint64_t mm_set_t;                    // a set of phases
 constexpr int MM_FAST_STEPS = 3;              // look-back windows of the per-candidate resolver: 64 (128 for keywords beyond 16 symbols),
                                               // then 256, then 512 positions
 constexpr int MM_MID_CHUNK = 512;             // mm_resolve2: a workgroup's waves map chunks of this many positions in parallel
@@ -72,7 +74,7 @@ struct MmWaveLdsT {
    uint32_t tile[((NPOS + MMH_MAX_KEYWORD + 1) * ELEM + 16 + 3) / 4];
    uint8_t jump[NPOS + 8];                   // J of every position of the window (| MM_JUMP_MATCH); the forward engine
                                              // stores four at a time and shifts the array by 0..3 bytes for that
-   uint8_t gmap[NPOS / 64][MM_MAXD];         // phase map of every group of 64 positions (long windows)
+   uint8_t gmap[NPOS / 64][MM_RMAXD];        // phase map of every group of 64 positions (long windows)
    uint8_t gentry[NPOS / 64];                // forward engine: the chain's phase on entering each group
 };
 using MmWaveLds = MmWaveLdsT<MM_TILE>;       // whole tiles: hard resolver, forward engine
@@ -186,10 +188,12 @@ __device__ __forceinline__ int mm_tile_skip(const MmTileArgs &a, const MmPlanLds
    return s;
 }
 
-// x mod D for x < 2100 without a division
+// x mod D for x < 4096 without a division: inv_d = ceil(2^20 / D) is exact while x (inv_d D - 2^20) < 2^20, i.e. for
+// x < 2^20 / 126 whatever D <= 127 (and x inv_d < 2^32).  (Until round 5: ceil(2^16 / D), exact for x < 2100 only while
+// D <= 31 -- with the resolvers' keywords of up to 64 symbols a 2048-position tile of the hard resolver came out wrong.)
 __device__ __forceinline__ uint32_t mm_modd(const MmTileArgs &a, uint32_t x)
 {
-   return x - ((x * a.inv_d) >> 16) * (a.plan.L - 1);
+   return x - ((x * a.inv_d) >> 20) * (a.plan.L - 1);
 }
 
 // x mod D for any x (domain positions): a multiply for 32-bit values, the division only beyond
@@ -334,9 +338,9 @@ __device__ __forceinline__ void mm_group_maps(const MmTileArgs &a, WL &W, int np
    J = J ? J : W.jump;
    const uint32_t D = a.plan.L - 1;
    const uint32_t ngroups = (uint32_t)(npos + 63) >> 6;
-   const uint32_t ntasks = ngroups * D;                        // <= 32 * 31
+   const uint32_t ntasks = ngroups * D;                        // <= 32 * 63
    for (uint32_t task = (uint32_t)lane; task < ntasks; task += 64) {
-      const uint32_t g = (task * a.inv_d) >> 16;                // task / D
+      const uint32_t g = (task * a.inv_d) >> 20;                // task / D
       const uint32_t e = task - g * D;
       const uint32_t first = 64 * g;
       const uint32_t end = first + 64 < (uint32_t)npos ? first + 64 : (uint32_t)npos;
@@ -398,10 +402,13 @@ __device__ __forceinline__ uint32_t mm_tile_map(const MmTileArgs &a, const MmPla
 }
 
 // A' = { e < D : map[e] in A }; `map` is the per-lane value mm_tile_map returned
-__device__ __forceinline__ uint32_t mm_pull_back(uint32_t A, uint32_t D, uint32_t map, int lane)
+__device__ __forceinline__ mm_set_t mm_pull_back(mm_set_t A, uint32_t D, uint32_t map, int lane)
 {
-   return (uint32_t)__ballot((uint32_t)lane < D && ((A >> map) & 1u) != 0);
+   return (mm_set_t)__ballot((uint32_t)lane < D && ((A >> map) & 1ull) != 0);
 }
+
+// all D phases
+__device__ __forceinline__ mm_set_t mm_full_set(uint32_t D) { return D >= 64 ? ~0ull : ((1ull << D) - 1ull); }
 
 // --------------------------------------------------------------------------
 // fast resolver: one wave per candidate, bounded look-back
@@ -424,7 +431,7 @@ struct MmResolveArgs {
    // candidates the two short windows could not settle, for mm_resolve2
    uint64_t *mid_off;                         // [MM_MID_CAP] candidate byte offset
    uint64_t *mid_hi;                          // [MM_MID_CAP] frontier (domain position)
-   uint32_t *mid_set;                         // [MM_MID_CAP] acceptable phases at the frontier
+   mm_set_t *mid_set;                         // [MM_MID_CAP] acceptable phases at the frontier
    uint32_t *mid_slot;                        // [MM_MID_CAP] the candidate's result slot
    unsigned int *mid_count;
    // Flag pass (after a scan whose left-over lists overflowed): instead of handing undecided
@@ -492,10 +499,10 @@ __device__ __forceinline__ uint64_t mm_candidate(const A &a, unsigned long long 
 // where the pull-back stands, for mm_resolve2; *dom: its domain), -2 not an alignment of any domain.
 template <class A, class WL>
 __device__ __forceinline__ int mm_resolve_candidate(const A &a, const MmPlanLds &P, WL &W, uint64_t o, int lane,
-                                                    unsigned long long *walked, int64_t *hi_out, uint32_t *set_out, uint64_t *dom_out)
+                                                    unsigned long long *walked, int64_t *hi_out, mm_set_t *set_out, uint64_t *dom_out)
 {
    const uint32_t D = a.t.plan.L - 1;
-   const uint32_t full = D >= 32 ? 0xFFFFFFFFu : ((1u << D) - 1u);
+   const mm_set_t full = mm_full_set(D);
    uint64_t b; uint32_t p; int64_t jc;
    if (!mm_locate_fast(a.t, o, &b, &p, &jc)) {
       return -2;                               // SWAR survivor that is not an alignment of any domain (file tail, 16-bit odd boundary)
@@ -503,7 +510,7 @@ __device__ __forceinline__ int mm_resolve_candidate(const A &a, const MmPlanLds 
    const uint64_t start = mm_domain_start(a.t.g, b, p);
    *dom_out = a.t.g.whole ? 0 : b * a.t.g.S + p;
 
-   uint32_t S = 1u << mm_modd64(a.t, (uint64_t)jc);
+   mm_set_t S = 1ull << mm_modd64(a.t, (uint64_t)jc);
    int64_t hi = jc;
    int verdict = -1;                           // 1 visited, 0 not visited, -1 undecided
    if (jc == 0) {
@@ -519,7 +526,7 @@ __device__ __forceinline__ int mm_resolve_candidate(const A &a, const MmPlanLds 
    // instead of up to four (round 2 started with an aligned window of up to 256 positions: at 64 K candidates the
    // tail kernel was bound by the instructions of that loop).
    for (int step = 0; step < MM_FAST_STEPS && hi > 0 && verdict < 0; step++) {
-      const int64_t size = step == 0 ? (a.t.plan.L <= 16 ? 64 : 128) : (int64_t)128 << step;
+      const int64_t size = step == 0 ? (a.t.plan.L <= 16 ? 64 : a.t.plan.L <= 32 ? 128 : 256) : (int64_t)128 << step;
       const int64_t lo = hi > size ? hi - size : 0;
       bool is_match = true;
       const uint32_t map = mm_tile_map(a.t, P, W, start, lo, (int)(hi - lo), mm_modd64(a.t, (uint64_t)lo), lane,
@@ -537,7 +544,7 @@ __device__ __forceinline__ int mm_resolve_candidate(const A &a, const MmPlanLds 
       }
    }
    if (verdict < 0 && hi == 0) {
-      verdict = (S & 1u) ? 1 : 0;              // domain start: the chain is in phase 0
+      verdict = (S & 1ull) ? 1 : 0;            // domain start: the chain is in phase 0
    }
    *hi_out = hi;
    *set_out = S;
@@ -547,7 +554,7 @@ __device__ __forceinline__ int mm_resolve_candidate(const A &a, const MmPlanLds 
 // lane 0 of the wave that could not settle candidate ci: hand it to mm_resolve2 (or, in the flag
 // pass, mark its domain)
 template <class A>
-__device__ __forceinline__ void mm_resolve_hand_over(const A &a, uint64_t o, uint64_t ci, int64_t hi, uint32_t set, uint64_t dom)
+__device__ __forceinline__ void mm_resolve_hand_over(const A &a, uint64_t o, uint64_t ci, int64_t hi, mm_set_t set, uint64_t dom)
 {
    if (a.flag_bits) {
       atomicOr(&a.flag_bits[dom >> 5], 1u << (dom & 31));
@@ -580,7 +587,7 @@ __device__ __forceinline__ void mm_resolve_body(const MmResolveArgs &a, const Mm
    for (uint64_t ci = (uint64_t)blockIdx.x * MM_WAVES + wave; ci < ncand; ci += nwaves) {
       // wave uniform from here on: the index arithmetic below runs on the scalar unit
       const uint64_t o = mm_candidate(a, excl, ci);
-      int64_t hi = 0; uint32_t set = 0; uint64_t dom = 0;
+      int64_t hi = 0; mm_set_t set = 0; uint64_t dom = 0;
       const int verdict = mm_resolve_candidate(a, P, W, o, lane, &walked, &hi, &set, &dom);
       if (lane == 0) {
          a.out[ci] = verdict == 1 ? mm_report_value(a.t.g, o, a.base_offset) : MM_NO_MATCH;
@@ -623,7 +630,7 @@ struct MmResolve2Args {
    MmTileArgs t;
    const uint64_t *mid_off;
    const uint64_t *mid_hi;
-   const uint32_t *mid_set;
+   const mm_set_t *mid_set;
    const uint32_t *mid_slot;
    const unsigned int *mid_count;
    uint64_t *out;                             // result slots (see MmResolveArgs)
@@ -631,18 +638,18 @@ struct MmResolve2Args {
    uint64_t base_offset;
    uint64_t *hard_off;                        // [MM_HARD_CAP] candidate byte offset
    uint64_t *hard_hi;                         // [MM_HARD_CAP] frontier (domain position, multiple of MM_TILE)
-   uint32_t *hard_set;                        // [MM_HARD_CAP] acceptable phases at the frontier
+   mm_set_t *hard_set;                        // [MM_HARD_CAP] acceptable phases at the frontier
    uint32_t *hard_slot;                       // [MM_HARD_CAP] the candidate's result slot
    unsigned int *hard_count;
 };
 
 __device__ __forceinline__ void mm_resolve2_body(const MmResolve2Args &a, const MmPlanLds &P, MmWaveLdsShort &W,
-                                                 uint8_t (&maps)[MM_TILE / MM_MID_CHUNK][MM_MAXD])
+                                                 uint8_t (&maps)[MM_TILE / MM_MID_CHUNK][MM_RMAXD])
 {
    const uint32_t D = a.t.plan.L - 1;
    const int wave = (int)mm_uniform(threadIdx.x >> 6);
    const int lane = threadIdx.x & 63;
-   const uint32_t full = D >= 32 ? 0xFFFFFFFFu : ((1u << D) - 1u);
+   const mm_set_t full = mm_full_set(D);
    unsigned int n = *a.mid_count;
    n = n > MM_MID_CAP ? 0u : n;                // overflow: the host discards this scan and switches engines
    unsigned long long walked = 0;
@@ -658,24 +665,24 @@ __device__ __forceinline__ void mm_resolve2_body(const MmResolve2Args &a, const 
          const int64_t lo = T + (int64_t)k * MM_MID_CHUNK;
          const int npos = (int)(hi - lo < MM_MID_CHUNK ? hi - lo : MM_MID_CHUNK);
          const uint32_t map = mm_tile_map(a.t, P, W, start, lo, npos, mm_modd64(a.t, (uint64_t)lo), lane);
-         if (lane < MM_MAXD) {
+         if (lane < MM_RMAXD) {
             maps[k][lane] = (uint8_t)map;
          }
          walked++;
       }
       __syncthreads();
       if (wave == 0) {
-         uint32_t A = a.mid_set[e];
+         mm_set_t A = a.mid_set[e];
          int verdict = -1;                       // 1 visited, 0 not visited, -1 undecided
          for (int k = nchunks - 1; k >= 0; k--) {
-            A = mm_pull_back(A, D, maps[k][lane & (MM_MAXD - 1)], lane);
+            A = mm_pull_back(A, D, maps[k][lane & (MM_RMAXD - 1)], lane);
             if (A == full || A == 0) {
                verdict = A ? 1 : 0;
                break;
             }
          }
          if (verdict < 0 && T == 0) {
-            verdict = (A & 1u) ? 1 : 0;          // domain start: the chain is in phase 0
+            verdict = (A & 1ull) ? 1 : 0;        // domain start: the chain is in phase 0
          }
          if (lane == 0) {
             if (verdict == 1) {
@@ -703,7 +710,7 @@ __global__ __launch_bounds__(64 * MM_WAVES) void mm_resolve2(MmResolve2Args a)
 {
    __shared__ MmPlanLds P;
    __shared__ MmWaveLdsShort Wv[MM_WAVES];
-   __shared__ uint8_t maps[MM_TILE / MM_MID_CHUNK][MM_MAXD];
+   __shared__ uint8_t maps[MM_TILE / MM_MID_CHUNK][MM_RMAXD];
    if (*a.mid_count == 0) {
       return;
    }
@@ -716,19 +723,19 @@ __global__ __launch_bounds__(64 * MM_WAVES) void mm_resolve2(MmResolve2Args a)
 // --------------------------------------------------------------------------
 //
 // grid = (MM_HARD_PARTS, MM_HARD_CAP).  The 4*PARTS waves of candidate i take the
-// tiles of [0, hi) round-robin and write each tile map (32 B) to scratch; the
+// tiles of [0, hi) round-robin and write each tile map (64 B) to scratch; the
 // workgroup that finishes last pulls the phase set back through them.
 
 struct MmHardArgs {
    MmTileArgs t;
    const uint64_t *hard_off;
    const uint64_t *hard_hi;
-   const uint32_t *hard_set;
+   const mm_set_t *hard_set;
    const uint32_t *hard_slot;
    const unsigned int *hard_count;
    unsigned int *done;                        // [MM_HARD_CAP] arrival tickets (zeroed per scan)
    unsigned int *overflow;                    // set when a prefix is too long: the host runs another engine
-   uint8_t *scratch;                          // [MM_HARD_CAP][MM_HARD_MAX_TILES][MM_MAXD]
+   uint8_t *scratch;                          // [MM_HARD_CAP][MM_HARD_MAX_TILES][MM_RMAXD]
    uint64_t *out;                             // result slots (see MmResolveArgs)
    unsigned long long *tiles_walked;
    uint64_t base_offset;
@@ -744,8 +751,8 @@ __device__ __forceinline__ void mm_hard_tiles(const MmHardArgs &a, const MmPlanL
    for (uint64_t t = (uint64_t)blockIdx.x * MM_WAVES + wave; t < ntiles; t += MM_HARD_PARTS * MM_WAVES) {
       const int64_t lo = (int64_t)(t * MM_TILE);
       const uint32_t map = mm_tile_map(a.t, P, W, start, lo, MM_TILE, mm_modd64(a.t, (uint64_t)lo), lane);
-      if (lane < MM_MAXD) {
-         maps[t * MM_MAXD + lane] = (uint8_t)map;
+      if (lane < MM_RMAXD) {
+         maps[t * MM_RMAXD + lane] = (uint8_t)map;
       }
       walked++;
    }
@@ -758,9 +765,9 @@ __global__ __launch_bounds__(64 * MM_WAVES) void mm_hard_resolve(MmHardArgs a)
 {
    __shared__ MmPlanLds P;
    __shared__ MmWaveLds Wv[MM_WAVES];
-   __shared__ uint8_t pull[256][MM_MAXD];
+   __shared__ uint8_t pull[128][MM_RMAXD];
    __shared__ int is_last;
-   __shared__ uint32_t sh_set;
+   __shared__ mm_set_t sh_set;
    __shared__ int sh_verdict;                            // 1 visited, 0 not visited, -1 undecided
    const int D = (int)a.t.plan.L - 1;
    const int wave = threadIdx.x >> 6;
@@ -789,7 +796,7 @@ __global__ __launch_bounds__(64 * MM_WAVES) void mm_hard_resolve(MmHardArgs a)
    uint64_t b; uint32_t p; int64_t jc;
    mm_locate_fast(a.t, o, &b, &p, &jc);
    const uint64_t start = mm_domain_start(a.t.g, b, p);
-   uint8_t *maps = a.scratch + (uint64_t)i * MM_HARD_MAX_TILES * MM_MAXD;
+   uint8_t *maps = a.scratch + (uint64_t)i * MM_HARD_MAX_TILES * MM_RMAXD;
 
    mm_hard_tiles(a, P, Wv[wave], start, ntiles, maps);
 
@@ -806,7 +813,7 @@ __global__ __launch_bounds__(64 * MM_WAVES) void mm_hard_resolve(MmHardArgs a)
    }
    __threadfence();
 
-   const uint32_t full = D >= 32 ? 0xFFFFFFFFu : ((1u << D) - 1u);
+   const mm_set_t full = mm_full_set((uint32_t)D);
    if (threadIdx.x == 0) {
       sh_set = a.hard_set[i];
       sh_verdict = -1;
@@ -820,26 +827,26 @@ __global__ __launch_bounds__(64 * MM_WAVES) void mm_hard_resolve(MmHardArgs a)
       if (t_hi == 0) {
          __syncthreads();
          if (threadIdx.x == 0) {
-            sh_verdict = (sh_set & 1u) ? 1 : 0;           // domain start: the chain is in phase 0
+            sh_verdict = (sh_set & 1ull) ? 1 : 0;         // domain start: the chain is in phase 0
          }
          continue;
       }
-      const int64_t t_lo = t_hi > 256 ? t_hi - 256 : 0;
+      const int64_t t_lo = t_hi > 128 ? t_hi - 128 : 0;
       const int n = (int)(t_hi - t_lo);
       {
          // volatile: these bytes were written by other workgroups during this launch
-         const volatile uint32_t *src = reinterpret_cast<const volatile uint32_t *>(maps + t_lo * MM_MAXD);
+         const volatile uint32_t *src = reinterpret_cast<const volatile uint32_t *>(maps + t_lo * MM_RMAXD);
          uint32_t *dst = reinterpret_cast<uint32_t *>(&pull[0][0]);
-         for (int k = threadIdx.x; k < n * (MM_MAXD / 4); k += blockDim.x) {
+         for (int k = threadIdx.x; k < n * (MM_RMAXD / 4); k += blockDim.x) {
             dst[k] = src[k];
          }
       }
       __syncthreads();
       if (wave == 0) {
-         uint32_t A = sh_set;
+         mm_set_t A = sh_set;
          for (int k = n - 1; k >= 0; k--) {
-            const int v = pull[k][lane & (MM_MAXD - 1)];
-            A = (uint32_t)__ballot(lane < D && ((A >> v) & 1u));
+            const int v = pull[k][lane & (MM_RMAXD - 1)];
+            A = (mm_set_t)__ballot(lane < D && ((A >> v) & 1ull));
             if (A == full || A == 0) {
                break;
             }

@@ -170,8 +170,8 @@ LONG = int(os.environ.get("MM_FUZZ_LONG", "24"))           # raise for a soak
 
 @pytest.mark.parametrize("seed", range(LONG))
 def test_fuzz_long_keywords(mm, gpu_engine, oracle, seed):
-    """Keywords of 33 .. 128 symbols (always the forward engine, phase maps of up to 127 phases handled by two
-    lanes each) and of 14 .. 32 (the resolvers' widest phase sets), random modes and alphabets."""
+    """Keywords of 65 .. 128 symbols (always the forward engine, phase maps of up to 127 phases handled by two lanes each),
+    of 33 .. 64 (the per-candidate resolvers' 64-bit phase sets, round 5) and of 14 .. 32, random modes and alphabets."""
     rng = np.random.default_rng(47000 + seed)
     for case in range(6):
         elem = int(rng.choice([1, 1, 2]))

@@ -345,14 +345,15 @@ def test_keyword_lengths(mm, gpu_engine, oracle, L):
         mm.plan_relative(1, [97 + (i % 5) for i in range(129)])   # longer than MMH_MAX_KEYWORD: refused, loudly
 
 
-@pytest.mark.parametrize("L", [33, 64, 127, 128])
+@pytest.mark.parametrize("L", [33, 48, 64, 65, 127, 128])
 @pytest.mark.parametrize("path", ["simple", "wildcard", "mixed-case"])
 @pytest.mark.parametrize("elem,be", [(1, False), (2, True)])
 def test_long_keywords(mm, gpu_engine, oracle, L, path, elem, be):
-    """Keywords beyond 32 symbols, up to the 128 the reference's char-sized tables allow
-    (monkey_moore.cpp:250-253): D = L - 1 phases no longer fit the resolvers' 32-bit phase sets, so
-    they run on the forward engine (phase maps of 128 bytes, lane e and lane e + 64).  Both reference
-    loops, both element sizes, engine and whole-buffer semantics, against the oracle."""
+    """Keywords beyond 32 symbols, up to the 128 the reference's char-sized tables allow (monkey_moore.cpp:250-253).  Up to
+    64 symbols the per-candidate resolvers take them (round 5: a phase set is a 64-bit ballot over the map's lanes,
+    D = L - 1 <= 63), beyond that D no longer fits a wave and they run on the forward engine (phase maps of 128 bytes,
+    lane e and lane e + 64).  Both reference loops, both element sizes, engine and whole-buffer semantics, the forward
+    engine forced on the shorter ones as well, against the oracle."""
     rng = np.random.default_rng(1000 + L + 7 * elem)
     wildcard = 0
     if path == "simple":
@@ -380,8 +381,15 @@ def test_long_keywords(mm, gpu_engine, oracle, L, path, elem, be):
     for block in (524288, 65536 + 2 * elem):
         want = oracle.engine(oplan, rom, block, be)
         got = gpu_engine.scan(plan, block_bytes=block, big_endian=be)
-        assert gpu_engine.counters()["path"] == 3
+        # (candidate path up to 64 symbols -- 2: its hard resolver, 4 / 5: the low-entropy stretches to the forward engine)
+        assert gpu_engine.counters()["path"] == 3 if L > 64 else gpu_engine.counters()["path"] in (0, 2, 4, 5), gpu_engine.counters()
         assert got.tolist() == want.tolist(), (L, path, elem, block)
+        if L <= 64:
+            gpu_engine.set_engine(2)                           # the forward engine's wide maps on the same keyword
+            assert gpu_engine.scan(plan, block_bytes=block, big_endian=be).tolist() == want.tolist(), (L, path, elem, block, "forward")
+            gpu_engine.set_engine(0)
+            whole = gpu_engine.scan(plan)                      # one chain over the whole buffer (elements in little-endian order)
+            assert whole.tolist() == oracle.search(oplan, rom if elem == 1 else rom[: n // 2 * 2].view("<u2")).tolist()
         if block == 524288:
             # (of the 60 plants the reference itself reports few when wildcards cap its skips: its chain
             # walks past most of them -- SURVEY fact 1; what matters is that the lists are identical)
