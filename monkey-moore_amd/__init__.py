@@ -462,8 +462,8 @@ class Engine:
         best, mean, ms = C.c_double(0), C.c_double(0), C.c_double(0)
         _check(lib().mmh_selftest_read_probe(self._h, reps, C.byref(best), C.byref(mean), C.byref(ms)))
         return dict(mean_GBps=mean.value, best_GBps=best.value, ms_per_pass=ms.value, passes=reps,
-                    what="pure-read kernels over the same ROM (grid-stride and 64 KiB wave spans, 16-byte loads), HIP events per pass, "
-                         "the better pattern's mean")
+                    what="pure-read kernels over the same ROM (grid-stride sweeps of 5 / 6 / 8 workgroups per CU and 64 KiB wave spans, 16-byte loads), "
+                         "HIP events per pass, the best pattern's mean")
 
     def counters(self):
         c = (C.c_uint64 * 4)()

@@ -5,7 +5,7 @@
 //
 // Two access patterns over the context's ROM, both with fully coalesced 16-byte loads and no work on the data beyond an
 // XOR that keeps the loads alive: a grid-stride sweep (every wave instruction reads 1 KiB, consecutive waves consecutive
-// KiB) and the filter's own pattern (a wave streams a contiguous 64 KiB span, four loads in flight).  The figure is the
+// KiB; grids of 8, 5 and 6 workgroups per CU) and the filter's own pattern (a wave streams a contiguous 64 KiB span, four loads in flight).  The figure is the
 // best mean over the patterns -- a ceiling, so the most favourable honest reading counts.  Round 1 measured 6.2-6.3 TB/s
 // with tools/stream_probe.hip (profiles/r01_stream_probe_read_ceiling.log); bench.py now runs this in every line.
 #include <hip/hip_runtime.h>
@@ -86,10 +86,13 @@ extern "C" int mmh_selftest_read_probe(mmh_ctx *c, int reps, double *best_GBps, 
    hipStream_t st = c->stream;
    double best_mean_ms = 1e30, best_min_ms = 1e30;
    int rc = MMH_OK;
-   for (int pattern = 0; pattern < 2 && rc == MMH_OK; pattern++) {
+   // (round 5, tools/stream_probe.hip on the sweep patterns: the grid-stride sweep with FIVE workgroups per CU, one load in
+   // flight per wave, read 6.55 TB/s where eight per CU read 6.3-6.4 -- the smaller the footprint in flight, the better the
+   // memory system likes it; a ceiling takes the best pattern it knows)
+   for (int pattern = 0; pattern < 4 && rc == MMH_OK; pattern++) {
       auto launch = [&]() {
-         if (pattern == 0) {
-            hipLaunchKernelGGL(mm_probe_gridstride, dim3(2048), dim3(256), 0, st, p, nchunks, sink);
+         if (pattern < 3) {
+            hipLaunchKernelGGL(mm_probe_gridstride, dim3(pattern == 0 ? 2048 : pattern == 1 ? 1280 : 1536), dim3(256), 0, st, p, nchunks, sink);
          }
          else {
             hipLaunchKernelGGL(mm_probe_wavespan, dim3(2048), dim3(256), 0, st, p, nchunks, (uint64_t)4096, sink);
