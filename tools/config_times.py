@@ -14,10 +14,21 @@ for name, n, kw, elem, wc, be in cfgs:
     eng.alloc(n)
     spec.apply_device(eng)
     plan = mm.plan_relative(elem, kw, wc or 0)
+    # the streaming kernel alone: ONE launch over the whole ROM per scan (MMH_ROUTE_NO_SPLIT) ...
+    eng.set_route(mm.ROUTE_NO_SPLIT)
     f, t = [], []
     for i in range(60):
         r = eng.scan(plan, block_bytes=524288, big_endian=be)
         tm = eng.timings(); f.append(tm["filter_ms"]); t.append(tm["total_ms"])
+    eng.set_route(0)
+    # ... and what a caller of mmh_scan gets (a pipeline of parts on ROMs of this size): wall time per scan
+    for i in range(10):
+        eng.scan(plan, block_bytes=524288, big_endian=be)
+    t0 = time.perf_counter()
+    for i in range(40):
+        r = eng.scan(plan, block_bytes=524288, big_endian=be)
+    sync_ms = (time.perf_counter() - t0) / 40 * 1e3
+    parts = eng.timings()["parts"]
     # the same scans with three tickets outstanding (mmh_scan_submit / mmh_scan_collect): wall time per scan
     def in_flight(n):
         tickets, last = [], None
@@ -33,6 +44,7 @@ for name, n, kw, elem, wc, be in cfgs:
     per_scan, last = in_flight(200)
     assert len(last) == len(r) and (last == r).all()
     k = 20
-    print("%-22s matches %6d  filter %.3f ms (%.0f GB/s)  total %.3f ms (%.0f GB/s)  in flight %.3f ms per scan (%.0f GB/s)  %s %s" % (
-        name, len(r), sum(f[-k:]) / k, n / (sum(f[-k:]) / k) / 1e6, sum(t[-k:]) / k, n / (sum(t[-k:]) / k) / 1e6, per_scan, n / per_scan / 1e6,
-        eng.timings(), eng.counters()))
+    print("%-22s matches %6d  streaming kernel alone %.3f ms (%.0f GB/s), device time of a one-launch scan %.3f ms | mmh_scan for the caller %.3f ms "
+          "(%.0f GB/s, %d parts) | in flight %.3f ms per scan (%.0f GB/s)  %s" % (
+              name, len(r), sum(f[-k:]) / k, n / (sum(f[-k:]) / k) / 1e6, sum(t[-k:]) / k, sync_ms, n / sync_ms / 1e6, parts, per_scan, n / per_scan / 1e6,
+              eng.counters()))
