@@ -504,8 +504,18 @@ __device__ __forceinline__ uint32_t mm_f8_chunk_any(const uint4 &w, uint32_t bac
                                                     const uint32_t (&sh)[4])
 {
    constexpr int S1 = MM_F8_STAGE1(SHAPE);
-   uint32_t p1 = mm_bytesub(back, back << 8);
-   uint32_t p2 = mm_bytesub(back, back << 16);
+   uint32_t p1, p2;
+   if constexpr (S1 == 2) {
+      // The contiguous two-condition stage (BASELINE's keywords): of the previous dword's deltas only the LAST byte's is ever
+      // looked at (v_alignbit ... 24), and that one is a single byte subtract -- round 5: 1 VALU instruction instead of the 6
+      // of a whole SWAR subtract, 5 of the ~62 a 16-byte chunk costs (the upper bytes of p1 are never read: left undefined)
+      asm("v_sub_u32_sdwa %0, %1, %1 dst_sel:BYTE_3 dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_2" : "=v"(p1) : "v"(back));
+      p2 = 0;
+   }
+   else {
+      p1 = mm_bytesub(back, back << 8);
+      p2 = mm_bytesub(back, back << 16);
+   }
    const uint32_t z0 = mm_f8_z<S1>(w.x, back, p1, p2, pat, sh);
    const uint32_t z1 = mm_f8_z<S1>(w.y, w.x, p1, p2, pat, sh);
    const uint32_t z2 = mm_f8_z<S1>(w.z, w.y, p1, p2, pat, sh);
@@ -1069,6 +1079,9 @@ __device__ __forceinline__ void mm_stream_u16(const A &a)
 
    const uint64_t nspans = (a.ngroups + gps - 1) / gps;
    MmSpanCursor cursor = mm_span_cursor(a, wave, nwaves, nspans);
+   // (the stage-1 constant in a VECTOR register: an SGPR source halves a VALU instruction's issue rate on gfx950, see mm_stream_u8)
+   uint32_t vpat[4] = {a.pat[0], a.pat[1], a.pat[2], a.pat[3]};
+   asm volatile("" : "+v"(vpat[0]));
    __shared__ MmSurvivorQueue Q;                                   // the waves' survivor queues (mm_queue_flush)
    if ((threadIdx.x & 63) == 0) {
       Q.count[threadIdx.x >> 6] = 0;
@@ -1109,7 +1122,7 @@ __device__ __forceinline__ void mm_stream_u16(const A &a)
                   r[1] = __builtin_amdgcn_update_dpp(k2, w[s][u].z, 0x138, 0xf, 0xf, false);
                   r[2] = __builtin_amdgcn_update_dpp(k3, w[s][u].w, 0x138, 0xf, 0xf, false);
                   r[3] = w[s][u].x; r[4] = w[s][u].y; r[5] = w[s][u].z; r[6] = w[s][u].w;
-                  const uint32_t any = mm_f16_chunk_any<SHAPE>(r, be, a.pat);
+                  const uint32_t any = mm_f16_chunk_any<SHAPE>(r, be, vpat);
                   flagged |= __ballot(any != 0) != 0 ? 1u << (first_bit + u) : 0u;
                }
                c1 = __builtin_amdgcn_readlane(w[s][3].y, 63);

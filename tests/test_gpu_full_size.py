@@ -2,6 +2,8 @@
 """BASELINE.json's GPU configurations at their full sizes, bit-exact against the oracle
 (which is run over all host cores on block-aligned slices), plus size-independent
 properties.  Needs a real MI355X and ~10 GiB of host memory."""
+import os
+
 import numpy as np
 import pytest
 
@@ -228,4 +230,69 @@ def test_flood_in_a_part_takes_finer_parts_then_the_flood_paths(mm, oracle):
             assert again.tolist() == want.tolist()
         eng.poke(0, rom[:1])                                                                 # the ROM "changed": nothing is remembered
         assert eng.scan(mm.plan_relative(1, "aaa"), block_bytes=BLOCK, cap=1 << 22).tolist() == want.tolist()
+        assert eng.health()["fallbacks"] == 0
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MM_FUZZ_SPLIT", "8"))))
+def test_fuzz_split_pipeline(mm, oracle, seed):
+    """Random big ROMs through mmh_scan's pipeline of parts (ROMs of >= 1 GiB): random size, element width, byte order, block
+    size, keyword (plain / wildcard, 3 .. 40 symbols), plant density from sparse to a flood stretch -- the default scan, the
+    one-launch scan (MMH_ROUTE_NO_SPLIT) and the oracle on the whole ROM must agree; so must a scan after the ROM changed."""
+    rng = np.random.default_rng(9100 + seed)
+    elem = int(rng.choice([1, 1, 2]))
+    be = bool(elem == 2 and rng.random() < 0.5)
+    nbytes = int(rng.integers(1 << 30, (5 << 30) // 2)) // elem * elem + int(rng.integers(0, 3)) * (elem == 1)
+    block = int(rng.choice([524288, 65536, 1 << 20, 524288 + 16, 4 << 20]))
+    L = int(rng.integers(3, 41))
+    letters = rng.integers(97, 123, L)
+    wc = 0
+    kw = [int(c) for c in letters]
+    if L >= 6 and rng.random() < 0.4:
+        wc = ord("*")
+        for i in rng.choice(np.arange(1, L - 1), size=max(1, L // 8), replace=False):
+            kw[int(i)] = wc
+    vals = np.array([0 if c == wc and wc else c for c in kw], np.int64)
+    lit = np.array([not (wc and c == wc) for c in kw])
+    rom = rng.integers(0, 256, nbytes, dtype=np.uint8)
+    density = str(rng.choice(["sparse", "medium", "dense", "flood"]))
+    nplants = {"sparse": 500, "medium": 40000, "dense": 400000, "flood": 20000}[density]
+    span = L * elem
+    pos = np.sort(rng.choice((nbytes - 4 * span - 64) // 64, size=nplants, replace=False)).astype(np.int64) * 64 + rng.integers(0, 32, nplants) * elem
+    if density == "flood":
+        # ... most of them crowded into 8 MiB: more than a bucket of the usual parts holds
+        lo = int(rng.integers(0, nbytes - (16 << 20)))
+        pos[: nplants * 3 // 4] = lo + np.sort(rng.choice((8 << 20) // (2 * span), size=nplants * 3 // 4, replace=False)).astype(np.int64) * 2 * span
+        pos = np.unique(pos)
+    shift = rng.integers(0, 120, len(pos))
+    for j in range(L):
+        if not lit[j]:
+            continue
+        x = (int(vals[j]) + shift).astype(np.int64)
+        if elem == 1:
+            rom[pos + j] = x.astype(np.uint8)
+        else:
+            hi, lo8 = (x >> 8).astype(np.uint8), (x & 0xFF).astype(np.uint8)
+            rom[pos + 2 * j], rom[pos + 2 * j + 1] = (hi, lo8) if be else (lo8, hi)
+    oplan = oracle.plan(elem, kw, wc)
+    want = oracle_engine_parallel(oracle, oplan, rom, block, be)
+    plan = mm.plan_relative(elem, kw, wc)
+    with mm.Engine(0) as eng:
+        eng.upload(rom)
+        got = eng.scan(plan, block_bytes=block, big_endian=be, cap=1 << 20)
+        t = eng.timings()
+        info = (seed, elem, be, nbytes, block, L, wc, density, len(want), eng.counters(), t)
+        assert got.tolist() == want.tolist(), info
+        if block % 16 == 0 and L <= 64:
+            assert t["parts"] >= 2 or eng.counters()["path"] >= 3, info          # the pipeline (or the flood paths behind it)
+        eng.set_route(mm.ROUTE_NO_SPLIT)
+        assert eng.scan(plan, block_bytes=block, big_endian=be, cap=1 << 20).tolist() == want.tolist(), info
+        assert eng.timings()["parts"] == 0
+        eng.set_route(0)
+        assert eng.scan(plan, block_bytes=block, big_endian=be, cap=1 << 20).tolist() == want.tolist(), info    # (with whatever the first scan remembered)
+        # the ROM changes under the memos: a plant wiped out in the middle
+        victim = int(pos[len(pos) // 2])
+        rom[victim: victim + span] = 0
+        eng.poke(victim, rom[victim: victim + span])
+        want2 = oracle_engine_parallel(oracle, oplan, rom, block, be)
+        assert eng.scan(plan, block_bytes=block, big_endian=be, cap=1 << 20).tolist() == want2.tolist(), info
         assert eng.health()["fallbacks"] == 0

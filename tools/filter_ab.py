@@ -42,6 +42,11 @@ class Variant:
         L.mmh_plan_relative.argtypes = [C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, C.c_void_p]
         self.h = C.c_void_p()
         self.check(L.mmh_create(0, C.byref(self.h)))
+        # one launch over the whole ROM per scan: since round 5 mmh_scan runs a ROM of >= 1 GiB as a pipeline of parts
+        # (MMH_ROUTE_NO_SPLIT = 16; older revisions have no such route and refuse the mask: they never split)
+        if hasattr(L, "mmh_set_route"):
+            L.mmh_set_route.argtypes = [C.c_void_p, C.c_uint32]
+            L.mmh_set_route(self.h, 16)
         self.plan = mm.PlanDesc()                     # (the plan's layout has not changed since round 1)
         self.out = np.zeros(1 << 16, np.uint64)
         self.count = C.c_uint64(0)
