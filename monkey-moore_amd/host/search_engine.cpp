@@ -129,8 +129,27 @@ namespace {
 // lists are gathered over RCCL (mmh_scan_multi).  Small files stay on one device -- bringing up
 // eight contexts and a communicator for a 16 MiB ROM would cost more than the search.
 //   MMOORE_HIP_DEVICES=n   use at most n devices (default: all visible)
-//   MMOORE_HIP_MULTI=1     take the multi-device path even with one device (tests: communicator of one)
+//   MMOORE_HIP_DEVICE_LIST=a,b,...  the devices to use, in rank order (default: MMOORE_HIP_DEVICE, MMOORE_HIP_DEVICE + 1, ...)
+//   MMOORE_HIP_MULTI=1     take the multi-device path even with one device (tests: communicator of one); with a device
+//                          list: over ALL listed devices whatever the file's size (tests: two contexts on one GPU through
+//                          the RCCL stand-in of tests/shim -- RCCL itself refuses a device that is listed twice)
 constexpr uint64_t kMinBytesPerDevice = 1ull << 30;
+
+std::vector<int> device_list()
+{
+   std::vector<int> ids;
+   const char *env = std::getenv("MMOORE_HIP_DEVICE_LIST");
+   for (const char *p = env; p && *p;) {
+      char *end = nullptr;
+      const long v = std::strtol(p, &end, 10);
+      if (end == p) {
+         break;
+      }
+      ids.push_back((int)v);
+      p = *end == ',' ? end + 1 : end;
+   }
+   return ids;
+}
 
 struct DeviceSet {
    std::mutex lock;                         // one run() at a time drives the set
@@ -154,12 +173,16 @@ int devices_wanted(uint64_t file_size, bool *forced)
    if (mmh_device_count(&visible) != MMH_OK || visible < 1) {
       return 1;                             // thread_context() reports the missing device properly
    }
-   // (the set starts at device MMOORE_HIP_DEVICE: only the devices from there on count)
+   // (the set starts at device MMOORE_HIP_DEVICE: only the devices from there on count -- or it is the explicit list)
+   const std::vector<int> listed = device_list();
    const char *first_env = std::getenv("MMOORE_HIP_DEVICE");
    const int first = first_env ? std::max(0, std::atoi(first_env)) : 0;
-   visible = std::max(1, visible - first);
+   visible = listed.empty() ? std::max(1, visible - first) : (int)listed.size();
    const char *cap = std::getenv("MMOORE_HIP_DEVICES");
    int most = cap && std::atoi(cap) > 0 ? std::min(visible, std::atoi(cap)) : visible;
+   if (*forced && !listed.empty()) {
+      return most;
+   }
    const uint64_t by_size = std::max<uint64_t>(1, file_size / kMinBytesPerDevice);
    return (int)std::min<uint64_t>((uint64_t)most, by_size);
 }
@@ -178,14 +201,15 @@ void ensure_devices(DeviceSet &set, int n)
    set.ctx.clear();
    const char *env = std::getenv("MMOORE_HIP_DEVICE");
    const int first = env ? std::atoi(env) : 0;
+   const std::vector<int> listed = device_list();
    int visible = 0;
-   if (mmh_device_count(&visible) != MMH_OK || first < 0 || first + n > visible) {
+   if (mmh_device_count(&visible) != MMH_OK || first < 0 || (listed.empty() ? first + n > visible : n > (int)listed.size())) {
       throw std::runtime_error("MMOORE_HIP_DEVICE=" + std::to_string(first) + " with " + std::to_string(n) + " devices wanted, but " +
-                               std::to_string(visible) + " are visible");
+                               std::to_string(listed.empty() ? visible : (int)listed.size()) + " are visible / listed");
    }
    for (int i = 0; i < n; i++) {
       mmh_ctx *c = nullptr;
-      if (mmh_create(first + i, &c) != MMH_OK) {
+      if (mmh_create(listed.empty() ? first + i : listed[i], &c) != MMH_OK) {
          throw_last_error("MI355X engine unavailable (there is no CPU fallback)");
       }
       set.ctx.push_back(c);

@@ -327,6 +327,24 @@ def test_search_engine_run_multi_device_path(mm):
     assert " 0 failures" in r.stdout
 
 
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+def test_search_engine_run_over_several_contexts_one_gpu(mm, devices):
+    """SearchEngine<T>::run's multi-device path with MORE THAN ONE device context: MMOORE_HIP_DEVICE_LIST names GPU 0 two / three
+    times (RCCL would refuse that: the stand-in of tests/shim serves the communicator), MMOORE_HIP_MULTI=1 takes the path
+    whatever the file's size -- partition rounds over the contexts, one ingest thread per context, mmh_scan_multi, the
+    merged list, previews, progress and abort: the facade's own test program (the reference's vectors among them)."""
+    from conftest import build_fake_rccl
+    from test_facade import _build_tests
+    exe = _build_tests(mm)
+    env = dict(os.environ, MMOORE_HIP_MULTI="1", MMOORE_HIP_DEVICE_LIST=devices, LD_PRELOAD=build_fake_rccl(), FAKE_RCCL_TRACE="1")
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, env=env)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert " 0 failures" in r.stdout
+    n = devices.count(",") + 1
+    assert "fake_rccl: rank %d / %d up" % (n - 1, n) in r.stdout and "process-local all-gather of %d ranks" % n in r.stdout
+
+
 @pytest.mark.parametrize("extra", [[], ["--depth", "1"], ["--depth", "2"], ["--sync-gather"], ["--torch-gather"]])
 def test_bench_multi_rank_path_with_one_rank(extra):
     """bench.py's N > 1 code path (process group, unique id, communicator, overlapped gather of collected
