@@ -364,7 +364,7 @@ __device__ __forceinline__ void mm_group_maps(const MmTileArgs &a, WL &W, int np
 // there, which the caller checked.
 template <class WL>
 __device__ __forceinline__ uint32_t mm_tile_map(const MmTileArgs &a, const MmPlanLds &P, WL &W, uint64_t start, int64_t lo,
-                                                int npos, uint32_t lo_mod, int lane, bool *end_matches = nullptr)
+                                                int npos, uint32_t lo_mod, int lane, bool *end_matches = nullptr, bool want_end = true)
 {
    start = mm_uniform64(start);
    lo = (int64_t)mm_uniform64((uint64_t)lo);
@@ -394,7 +394,9 @@ __device__ __forceinline__ uint32_t mm_tile_map(const MmTileArgs &a, const MmPla
       v = mm_modd(a, lo_mod + (uint32_t)npos) + (p - (uint32_t)npos);
       v = v >= D ? v - D : v;
    }
-   if (end_matches) {
+   // (want_end: a caller that only sometimes wants the answer passes its flag instead of a pointer that is sometimes null --
+   // the compiler kept such a flag in scratch memory: 8 bytes per lane in every resolver kernel until round 5)
+   if (end_matches && want_end) {
       *end_matches = mm_tile_matches(a, P, tile, npos);
    }
    mm_wave_sync();                                        // the wave's LDS may be restaged now
@@ -529,8 +531,7 @@ __device__ __forceinline__ int mm_resolve_candidate(const A &a, const MmPlanLds 
       const int64_t size = step == 0 ? (a.t.plan.L <= 16 ? 64 : a.t.plan.L <= 32 ? 128 : 256) : (int64_t)128 << step;
       const int64_t lo = hi > size ? hi - size : 0;
       bool is_match = true;
-      const uint32_t map = mm_tile_map(a.t, P, W, start, lo, (int)(hi - lo), mm_modd64(a.t, (uint64_t)lo), lane,
-                                       step == 0 ? &is_match : nullptr);
+      const uint32_t map = mm_tile_map(a.t, P, W, start, lo, (int)(hi - lo), mm_modd64(a.t, (uint64_t)lo), lane, &is_match, step == 0);
       (*walked)++;
       if (!is_match) {
          verdict = 0;                           // survived the SWAR conditions only
