@@ -177,3 +177,19 @@ def test_partition_rule_in_cpp():
     r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
     assert r.returncode == 0, r.stdout[-2000:]
     assert " 0 failures" in r.stdout
+
+
+def test_rccl_stand_in_builds_and_covers_what_the_library_calls():
+    """tests/shim/libfake_rccl.so (the stand-in the GPU suite preloads so that several ranks can share one GPU): builds with
+    plain g++, links against neither HIP nor RCCL, and defines every nccl* symbol libmmoore_hip.so imports."""
+    import subprocess
+    from conftest import build_fake_rccl
+    mm = load_package()
+    mm.build.build_all()
+    shim = build_fake_rccl()
+    defined = {l.split()[-1] for l in subprocess.check_output(["nm", "-D", "--defined-only", shim], text=True).splitlines() if l.strip()}
+    wanted = {l.split()[-1].split("@")[0] for l in subprocess.check_output(["nm", "-D", "--undefined-only", mm.LIB_PATH], text=True).splitlines()
+              if " nccl" in l}
+    assert wanted and wanted <= defined, sorted(wanted - defined)
+    needed = subprocess.check_output(["readelf", "-d", shim], text=True)
+    assert "libamdhip64" not in needed and "librccl" not in needed

@@ -211,7 +211,7 @@ int main(int argc, char **argv)
    hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, p, nchunks);
    CK(hipDeviceSynchronize());
    const uint32_t kk = (uint32_t)argc * 0x01020304u;
-   for (int grid : {1280, 1536, 1792, 2048}) {
+   for (int grid : {1536, 1792}) {
       char nm[128];
 #define SWEEP(L, D, W)                                                                                                              \
       snprintf(nm, sizeof nm, "sweep %d KiB per wave and round, %d rounds in flight%s, grid %d", L, D, W ? " + 14 VALU/dword" : "", grid); \
@@ -220,6 +220,16 @@ int main(int argc, char **argv)
       SWEEP(1, 2, true) SWEEP(1, 4, true) SWEEP(1, 8, true) SWEEP(4, 1, true) SWEEP(4, 2, true) SWEEP(4, 3, true) SWEEP(2, 2, true) SWEEP(2, 4, true)
       snprintf(nm, sizeof nm, "wavespan 28K + 14 VALU/dword, 2 groups ahead, grid %d", grid);
       timeit(nm, bytes, [&] { hipLaunchKernelGGL(read_wavespan_work<2>, dim3(grid), dim3(256), 0, 0, p, nchunks, (uint64_t)7, sink, kk); });
+      snprintf(nm, sizeof nm, "wavespan 28K + 14 VALU/dword, 1 group ahead, grid %d", grid);
+      timeit(nm, bytes, [&] { hipLaunchKernelGGL(read_wavespan_work<1>, dim3(grid), dim3(256), 0, 0, p, nchunks, (uint64_t)7, sink, kk); });
+      snprintf(nm, sizeof nm, "wavespan 28K + 14 VALU/dword, 3 groups ahead, grid %d", grid);
+      timeit(nm, bytes, [&] { hipLaunchKernelGGL(read_wavespan_work<3>, dim3(grid), dim3(256), 0, 0, p, nchunks, (uint64_t)7, sink, kk); });
+      snprintf(nm, sizeof nm, "wavespan 16K + 14 VALU/dword, 2 groups ahead, grid %d", grid);
+      timeit(nm, bytes, [&] { hipLaunchKernelGGL(read_wavespan_work<2>, dim3(grid), dim3(256), 0, 0, p, nchunks, (uint64_t)4, sink, kk); });
+      for (uint64_t sg : {3, 5, 6, 9, 11, 13, 15}) {
+         snprintf(nm, sizeof nm, "wavespan %lluK + 14 VALU/dword, 2 groups ahead, grid %d", (unsigned long long)(4 * sg), grid);
+         timeit(nm, bytes, [&] { hipLaunchKernelGGL(read_wavespan_work<2>, dim3(grid), dim3(256), 0, 0, p, nchunks, sg, sink, kk); });
+      }
       snprintf(nm, sizeof nm, "wavespan 64K + 14 VALU/dword, 2 groups ahead, grid %d", grid);
       timeit(nm, bytes, [&] { hipLaunchKernelGGL(read_wavespan_work<2>, dim3(grid), dim3(256), 0, 0, p, nchunks, (uint64_t)16, sink, kk); });
       snprintf(nm, sizeof nm, "gridstride u1 grid %d", grid);
