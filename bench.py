@@ -650,16 +650,20 @@ def main():
             while time.perf_counter() < t_end:
                 pass
 
-    def run_steps(k, depth, at=None, gather=True):
+    def run_steps(k, depth, at=None, gather=True, per_step=None):
         """k steps = k scans of the shard + k deliveries, nothing left in flight at the end.  at: the shard's base offset
-        (default: this rank's weak-scaling partition); gather=False: no collective (a rank measuring on its own)"""
+        (default: this rank's weak-scaling partition); gather=False: no collective (a rank measuring on its own);
+        per_step: a list that receives every step's own wall time in ms (depth 1 only: a step is one call there)"""
         at = base if at is None else at
         hand = deliver if gather else (lambda offs: offs)
         last, tickets = None, []
         for _ in range(k):
             late_host()
             if depth == 1:
+                t_step = time.perf_counter()
                 last = hand(eng.scan(plan, block_bytes=BLOCK, big_endian=BE, base_offset=at))
+                if per_step is not None:
+                    per_step.append((time.perf_counter() - t_step) * 1e3)
             else:
                 tickets.append(eng.submit(plan, block_bytes=BLOCK, big_endian=BE, base_offset=at))
                 if len(tickets) == depth:
@@ -718,7 +722,8 @@ def main():
         fence()
         t1 = time.perf_counter()
         phase("warm-up of the other leg")
-        offs_other = run_steps(args.steps, other_depth)
+        other_per_step = []
+        offs_other = run_steps(args.steps, other_depth, per_step=other_per_step)
         fence()
         elapsed_other = time.perf_counter() - t1
         filt_other, tot_other = eng.timing_history(min(args.steps, 64))
@@ -988,6 +993,8 @@ def main():
                 "value": total * args.steps / elapsed_other / 1e9, "unit": "GB/s", "ms_per_step": elapsed_other / args.steps * 1e3,
                 "kernel_ms": float(np.mean(filt_other)), "scan_device_ms": float(np.mean(tot_other)),
                 "parts": other_parts if other_depth == 1 else 0,
+                **({"ms_per_step_median": float(np.median(other_per_step)), "ms_per_step_min": float(np.min(other_per_step)),
+                    "ms_per_step_max": float(np.max(other_per_step))} if other_per_step else {}),
                 "kernel_ms_is": ("the streaming kernels of the scan's parts SUMMED (they overlap: mmh_scan runs a ROM of >= 1 GiB as a pipeline "
                                  "of parts), scan_device_ms = the pipeline's wall time on the host" if other_depth == 1 and not args.no_split and shard >= (1 << 30)
                                  else "HIP events on the scan's own launches"),

@@ -24,10 +24,14 @@
 //       [wait until posted[q] >= s + 1 for every q]       hipStreamWaitValue64
 //       segment slot (s % kRing, 0 .. n-1) -> recv buffer hipMemcpyAsync H2D (the slots of one sequence are contiguous)
 //       consumed[r] = s + 1                               hipStreamWriteValue64
-// -- stream memory operations only: no kernels, no host callbacks, nothing blocks the calling thread (two contexts of
-// one process inside ncclGroupStart / ncclGroupEnd cannot deadlock).  The HIP runtime is looked up at run time in the
-// copy the process has already loaded (a torch wheel ships its own under the same SONAME): this file links against
-// neither HIP nor RCCL.
+// -- stream memory operations only: no kernels, no host callbacks, nothing blocks the calling thread.
+// Communicators of ONE process (ncclCommInitAll) take another route: the high-priority streams of two contexts on one
+// device share a hardware queue, where a wait-value packet of rank 0 keeps rank 1's post from ever running (seen as a
+// hang).  Their all-gathers are held until ncclGroupEnd (the library issues them inside a group), where every rank's
+// call is known, and are ordered with HIP events: send buffer -> staging slot + event per rank, then every rank's stream
+// waits for all events and fills its receive buffer -- equally asynchronous, equally stream-ordered.
+// The HIP runtime is looked up at run time in the copy the process has already loaded (a torch wheel ships its own
+// under the same SONAME): this file links against neither HIP nor RCCL.
 //
 // NEVER part of the product: nothing under monkey-moore_amd/ refers to it, bench.py refuses ranks that share a device
 // unless --allow-shared-device is given, and the library's own RCCL calls are untouched.

@@ -71,6 +71,33 @@ def test_scan_multi_communicator_of_one(mm, comm_engine, oracle, elem, kw, be):
     assert got.tolist() == want.tolist() and len(got) >= 6
 
 
+def test_gather_behind_a_split_scan(mm, comm_engine, oracle):
+    """mmh_scan on a ROM of >= 1 GiB runs as a pipeline of parts (the parts' lists live in three lanes' blocks): the gather of
+    "the last scan's list" takes the concatenated list from the host -- short (a narrow record), long (second phase), and
+    behind MMH_ROUTE_NO_SPLIT from the device again."""
+    from _oracle import oracle_engine_parallel
+    eng = comm_engine
+    n = (1 << 30) + 3 * 524288 + 5
+    spec = mm.synth.RomSpec(23, n, "relativesrch", 1, None, False, 524288, plants_per_mib=24)
+    eng.alloc(n)
+    spec.apply_device(eng)
+    rom = eng.download(0, n)
+    for kw in ("relativesrch", "elativesrch"):
+        want = oracle_engine_parallel(oracle, oracle.plan(1, kw), rom, 524288)
+        assert len(want) > 20000
+        plan = mm.plan_relative(1, kw)
+        for route in (0, mm.ROUTE_NO_SPLIT, 0):
+            eng.set_route(route)
+            local = eng.scan(plan, block_bytes=524288, base_offset=1 << 36, cap=1 << 16)
+            assert (eng.timings()["parts"] > 0) == (route == 0)
+            eng.gather_start(None)
+            eng.scan(mm.plan_relative(1, "zzzzqqqq"), block_bytes=524288)          # (another scan behind the gather's start)
+            merged = eng.gather_finish(cap=1 << 16)
+            assert merged.tolist() == local.tolist() == (want + np.uint64(1 << 36)).tolist(), (kw, route)
+    eng.set_route(0)
+    eng.alloc(1 << 20)
+
+
 def test_gather_of_host_lists_short_long_and_empty(mm, comm_engine):
     eng = comm_engine
     rng = np.random.default_rng(3)
