@@ -236,7 +236,8 @@ def test_flood_in_a_part_takes_finer_parts_then_the_flood_paths(mm, oracle):
 @pytest.mark.parametrize("seed", range(int(os.environ.get("MM_FUZZ_SPLIT", "8"))))
 def test_fuzz_split_pipeline(mm, oracle, seed):
     """Random big ROMs through mmh_scan's pipeline of parts (ROMs of >= 1 GiB): random size, element width, byte order, block
-    size, keyword (plain / wildcard, 3 .. 40 symbols), plant density from sparse to a flood stretch -- the default scan, the
+    size, keyword (plain / wildcard / mixed case / custom character sequence / value scan, 3 .. 40 symbols), plant density from
+    sparse to a flood stretch -- the default scan, the
     one-launch scan (MMH_ROUTE_NO_SPLIT) and the oracle on the whole ROM must agree; so must a scan after the ROM changed."""
     rng = np.random.default_rng(9100 + seed)
     elem = int(rng.choice([1, 1, 2]))
@@ -245,14 +246,35 @@ def test_fuzz_split_pipeline(mm, oracle, seed):
     block = int(rng.choice([524288, 65536, 1 << 20, 524288 + 16, 4 << 20]))
     L = int(rng.integers(3, 41))
     letters = rng.integers(97, 123, L)
-    wc = 0
+    wc, seq, values = 0, None, None
     kw = [int(c) for c in letters]
-    if L >= 6 and rng.random() < 0.4:
+    mode = str(rng.choice(["plain", "plain", "wild", "case", "seq", "values"]))
+    if mode == "wild" and L >= 6:
         wc = ord("*")
         for i in rng.choice(np.arange(1, L - 1), size=max(1, L // 8), replace=False):
             kw[int(i)] = wc
-    vals = np.array([0 if c == wc and wc else c for c in kw], np.int64)
-    lit = np.array([not (wc and c == wc) for c in kw])
+    elif mode == "case" and L >= 6:
+        wc = ord("*")                                        # (the engine's default wildcard; the minority case becomes wildcards)
+        for i in rng.choice(np.arange(0, L), size=max(1, L // 6), replace=False):
+            kw[int(i)] -= 32
+    elif mode == "seq":
+        seq = [int(c) for c in rng.permutation(np.arange(48, 48 + 40))]      # a custom character sequence of 40 symbols
+        kw = [int(c) for c in rng.choice(seq, L)]
+    elif mode == "values":
+        values = [int(v) for v in rng.integers(0, 120, L)]                   # value scan: the keyword IS the values
+    # the element values a plant carries (None: a wildcard slot keeps the ROM's bytes)
+    if values is not None:
+        plant_vals = list(values)
+    elif seq is not None:
+        plant_vals = [seq.index(c) for c in kw]
+    elif mode == "case" and wc:
+        upper = sum(1 for c in kw if c < 97)
+        minority_upper = upper <= L - upper                  # (ties: the upper-case letters go, monkey_moore.cpp:163-180)
+        plant_vals = [None if ((c < 97) == minority_upper) else c for c in kw]
+    else:
+        plant_vals = [None if (wc and c == wc) else c for c in kw]
+    vals = np.array([0 if v is None else v for v in plant_vals], np.int64)
+    lit = np.array([v is not None for v in plant_vals])
     rom = rng.integers(0, 256, nbytes, dtype=np.uint8)
     density = str(rng.choice(["sparse", "medium", "dense", "flood"]))
     nplants = {"sparse": 500, "medium": 40000, "dense": 400000, "flood": 20000}[density]
@@ -273,14 +295,16 @@ def test_fuzz_split_pipeline(mm, oracle, seed):
         else:
             hi, lo8 = (x >> 8).astype(np.uint8), (x & 0xFF).astype(np.uint8)
             rom[pos + 2 * j], rom[pos + 2 * j + 1] = (hi, lo8) if be else (lo8, hi)
-    oplan = oracle.plan(elem, kw, wc)
+    if values is not None:
+        oplan, plan = oracle.plan_values(elem, values), mm.plan_value_scan(elem, values)
+    else:
+        oplan, plan = oracle.plan(elem, kw, wc, seq), mm.plan_relative(elem, kw, wc, seq)
     want = oracle_engine_parallel(oracle, oplan, rom, block, be)
-    plan = mm.plan_relative(elem, kw, wc)
     with mm.Engine(0) as eng:
         eng.upload(rom)
         got = eng.scan(plan, block_bytes=block, big_endian=be, cap=1 << 20)
         t = eng.timings()
-        info = (seed, elem, be, nbytes, block, L, wc, density, len(want), eng.counters(), t)
+        info = (seed, mode, elem, be, nbytes, block, L, wc, density, len(want), eng.counters(), t)
         assert got.tolist() == want.tolist(), info
         if block % 16 == 0 and L <= 64:
             assert t["parts"] >= 2 or eng.counters()["path"] >= 3, info          # the pipeline (or the flood paths behind it)
