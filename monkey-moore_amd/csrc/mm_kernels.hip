@@ -370,9 +370,14 @@ __device__ __forceinline__ uint64_t *mm_bucket_reserve(const A &a, uint64_t piec
 // or two during which the wave streams nothing.  Harmless at one candidate per MiB; in the script of a ROM, where a common
 // word sits every few hundred bytes, every piece of a span is flagged: 28 round trips on a span that streams in 28 us, and
 // the kernel is as slow as its slowest round (profiles/r03_candidate_density.log: 0.72 -> 0.80-0.82 ms at 90 K candidates).
-// So a span's survivors are parked in LDS -- MM_QCAP entries per wave, candidate offsets in the order they were found -- and
-// their buckets are reserved behind the span: one atomic per RUN of entries of the same bucket (a span lies in one or two
-// buckets of a big ROM) instead of one per flagged piece.  Survivors that do not fit (a flood) take the old way.
+// So survivors are parked in LDS -- MM_QCAP entries per wave, candidate offsets in the order they were found -- and their
+// buckets are reserved later, between two spans once the queue is half full and at the wave's end: one atomic per RUN of
+// entries of the same bucket (a span lies in one or two buckets of a big ROM), all runs of 64 entries with one wave
+// instruction (mm_queue_flush).  Survivors that do not fit (a flood) take the old way.
+// (Round 4 emptied the queue behind every span.  A wave's stores and atomics count on vmcnt like its loads, in order: the next
+// span's first group cannot be waited for before they are done, and with a two-condition keyword -- `th*s`, any three-symbol
+// word: 2^-16 of random positions survive, 65 K per 4 GiB -- the waves that met five or six survivors ended the kernel late:
+// 0.77-0.82 ms per 4 GiB of random bytes against 0.73-0.75 now, tools/filter_ab.py --config THIS, profiles/r05_dense_ab.log.)
 constexpr uint32_t MM_QCAP = 128;                 // entries per wave: 1 KiB of LDS (4 KiB per workgroup)
 constexpr int MM_FILTER_WAVES = 4;
 // Queue AND fill count live in LDS, the wave's number is worked out where it is needed: nothing of this is held in a
@@ -393,37 +398,45 @@ __device__ __forceinline__ int mm_queue_wave()
 
 // queue entries [0, n) to their buckets.  key_bytes: candidate offset + key_bytes = the position the filter keyed on, which is
 // what orders candidates into buckets (monotone in the offset, and inside the piece the wave read it from -- 16-bit odd
-// stream: at most one byte in front of it, which still keeps bucket order = offset order)
+// stream: at most one byte in front of it, which still keeps bucket order = offset order).
+// 64 entries per step, one per lane: the lanes at the head of a RUN of entries of one bucket reserve the run's slots -- all
+// runs of the step with ONE wave instruction, one round trip to L2 however many buckets the entries belong to (round 5:
+// the queue is no longer emptied behind every span, see mm_stream_u8, and holds the survivors of spans far apart).
 template <class A>
-__device__ __forceinline__ void mm_queue_flush(const A &a, MmSurvivorQueue &Q, uint32_t key_bytes)
+__device__ __forceinline__ void mm_queue_flush(const A &a, MmSurvivorQueue &Q, uint32_t key_bytes, uint32_t at_least = 1)
 {
    const int w = mm_queue_wave();
    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)Q.count[w]);
-   if (n == 0) {
-      return;
+   if (n < at_least) {
+      return;                                                              // (at_least >= 1: nothing parked, nothing to do)
    }
    Q.count[w] = 0;
    const uint64_t *q = Q.entry[w];
    const uint32_t lane = __lane_id();
-   for (uint32_t pos = 0; pos < n;) {                                     // wave uniform
-      const uint32_t left = n - pos;
-      const uint64_t e = lane < left ? q[pos + lane] : 0ull;
-      const uint64_t b = (e + key_bytes) >> a.bshift;
-      const uint64_t b0 = mm_uniform64_k(b);
-      const unsigned long long same = __ballot(lane < left && b == b0);   // (lane 0 is always in)
-      const uint32_t run = same == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~same);
+   for (uint32_t pos = 0; pos < n; pos += 64) {                            // wave uniform
+      const uint32_t valid = n - pos < 64u ? n - pos : 64u;
+      const bool in = lane < valid;
+      const uint64_t e = in ? q[pos + lane] : 0ull;
+      const uint32_t b = in ? (uint32_t)((e + key_bytes) >> a.bshift) : 0xFFFFFFFFu;
+      const uint32_t b_prev = (uint32_t)__builtin_amdgcn_update_dpp((int)~b, (int)b, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+      const unsigned long long heads = __ballot(in && b != b_prev);       // (lane 0: its `old` is ~b -- always a head)
+      const unsigned long long upto = heads & ((2ull << lane) - 1ull);    // the heads at or below this lane
+      const unsigned long long above = heads & ~((2ull << lane) - 1ull);
+      const uint32_t head = in ? 63u - (uint32_t)__builtin_clzll(upto) : lane;
+      const uint32_t next = above ? (uint32_t)__builtin_ctzll(above) : valid;
       unsigned int base = 0;
-      if (lane == 0) {
-         base = atomicAdd(a.bcount + b0, run);
+      if (in && head == lane) {
+         const uint32_t run = next - lane;
+         base = atomicAdd(a.bcount + b, run);
          if (base + run > MM_BUCKET_CAP) {
             atomicAdd(a.boverflow, 1ull);
          }
       }
-      base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
-      if (lane < run && base + lane < MM_BUCKET_CAP) {
-         mm_store_shared(a.bcand + b0 * MM_BUCKET_CAP + base + lane, e);
+      base = (unsigned int)__shfl((int)base, (int)head);
+      const uint32_t slot = base + (lane - head);
+      if (in && slot < MM_BUCKET_CAP) {
+         mm_store_shared(a.bcand + (uint64_t)b * MM_BUCKET_CAP + slot, e);
       }
-      pos += run;
    }
 }
 
@@ -824,10 +837,16 @@ __device__ __forceinline__ void mm_stream_u8(const A &a)
             }
          }
       }
-      // the span's survivors to their buckets (the ring registers are dead here; a span without survivors: one LDS read)
+      // The parked survivors to their buckets once the queue is half full (the ring registers are dead here; else: one LDS
+      // read).  Round 4 emptied it behind every span: a returning atomic per span with a survivor, a microsecond or two in
+      // which the wave has no load in flight -- with a two-condition keyword (2^-16 of random positions survive: two or three
+      // per wave) the waves that meet six of them end the kernel late.
       if (a.bcount) {
-         mm_queue_flush(a, Q, a.iA);
+         mm_queue_flush(a, Q, a.iA, MM_QCAP / 2);
       }
+   }
+   if (a.bcount) {
+      mm_queue_flush(a, Q, a.iA);
    }
 }
 
@@ -1152,8 +1171,11 @@ __device__ __forceinline__ void mm_stream_u16(const A &a)
          }
       }
       if (a.bcount) {
-         mm_queue_flush(a, Q, 2 * a.iA);
+         mm_queue_flush(a, Q, 2 * a.iA, MM_QCAP / 2);             // (once it is half full: see mm_stream_u8)
       }
+   }
+   if (a.bcount) {
+      mm_queue_flush(a, Q, 2 * a.iA);
    }
 }
 
@@ -1473,7 +1495,8 @@ const Tuning &tuning()
 //     8-bit : s_k + gap_k <= 4                       (one dword in front of a chunk)
 //     16-bit: (s,gap) of condition 1 in {(1,1),(1,2),(2,1)}   (see mm_f16_chunk)
 // Among the anchors the one with the most conditions wins; ties go to the contiguous run of
-// adjacent literals (compile-time shifts), then to the rightmost anchor.
+// adjacent literals (compile-time shifts), then to one whose first two conditions share their gap
+// (round 5: the streaming loop's cost), then to the rightmost anchor.
 bool choose_filter(const mmh_plan_desc &pl, FilterChoice *fc)
 {
    const int L = (int)pl.L;
@@ -1490,7 +1513,7 @@ bool choose_filter(const mmh_plan_desc &pl, FilterChoice *fc)
    const int want = std::min(u8 ? 4 : 2, tuning().filter_max_conditions);
    FilterChoice best;
    best.ncond = 0;
-   bool best_contiguous = false;
+   bool best_contiguous = false, best_uniform = false;
    for (int A = L - 1; A >= 1; --A) {
       const int g0 = gap_of(A);
       if (!g0) {
@@ -1514,9 +1537,26 @@ bool choose_filter(const mmh_plan_desc &pl, FilterChoice *fc)
       for (uint32_t k = 0; k < c.ncond; k++) {
          contiguous = contiguous && c.shift[k] == k && c.gap[k] == 1;
       }
-      if (c.ncond > best.ncond || (c.ncond == best.ncond && contiguous && !best_contiguous)) {
+      // The streaming loop tests conditions 0 and 1 on every byte (stage 1; the others on flagged pieces only).  When those
+      // two have the SAME gap it needs one SWAR subtraction per dword, else two (gap-1 AND gap-2 deltas: 21 instead of 14
+      // VALU operations per dword -- `ab*de`: 348 M against 215 M wave instructions per 4 GiB, a kernel bound by them,
+      // profiles/r05_dense_sq_counters.txt): a condition with the anchor's gap moves up to place 1 where there is one.
+      if (u8 && c.ncond >= 3 && c.gap[1] != c.gap[0]) {
+         for (uint32_t k = 2; k < c.ncond; k++) {
+            if (c.gap[k] == c.gap[0]) {
+               std::swap(c.pos[1], c.pos[k]);
+               std::swap(c.shift[1], c.shift[k]);
+               std::swap(c.gap[1], c.gap[k]);
+               break;
+            }
+         }
+      }
+      const bool uniform = c.ncond < 2 || c.gap[1] == c.gap[0];
+      if (c.ncond > best.ncond || (c.ncond == best.ncond && ((contiguous && !best_contiguous) ||
+                                                             (!best_contiguous && uniform && !best_uniform)))) {
          best = c;
          best_contiguous = contiguous;
+         best_uniform = uniform;
       }
    }
    if (best.ncond == 0) {

@@ -126,7 +126,12 @@ def test_models_against_reference_engine_vectors(mm):
     # (keyword position, gap) of the SWAR conditions the streaming filter keys on
     (1, "relativesrch", [(11, 1), (10, 1), (9, 1), (8, 1)], False),     # BASELINE C2: the contiguous shape
     (1, "abcde", [(4, 1), (3, 1), (2, 1), (1, 1)], False),
-    (1, "ab*de", [(4, 1), (3, 2), (1, 1)], False),                      # bench_search.cpp Wildcard/Middle
+    # bench_search.cpp Wildcard/Middle: the streaming loop tests conditions 0 and 1 on every byte -- two of the same gap
+    # cost it one SWAR subtraction per dword instead of two, so the gap-1 condition three positions back moves up
+    (1, "ab*de", [(4, 1), (1, 1), (3, 2)], False),
+    (1, "ab*defg", [(6, 1), (5, 1), (4, 1)], False),                    # (the look-back ends 4 bytes behind the anchor)
+    (1, "a*cd*f", [(5, 2), (3, 1)], True),                              # (no choice: one of each)
+    (1, "a*c*ef*h", [(4, 2), (2, 2)], True),                            # ties between anchors: the one whose two conditions share the gap
     (1, "*bcde", [(4, 1), (3, 1), (2, 1)], False),
     (1, "abcd*", [(3, 1), (2, 1), (1, 1)], False),
     (1, "re*ative*ear*hxy", [(7, 1), (6, 1), (5, 1), (4, 1)], False),   # BASELINE C3

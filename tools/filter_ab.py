@@ -23,7 +23,10 @@ from __graft_entry__ import load_package  # noqa: E402
 
 BLOCK = 524288
 CONFIGS = {"C2": (4 << 30, 1, "relativesrch", 0, False), "C3": (4 << 30, 1, "re*ative*ear*hxy", ord("*"), False),
-           "C4": (8 << 30, 2, "textsrch", 0, False), "C4BE": (8 << 30, 2, "textsrch", 0, True)}
+           "C4": (8 << 30, 2, "textsrch", 0, False), "C4BE": (8 << 30, 2, "textsrch", 0, True),
+           # the reference's Wildcard/Middle benchmark keyword and two short wildcard keywords, on C2's ROM
+           "WM": (4 << 30, 1, "mo*ke", ord("*"), False), "THIS": (4 << 30, 1, "th*s", ord("*"), False),
+           "ACDF": (4 << 30, 1, "a*cd*f", ord("*"), False)}
 
 
 class Variant:
@@ -48,7 +51,7 @@ class Variant:
             L.mmh_set_route.argtypes = [C.c_void_p, C.c_uint32]
             L.mmh_set_route(self.h, 16)
         self.plan = mm.PlanDesc()                     # (the plan's layout has not changed since round 1)
-        self.out = np.zeros(1 << 16, np.uint64)
+        self.out = np.zeros(1 << 20, np.uint64)
         self.count = C.c_uint64(0)
         self.t = (C.c_float * 4)()
 
