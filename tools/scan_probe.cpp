@@ -8,13 +8,13 @@
 int main(int argc, char **argv)
 {
    mmh_ctx *c; if (mmh_create(0, &c)) { printf("%s\n", mmh_last_error()); return 1; }
-   uint64_t n = 4ull << 30;
+   uint64_t n = argc > 3 ? (uint64_t)atoll(argv[3]) << 20 : 4ull << 30;      // [reps] [plant] [MiB]
    mmh_rom_alloc(c, n); mmh_rom_synth(c, 42, 0);
    mmh_plan_desc pl; uint32_t kw[12]; const char *k = "relativesrch"; for (int i = 0; i < 12; i++) kw[i] = k[i];
    mmh_plan_relative(1, kw, 12, 0, nullptr, 0, &pl);
    std::vector<uint64_t> out(1 << 16); uint64_t cnt;
    int reps = argc > 1 ? atoi(argv[1]) : 12;
-   if (argc > 2) {   // plant matches: 1 per MiB
+   if (argc > 2 && argv[2][0] == '1') {   // plant matches: 1 per MiB
       for (uint64_t m = 0; m < (n >> 20); m++) {
          uint8_t v[12]; for (int i = 0; i < 12; i++) v[i] = (uint8_t)(k[i] - 40);
          mmh_rom_poke(c, (m << 20) + 1000 + (m * 7919) % 900000, v, 12);
