@@ -1995,9 +1995,27 @@ int submit_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int
       p.needs_rescan = true;                    // collect runs mmh_scan
    }
    else {
-      // the ROM may still be in the making on the context's stream (upload, synth, poke)
-      HIP_TRY(hipEventRecord(c->lane_fence, c->stream));
-      HIP_TRY(hipStreamWaitEvent(lane_st, c->lane_fence, 0));
+      // The ROM may still be in the making on the context's stream (upload, synth, poke; a stream the caller gave us: whatever
+      // it put there): the lane waits for that -- when there is something to wait for.  An idle stream (one query, no packet)
+      // spares the scan an event record, a marker on that stream and a barrier packet in front of its streaming kernel:
+      // ~6 us of a synchronous scan's first part (round 5; MMOORE_LANE_FENCE=always: as before).
+      static const bool fence_always = [] { const char *e = getenv("MMOORE_LANE_FENCE"); return e && *e == 'a'; }();
+      bool idle = false;
+      if (!fence_always) {
+         const hipError_t q = hipStreamQuery(c->stream);
+         idle = q == hipSuccess;
+         if (q != hipSuccess && q != hipErrorNotReady) {
+            (void)hip_ok(q, "hipStreamQuery (the context's stream)");
+            return MMH_E_DEVICE;
+         }
+         if (!idle) {
+            (void)hipGetLastError();                // (hipErrorNotReady is sticky for hipGetLastError)
+         }
+      }
+      if (!idle) {
+         HIP_TRY(hipEventRecord(c->lane_fence, c->stream));
+         HIP_TRY(hipStreamWaitEvent(lane_st, c->lane_fence, 0));
+      }
       static const int gate_percent = [] { const char *e = getenv("MMOORE_LANE_GATE"); return e && *e ? atoi(e) : 0; }();
       if (gated && gate_percent > 0) {
          // (a streaming kernel reads ~6 TB/s)
@@ -2216,12 +2234,23 @@ int scan_split_try(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, 
    int error = MMH_OK;
    const uint64_t first_recorded = c->scans_recorded;
    const auto t_start = std::chrono::steady_clock::now();
+   // MMOORE_SPLIT_TRACE=1 (development): when the host was done with every submit and collect of the pipeline
+   static const bool split_trace = getenv("MMOORE_SPLIT_TRACE") != nullptr;
+   char trace_line[512];
+   size_t trace_len = 0;
+   auto trace = [&](const char *what) {
+      if (split_trace && trace_len + 48 < sizeof(trace_line)) {
+         trace_len += (size_t)snprintf(trace_line + trace_len, sizeof(trace_line) - trace_len, " %s %.1f", what,
+                                       std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() * 1e6);
+      }
+   };
    auto collect_oldest = [&]() {
       uint64_t n = 0;
       bool unsettled = false, overflow = false;
       const uint64_t room = total <= cap ? cap - total : 0;
       uint64_t nowhere = 0;                         // (no room left: the part is only counted)
       int rc = collect_impl(c, tickets[0], room ? out + total : &nowhere, room, &n, &unsettled, &overflow);
+      trace("collected");
       if (rc == MMH_E_CAPACITY) {
          // (the part's list is in its lane's block; only the count matters now: the caller comes back with more room)
          c->pending[((tickets[0] % mmh_ctx::kLanes) + mmh_ctx::kLanes) % mmh_ctx::kLanes].active = false;
@@ -2271,6 +2300,7 @@ int scan_split_try(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, 
       const uint64_t bytes = std::min((b1 - b0) * block_bytes + overlap, N - first);
       int t = 0;
       const int rc = submit_impl(c, plan, block_bytes, big_endian, base_offset + first, &t, true, first, bytes);
+      trace("submitted");
       if (rc != MMH_OK) {
          error = rc;
          failed = true;
@@ -2288,6 +2318,10 @@ int scan_split_try(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, 
    // of its own: mmh_last_timings after a split scan described one eighth of the ROM)
    for (int lane = 0; lane < mmh_ctx::kLanes; lane++) {
       settle_lane_timing(c, lane);
+   }
+   if (split_trace) {
+      trace("timings settled");
+      fprintf(stderr, "mmh_scan pipeline of %u parts, host clock in us from its start:%s\n", *parts_run, trace_line);
    }
    if (c->scans_recorded > first_recorded && c->scans_recorded - first_recorded <= mmh_ctx::kRing) {
       float filter_sum = 0;

@@ -23,10 +23,14 @@ rom = ns["text_like_piece"](rng)
 eng = mm.Engine(0)
 PIECE = 256 << 20
 eng.alloc(16 * PIECE)
-for k in range(16):
-    eng.poke(k * PIECE, rom)
+if kw == "C2":                                                # bench.py's ROM and keyword instead of the text-like ROM
+    kw = "relativesrch"
+    mm.synth.RomSpec(42, 16 * PIECE, kw, 1, None, False, 524288).apply_device(eng)
+else:
+    for k in range(16):
+        eng.poke(k * PIECE, rom)
 plan = mm.plan_relative(1, kw, ord("*") if "*" in kw else 0)
-for i in range(4):
+for i in range(6):
     sys.stderr.write("---- scan %d\n" % i)
     t0 = time.perf_counter()
     offs = eng.scan(plan, block_bytes=524288, cap=1 << 20)
