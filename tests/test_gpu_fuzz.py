@@ -107,9 +107,10 @@ def test_fuzz_against_oracle(mm, gpu_engine, oracle, seed):
 
 
 MEDIUM = int(os.environ.get("MM_FUZZ_MEDIUM", "32"))       # raise for a soak
+MEDIUM_FIRST = int(os.environ.get("MM_FUZZ_MEDIUM_FIRST", "0"))   # fresh seeds: MM_FUZZ_MEDIUM_FIRST=300 MM_FUZZ_MEDIUM=600
 
 
-@pytest.mark.parametrize("seed", range(MEDIUM))
+@pytest.mark.parametrize("seed", range(MEDIUM_FIRST, MEDIUM_FIRST + MEDIUM))
 def test_fuzz_medium_roms(mm, gpu_engine, oracle, seed):
     """The same kind of case at 5 .. 48 MiB: beyond the single-launch kernel's sizes -- the plain streaming kernel's
     full grid, the tail kernel, the flood / flagged-domain paths with hundreds of domains."""
