@@ -233,7 +233,8 @@ def test_flood_in_a_part_takes_finer_parts_then_the_flood_paths(mm, oracle):
         assert eng.health()["fallbacks"] == 0
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("MM_FUZZ_SPLIT", "8"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MM_FUZZ_SPLIT_FIRST", "0")),
+                                        int(os.environ.get("MM_FUZZ_SPLIT_FIRST", "0")) + int(os.environ.get("MM_FUZZ_SPLIT", "8"))))
 def test_fuzz_split_pipeline(mm, oracle, seed):
     """Random big ROMs through mmh_scan's pipeline of parts (ROMs of >= 1 GiB): random size, element width, byte order, block
     size, keyword (plain / wildcard / mixed case / custom character sequence / value scan, 3 .. 40 symbols), plant density from
