@@ -401,26 +401,30 @@ def test_bench_multi_rank_path_with_one_rank(extra):
     assert other["same_offsets"] is True
 
 
-def test_bench_two_ranks_one_gpu_through_the_stand_in():
-    """`bench.py --gpus 2` end to end with two REAL ranks (torch.distributed.run, gloo for the rendezvous, the library's own
-    communicator + gathers over the RCCL stand-in, both on GPU 0): weak and strong legs, gather_check against the
-    torch.distributed double, rccl_ranks == 2 on both ranks.  And: the stand-in is refused where it was not asked for."""
+@pytest.mark.parametrize("nranks", [2, 8])
+def test_bench_two_ranks_one_gpu_through_the_stand_in(nranks):
+    """`bench.py --gpus N` end to end with N REAL ranks (torch.distributed.run, gloo for the rendezvous, the library's own
+    communicator + gathers over the RCCL stand-in, all on GPU 0): weak and strong legs, gather_check against the
+    torch.distributed double, rccl_ranks == N on every rank -- N = 2, and N = 8 (the driver's largest run: a communicator of
+    eight, 32 MiB partitions in the strong leg).  And: the stand-in is refused where it was not asked for."""
     import json
     from conftest import build_fake_rccl
     env = dict(os.environ, LD_PRELOAD=build_fake_rccl())
     common = ["--gib-per-gpu", "0.25", "--steps", "6", "--warmup", "2", "--prewarm-s", "0.02", "--no-cpu-baseline"]
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--allow-shared-device"] + common,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nranks), "--allow-shared-device"] + common,
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(line) == 1, r.stdout[-2000:]
     res = json.loads(line[0])
-    assert res["n_gpus"] == 2 and res["value"] > 0 and "shared_device" in res
-    assert res["rccl_ranks"] == {"min": 2, "max": 2, "expected": 2}
-    assert "identical" in res["gather_check"] and "2 ranks" in res["gather_check"]
-    assert res["config"]["matches"] > 500                                   # both partitions' plants in rank 0's merged list
+    assert res["n_gpus"] == nranks and res["value"] > 0 and "shared_device" in res
+    assert res["rccl_ranks"] == {"min": nranks, "max": nranks, "expected": nranks}
+    assert "identical" in res["gather_check"] and "%d ranks" % nranks in res["gather_check"]
+    assert res["config"]["matches"] > 250 * nranks                          # every partition's plants in rank 0's merged list
     assert res["gather_ms"]["device_collective_and_pack"] > 0
-    assert res["strong"]["n_gpus"] == 2 and res["strong"]["matches"] > 250 and res["strong"]["gather_ms"]["device_collective_and_pack"] > 0
+    assert res["strong"]["n_gpus"] == nranks and res["strong"]["matches"] > 250 and res["strong"]["gather_ms"]["device_collective_and_pack"] > 0
+    if nranks != 2:
+        return
     # one rank, stand-in loaded, not asked for: refused before anything is timed
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-pmc"] + common[:2] + common[6:],
                        capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
