@@ -127,7 +127,7 @@ def main():
     rom2 = rng.integers(0, 256, 48 << 20).astype(np.uint8)
     letters = np.frombuffer(kw.encode(), np.uint8).astype(np.int64) - ord("a")
     lo2 = (len(rom2) // BLOCK) * (nranks - 1) // nranks * BLOCK
-    for j, at in enumerate(range(lo2 + 100, len(rom2) - 64, 400)):
+    for j, at in enumerate(range(lo2 + 100, len(rom2) - 64, 400 if nranks <= 3 else 128)):   # (the last rank's share shrinks with the ranks)
         rom2[at:at + len(kw)] = (letters + int(rng.integers(0, 200))).astype(np.uint8)
         if j % 3 == 0:
             rom2[at] ^= 0x55                                               # a candidate that is no match: a hole in the slots

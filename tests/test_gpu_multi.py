@@ -317,7 +317,7 @@ def _run_ranks(script, nranks, extra_env=None, timeout=420):
     return outs
 
 
-@pytest.mark.parametrize("nranks", [2, 3])
+@pytest.mark.parametrize("nranks", [2, 3, 8])
 def test_native_gather_two_ranks_one_gpu(mm, nranks):
     """The library's own communicator and gather (csrc/mm_multi.hip) with MORE THAN ONE RANK: nranks processes on the one
     GPU, RCCL's nine entry points served by tests/shim/fake_rccl.cpp (stream-ordered, asynchronous, shared memory; RCCL
@@ -330,7 +330,7 @@ def test_native_gather_two_ranks_one_gpu(mm, nranks):
         assert "rank %d of %d ok: rccl_ranks %d" % (r, nranks, nranks) in o, o[-2000:]
 
 
-@pytest.mark.parametrize("n", [2, 4])
+@pytest.mark.parametrize("n", [2, 4, 8])
 def test_scan_multi_two_contexts_one_gpu(mm, n):
     """mmh_comm_init_all + mmh_scan_multi with n > 1 contexts (one process, one host thread per context, the collective
     inside ncclGroupStart / ncclGroupEnd, the padded second phase inside the group) -- on one GPU through the stand-in."""
