@@ -984,10 +984,16 @@ int finish_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev, 
             // a copy engine) -- NOT on the scan's stream: with scans in flight the next scan's streaming kernel is
             // already queued there, and waiting for the copy would mean waiting for that scan (measured: C4 / C5,
             // 8.2 - 8.5 K candidates, ran one scan at a time with three tickets outstanding).
+            static const bool fetch_trace = getenv("MMOORE_SPLIT_TRACE") != nullptr;
+            const auto t_fetch = std::chrono::steady_clock::now();
             HIP_TRY(hipStreamWaitEvent(c->own_stream, ev[2], 0));
             HIP_TRY(hipMemcpyAsync(w.h_result + kHeaderWords, w.d_result[w.result_turn] + kHeaderWords, oc->candidates * sizeof(uint64_t),
                                    hipMemcpyDeviceToHost, c->own_stream));
             HIP_TRY(hipStreamSynchronize(c->own_stream));
+            if (fetch_trace) {
+               fprintf(stderr, "   a list of %llu slots fetched from the device in %.1f us\n", (unsigned long long)oc->candidates,
+                       std::chrono::duration<double>(std::chrono::steady_clock::now() - t_fetch).count() * 1e6);
+            }
          }
          note_dirty_slots(w, oc->candidates);
          oc->listed = oc->candidates;
@@ -998,7 +1004,14 @@ int finish_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev, 
          oc->matches = w.h_result[6] - 1;
          if (!leftovers) {
             inject_slots(c, w, g, base_offset, oc->candidates);
+            static const bool slots_trace = getenv("MMOORE_SPLIT_TRACE") != nullptr;
+            const auto t_slots = std::chrono::steady_clock::now();
             violation = validate_slots(c, w, g, base_offset, oc->candidates, oc->matches, direct);
+            if (slots_trace && oc->candidates > 4096) {
+               fprintf(stderr, "   %llu slots validated in %.1f us (%s)\n", (unsigned long long)oc->candidates,
+                       std::chrono::duration<double>(std::chrono::steady_clock::now() - t_slots).count() * 1e6,
+                       direct ? "published straight into pinned memory" : "fetched");
+            }
             what = "result slots";
             if (!violation) {
                w.ctrl_clean = true;               // the kernel's last workgroup re-zeroed the control block
