@@ -685,7 +685,9 @@ int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev,
    w.bucketed = false;
    const mm::ResolveBuffers rb = resolve_buffers(w);
 
-   poison_dirty_slots(w);
+   if (!bucketed) {
+      poison_dirty_slots(w);                   // (bucketed: behind the streaming kernel's launch, below -- up to 128 KiB of memset)
+   }
    w.max_rank = bucketed ? MM_MAX_PUBLISH : kMaxRankSort;
    w.h_result[6] = 0;                          // mm_rank_scatter publishes "matches + 1" here
    w.result_turn ^= 1;                         // the other device-side copy may still be feeding a gather ...
@@ -726,6 +728,7 @@ int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev,
          w.buckets_clean = false;                 // (until the tail kernel has been seen to finish: it zeroes the counters)
          w.bucketed = true;
          mm::launch_filter_buckets(st, g, pl, fc, rb, ev[0], ev[1]);
+         poison_dirty_slots(w);                   // (only the tail kernel stores into the pinned block: the device streams meanwhile)
          if (tail_st && tail_st != st) {
             HIP_TRY(hipStreamWaitEvent(tail_st, ev[1], 0));
          }
