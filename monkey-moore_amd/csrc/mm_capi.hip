@@ -160,6 +160,8 @@ int ensure_workspace(mmh_ctx *c, MmWorkspace &w, uint64_t out_cap)
       w.dirty_slots = 0;
       for (auto &d : w.d_result) {
          HIP_TRY(hipMalloc(&d, MM_RESULT_BLOCK_WORDS * sizeof(uint64_t)));
+         // (the words behind the slots: mm_publish_list's arrival counter lives there, zero between uses)
+         HIP_TRY(hipMemset(d + MM_HDR_FLAG_WORD, 0, (MM_RESULT_BLOCK_WORDS - MM_HDR_FLAG_WORD) * sizeof(uint64_t)));
       }
       w.ctrl_clean = false;
    }
@@ -990,9 +992,40 @@ int finish_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev, 
             static const bool fetch_trace = getenv("MMOORE_SPLIT_TRACE") != nullptr;
             const auto t_fetch = std::chrono::steady_clock::now();
             HIP_TRY(hipStreamWaitEvent(c->own_stream, ev[2], 0));
-            HIP_TRY(hipMemcpyAsync(w.h_result + kHeaderWords, w.d_result[w.result_turn] + kHeaderWords, oc->candidates * sizeof(uint64_t),
-                                   hipMemcpyDeviceToHost, c->own_stream));
-            HIP_TRY(hipStreamSynchronize(c->own_stream));
+            // Round 5: up to a megabyte comes over by a KERNEL that stores it into the pinned block and raises a word behind
+            // the scan's flag, which this thread polls -- hipMemcpyAsync + hipStreamSynchronize took 82-120 us for the 130-200 KiB
+            // of a part with 16-24 K matches (the runtime's time, not the DMA engine's; MMOORE_PUBLISH_KERNEL=0: as before).
+            static const bool by_kernel = [] { const char *e = getenv("MMOORE_PUBLISH_KERNEL"); return !(e && *e == '0'); }();
+            bool fetched = false;
+            // (only with the device to itself: beside another part's streaming kernel the copy kernel waits for wave slots --
+            // 153 us measured -- where the copy engine's 100 us at least overlap the device's work)
+            if (by_kernel && c->device_idle_hint && oc->candidates <= 131072) {
+               w.pub_seq++;
+               unsigned long long *arrive = reinterpret_cast<unsigned long long *>(w.d_result[w.result_turn] + MM_HDR_FLAG_WORD + 1);
+               volatile uint64_t *word = w.h_result + MM_HDR_FLAG_WORD + 1;
+               mm::launch_publish_list(c->own_stream, w.d_result[w.result_turn] + kHeaderWords, w.h_result + kHeaderWords,
+                                       (uint32_t)oc->candidates, arrive, reinterpret_cast<unsigned long long *>(w.h_result + MM_HDR_FLAG_WORD + 1),
+                                       w.pub_seq);
+               HIP_TRY(hipGetLastError());
+               for (uint64_t spins = 1; !fetched; spins++) {
+                  if (*word == w.pub_seq) {
+                     fetched = true;
+                     break;
+                  }
+                  __builtin_ia32_pause();
+                  if ((spins & 0xFFFF) == 0 && hipStreamQuery(c->own_stream) == hipSuccess) {
+                     fetched = *word == w.pub_seq;
+                     break;                          // (the kernel has retired: the word is there, or the copy below repairs it)
+                  }
+               }
+               std::atomic_thread_fence(std::memory_order_acquire);
+               (void)hipGetLastError();               // (hipErrorNotReady of the queries)
+            }
+            if (!fetched) {
+               HIP_TRY(hipMemcpyAsync(w.h_result + kHeaderWords, w.d_result[w.result_turn] + kHeaderWords, oc->candidates * sizeof(uint64_t),
+                                      hipMemcpyDeviceToHost, c->own_stream));
+               HIP_TRY(hipStreamSynchronize(c->own_stream));
+            }
             if (fetch_trace) {
                fprintf(stderr, "   a list of %llu slots fetched from the device in %.1f us\n", (unsigned long long)oc->candidates,
                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t_fetch).count() * 1e6);
@@ -1126,7 +1159,9 @@ int run_pipeline(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, const mm:
    if (fused) {
       c->ring_has_filter[slot] = false;            // one launch: no event marks the end of its streaming phase
    }
+   c->device_idle_hint = true;                  // (a synchronous scan: this wait is all the context is doing)
    rc = finish_pipeline(c, c->ws[0], c->stream, c->ev, g, pl, base_offset, max_candidates, sequential, oc);
+   c->device_idle_hint = false;
    if (fused) {
       c->ring_filter_ms[slot] = c->ws[0].fused_filter_ms;
    }
@@ -2265,7 +2300,9 @@ int scan_split_try(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, 
       bool unsettled = false, overflow = false;
       const uint64_t room = total <= cap ? cap - total : 0;
       uint64_t nowhere = 0;                         // (no room left: the part is only counted)
+      c->device_idle_hint = next_block >= nblocks;       // (everything is submitted: what is still collected lies in the open)
       int rc = collect_impl(c, tickets[0], room ? out + total : &nowhere, room, &n, &unsettled, &overflow);
+      c->device_idle_hint = false;
       trace("collected");
       if (rc == MMH_E_CAPACITY) {
          // (the part's list is in its lane's block; only the count matters now: the caller comes back with more room)

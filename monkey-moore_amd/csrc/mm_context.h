@@ -59,6 +59,7 @@ struct MmWorkspace {
    uint64_t *d_result[2] = {nullptr, nullptr};
    int result_turn = 0;             // d_result[result_turn] belongs to the most recent scan
    uint64_t seq = 0;                // fused scans: the number the kernel raises in h_result[MM_HDR_FLAG_WORD]
+   uint64_t pub_seq = 0;            // ... and mm_publish_list in the word behind it (a long list fetched by a kernel, finish_pipeline)
    bool fused = false;              // the scan under way is one mm_scan_fused launch (and holds the process-wide fused lock)
    bool polled = false;             // the scan under way announces its end in h_result[MM_HDR_FLAG_WORD] (fused or filter + tail)
    float fused_filter_ms = 0;       // its streaming phase, from the kernel's own wall-clock stamps
@@ -162,6 +163,9 @@ struct mmh_ctx {
    uint64_t rom_alloc = 0;          //   ... and its size
    uint8_t *rom_host = nullptr;     // pinned host buffer small uploads are scanned from in place (zero copy)
 
+   // finish_pipeline: nothing else of this context is at work on the device (a synchronous scan's own wait, the last collects of
+   // mmh_scan's pipeline of parts): a long list is fetched by mm_publish_list + a polled word instead of hipMemcpy
+   bool device_idle_hint = false;
    static constexpr int kLanes = 3; // scans mmh_scan_submit keeps in flight
    MmWorkspace ws[1 + kLanes];      // [0] mmh_scan; [1 ...] the lanes of mmh_scan_submit / _collect
    uint8_t *d_dense = nullptr;      // dense engine: tile maps, super-tile maps, entry phases (one allocation)

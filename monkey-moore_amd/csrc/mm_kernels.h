@@ -87,6 +87,9 @@ bool launch_fused(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, cons
 bool fused_applies(const MmGeom &g);
 // Big ROMs: the streaming kernel filling the bucketed store of rb, and mm_scan_tail2 (mm_tail2.h) behind it: results,
 // header and `seq` as launch_fused; tail_blocks = 0: the default grid (every workgroup resident at once: 256 CUs x the variant's occupancy)
+// n ordered slots from the device-side copy of a result block into the pinned block; `seq` raised in *flag (pinned) behind them
+void launch_publish_list(hipStream_t st, const uint64_t *src, uint64_t *dst, uint32_t n, unsigned long long *arrive,
+                         unsigned long long *flag, unsigned long long seq);
 void launch_filter_buckets(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc, const ResolveBuffers &rb,
                            hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 void launch_tail2(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const FilterChoice &fc, const ResolveBuffers &rb,

@@ -1445,6 +1445,30 @@ __global__ __launch_bounds__(256) void mm_gather(const uint8_t *rom, uint64_t nb
 
 // One wave that does nothing for `ticks` of the 100 MHz wall clock: holds the kernels behind it on its stream back
 // (mmh_scan_submit: the second scan of a burst starts half a streaming kernel behind the first, see there).
+// A long list's way to the host (round 5): n ordered slots from the device-side copy of the result block into the pinned block,
+// contiguous system-scope stores by as many workgroups as the list has KiB; the workgroup that finishes last raises `seq` in
+// the word behind the scan's flag.  Launched by the host when it has seen the scan's flag and the list is on the device only
+// (more than MM_DIRECT_PUBLISH slots) -- in place of hipMemcpy, which takes 82-120 us for 130-200 KiB on this stack
+// whatever the device is doing; nothing waits on a stream: the host polls the word.
+__global__ __launch_bounds__(256) void mm_publish_list(const uint64_t *src, uint64_t *dst, uint32_t n, unsigned long long *arrive,
+                                                       unsigned long long *flag, unsigned long long seq)
+{
+   for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+      __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst) + k, (unsigned long long)src[k], __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+   }
+   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's slots have arrived
+   __syncthreads();
+   if (threadIdx.x == 0) {
+      const unsigned long long before = __hip_atomic_fetch_add(arrive, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (before + 1 == gridDim.x) {
+         __hip_atomic_store(arrive, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (for the next list)
+         __threadfence_system();
+         __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+   }
+}
+
 __global__ __launch_bounds__(64) void mm_gate(unsigned long long ticks)
 {
    const unsigned long long t0 = wall_clock64();
@@ -2214,6 +2238,13 @@ void launch_rank_sort(hipStream_t st, const uint64_t *in, unsigned long long *ct
       hipLaunchKernelGGL(mm_rank_scatter, dim3(64), dim3(256), 0, st, in, ctrl, count_index, cap, max_n, partials,
                          host_result, dev_result, ctrl_words, keep);
    }
+}
+
+void launch_publish_list(hipStream_t st, const uint64_t *src, uint64_t *dst, uint32_t n, unsigned long long *arrive,
+                         unsigned long long *flag, unsigned long long seq)
+{
+   const unsigned blocks = std::max(1u, std::min(256u, (n + 1023u) / 1024u));
+   hipLaunchKernelGGL(mm_publish_list, dim3(blocks), dim3(256), 0, st, src, dst, n, arrive, flag, seq);
 }
 
 void launch_gate(hipStream_t st, double ms)

@@ -565,6 +565,8 @@ def test_scans_in_flight(mm, gpu_engine, oracle, depth):
     plans = [mm.plan_relative(1, kw, wc) for kw, wc in kws]
     want = [gpu_engine.scan(p, block_bytes=524288, cap=1 << 16).tolist() for p in plans]
     assert want[0] == oracle.engine(oracle.plan(1, kws[0][0]), rom, 524288).tolist()
+    # (more than MM_DIRECT_PUBLISH slots, the device to itself: the list comes over through mm_publish_list + a polled word)
+    assert want[3] == oracle.engine(oracle.plan(1, kws[3][0]), rom, 524288).tolist()
     assert len(want[3]) > 16384 and all(len(w) > 20 for w in want), [len(w) for w in want]
     order = [0, 1, 2, 3, 3, 0, 2, 1, 0, 0, 1, 0, 0, 0, 1, 1, 2]
     tickets, got = [], []
