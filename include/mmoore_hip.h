@@ -233,6 +233,12 @@ int mmh_selftest_gather_pack(mmh_ctx *ctx, const uint64_t *records, int nranks, 
  * All three produce identical results. */
 int mmh_set_engine(mmh_ctx *ctx, int engine);
 
+/* Whether scans record the HIP events behind mmh_last_timings / mmh_timing_history (default: 1).  The event at a scan's START costs
+ * its first kernel's dispatch ~4.5 us on this stack (hipExtLaunchKernelGGL with a start event: 23.1 -> 18.6 us for a synchronous scan
+ * of a 2 MiB ROM); a caller that never asks for timings -- the include/mmoore facade does not -- switches them off.  With 0 the
+ * timing calls report 0 for every scan but the single-launch ones of small ROMs, whose figures come from the kernel's own clock. */
+int mmh_set_timing(mmh_ctx *ctx, int on);
+
 /* Device timings of the last mmh_scan, in milliseconds (HIP events on the scan's
  * stream): [0] streaming filter kernel(s), [1] everything behind it (resolvers, ordering,
  * publication of the results), [2] 0, [3] total.

@@ -220,6 +220,7 @@ void begin_scan_events(mmh_ctx *c, bool has_filter)
    c->ev = c->ring[slot];
    c->ring_has_filter[slot] = has_filter;
    c->ring_is_ms[slot] = false;
+   c->ring_timed[slot] = c->timing;
    c->ring_parts[slot] = 0;
 }
 
@@ -425,6 +426,16 @@ extern "C" int mmh_set_engine(mmh_ctx *c, int engine)
       return MMH_E_ARG;
    }
    c->engine = engine;
+   return MMH_OK;
+}
+
+extern "C" int mmh_set_timing(mmh_ctx *c, int on)
+{
+   if (!c) {
+      mmh_set_error("mmh_set_timing: bad argument");
+      return MMH_E_ARG;
+   }
+   c->timing = on != 0;
    return MMH_OK;
 }
 
@@ -669,6 +680,8 @@ int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev,
 {
    const int count_index = sequential ? 1 : 0;
    const uint32_t off = routes_off(c);
+   // (the event at a scan's start costs its first dispatch ~4.5 us: only for callers that ask for timings, mmh_set_timing)
+   hipEvent_t const ev_start = c->timing ? ev[0] : nullptr;
    const bool polled = allow_polled && !sequential && !skip_bits && fused_enabled() && !(off & MMH_ROUTE_NO_POLLED);
    const bool single_launch = polled && allow_single_launch && c->fused_ok && !(off & MMH_ROUTE_NO_SINGLE_LAUNCH) && mm::fused_applies(g);
    const bool bucketed = polled && !single_launch && buckets_enabled() && !(off & MMH_ROUTE_NO_BUCKETS);
@@ -711,7 +724,7 @@ int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev,
       if (single_launch && g_fused_lock.try_lock()) {
          w.seq++;
          if (mm::launch_fused(st, g, pl, fc, rb, base_offset, max_candidates, w.h_result, w.d_result[w.result_turn], kMaxRankSort,
-                              w.seq, ev[0], ev[2])) {
+                              w.seq, ev_start, ev[2])) {
             if (!hip_ok(hipGetLastError(), "launching the fused scan kernel")) {
                g_fused_lock.unlock();
                return MMH_E_DEVICE;
@@ -729,7 +742,7 @@ int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev,
          // the tail kernel goes to a stream of its own, behind the streaming kernel's end event (scans in flight)
          w.buckets_clean = false;                 // (until the tail kernel has been seen to finish: it zeroes the counters)
          w.bucketed = true;
-         mm::launch_filter_buckets(st, g, pl, fc, rb, ev[0], ev[1]);
+         mm::launch_filter_buckets(st, g, pl, fc, rb, ev_start, ev[1]);
          poison_dirty_slots(w);                   // (only the tail kernel stores into the pinned block: the device streams meanwhile)
          if (tail_st && tail_st != st) {
             HIP_TRY(hipStreamWaitEvent(tail_st, ev[1], 0));
@@ -738,7 +751,7 @@ int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev,
                           ev[2], tail_blocks);
       }
       else {
-         mm::launch_filter(st, g, pl, fc, w.d_cand, w.d_ctrl, w.cand_cap, ev[0], ev[1], nullptr, nullptr);
+         mm::launch_filter(st, g, pl, fc, w.d_cand, w.d_ctrl, w.cand_cap, ev_start, ev[1], nullptr, nullptr);
          mm::launch_tail(st, g, pl, fc, rb, base_offset, max_candidates, w.h_result, w.d_result[w.result_turn], kMaxRankSort, w.seq,
                          ev[2]);
       }
@@ -749,11 +762,13 @@ int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev,
    // The scan's three events ride on kernel dispatches (hipExtLaunchKernelGGL) where they can:
    // a hipEventRecord between dependent kernels costs ~6 us of stream time on this stack.
    if (!sequential) {
-      mm::launch_filter(st, g, pl, fc, w.d_cand, w.d_ctrl, w.cand_cap, ev[0], ev[1], nullptr, skip_bits);
+      mm::launch_filter(st, g, pl, fc, w.d_cand, w.d_ctrl, w.cand_cap, ev_start, ev[1], nullptr, skip_bits);
       mm::launch_resolve(st, g, pl, rb, base_offset, max_candidates);
    }
    else {
-      HIP_TRY(hipEventRecord(ev[0], st));
+      if (ev_start) {
+         HIP_TRY(hipEventRecord(ev_start, st));
+      }
       HIP_TRY(hipEventRecord(ev[1], st));
       mm::launch_chain_seq(st, g, pl, w.d_out, w.d_ctrl + 1, w.out_cap, base_offset);
    }
@@ -954,6 +969,8 @@ int finish_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev, 
       }
       const uint64_t flags = w.h_result[4];
       w.fused_filter_ms = was_fused ? (float)((double)(flags >> 8) * 1e-5) : 0.0f;   // 100 MHz ticks -> ms
+      // (header word 1, bits 40-59: from the end of the streaming phase to the header, same clock)
+      w.fused_total_ms = was_fused ? w.fused_filter_ms + (float)((double)((w.h_result[1] >> 40) & 0xFFFFF) * 1e-5) : 0.0f;
       static const bool trace = getenv("MMOORE_FUSED_TRACE") != nullptr;
       if (trace && was_fused) {
          const uint64_t st = w.h_result[1];
@@ -1164,6 +1181,12 @@ int run_pipeline(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, const mm:
    c->device_idle_hint = false;
    if (fused) {
       c->ring_filter_ms[slot] = c->ws[0].fused_filter_ms;
+      if (!c->ring_timed[slot]) {
+         // (no start event: the kernel's own clock, from its first workgroup's start to its header)
+         c->ring_is_ms[slot] = true;
+         c->ring_ms[slot][0] = c->ws[0].fused_filter_ms;
+         c->ring_ms[slot][1] = c->ws[0].fused_total_ms;
+      }
    }
    return rc;
 }
@@ -2154,7 +2177,7 @@ int collect_impl(mmh_ctx *c, int ticket, uint64_t *out, uint64_t cap, uint64_t *
       }
       rescan = oc.candidates > w.out_cap || oc.candidates > oc.limit || oc.hard_overflow || !oc.sorted_on_device;
       static const bool lane_trace = getenv("MMOORE_LANE_TRACE") != nullptr;     // development: where the lanes' kernels lie in time
-      if (lane_trace) {
+      if (lane_trace && c->timing) {
          static hipEvent_t base = nullptr;
          if (!base && hipEventCreate(&base) == hipSuccess) {
             (void)hipEventRecord(base, lane_st);
@@ -2174,7 +2197,7 @@ int collect_impl(mmh_ctx *c, int ticket, uint64_t *out, uint64_t cap, uint64_t *
       c->ring_is_ms[slot] = true;
       c->ring_parts[slot] = 0;
       c->ring_ms[slot][0] = c->ring_ms[slot][1] = 0;
-      c->lane_timing_owed[lane] = (int64_t)c->scans_recorded;
+      c->lane_timing_owed[lane] = c->timing ? (int64_t)c->scans_recorded : -1;      // (no start event: the entry stays at 0)
       c->scans_recorded++;
       if (hipEventQuery(p.ev[2]) == hipSuccess) {
          settle_lane_timing(c, lane);
@@ -2472,6 +2495,9 @@ void scan_timings(mmh_ctx *c, uint64_t k, float *ms4)
    if (c->ring_is_ms[slot]) {
       ms4[0] = c->ring_ms[slot][0];
       ms4[3] = c->ring_ms[slot][1];
+   }
+   else if (!c->ring_timed[slot]) {
+      return;                                     // (mmh_set_timing(0): no start event, nothing to measure from)
    }
    else {
       // (a scan's end shows in pinned memory a few microseconds before its last event completes: wait for it;

@@ -63,6 +63,7 @@ struct MmWorkspace {
    bool fused = false;              // the scan under way is one mm_scan_fused launch (and holds the process-wide fused lock)
    bool polled = false;             // the scan under way announces its end in h_result[MM_HDR_FLAG_WORD] (fused or filter + tail)
    float fused_filter_ms = 0;       // its streaming phase, from the kernel's own wall-clock stamps
+   float fused_total_ms = 0;        // ... and the whole launch up to its header, from the same stamps
    bool ctrl_clean = false;         // the previous scan's last kernel left d_ctrl zeroed
    uint64_t bcand_buckets = 0;      // buckets d_bcand has room for (sized from the ROM, grown when a larger one arrives)
    // Result slots of h_result that may hold something else than MM_SLOT_POISON (slots a scan published straight into
@@ -166,6 +167,7 @@ struct mmh_ctx {
    // finish_pipeline: nothing else of this context is at work on the device (a synchronous scan's own wait, the last collects of
    // mmh_scan's pipeline of parts): a long list is fetched by mm_publish_list + a polled word instead of hipMemcpy
    bool device_idle_hint = false;
+   bool timing = true;              // mmh_set_timing: scans record their start events (mmh_last_timings works for every scan)
    static constexpr int kLanes = 3; // scans mmh_scan_submit keeps in flight
    MmWorkspace ws[1 + kLanes];      // [0] mmh_scan; [1 ...] the lanes of mmh_scan_submit / _collect
    uint8_t *d_dense = nullptr;      // dense engine: tile maps, super-tile maps, entry phases (one allocation)
@@ -195,6 +197,7 @@ struct mmh_ctx {
    // their timings in here when they are collected
    float ring_filter_ms[kRing] = {};   // streaming phase of a fused scan (no event marks it inside the one launch)
    bool ring_is_ms[kRing] = {};
+   bool ring_timed[kRing] = {};     // the scan recorded its start event (mmh_set_timing): else only what kernels stamped themselves is known
    float ring_ms[kRing][2] = {};    // {streaming kernel, whole scan}
    uint32_t ring_parts[kRing] = {}; // parts a scan ran as when it went through the split pipeline (0: one launch)
    uint64_t scans_recorded = 0;     // slot of scan k is k % kRing

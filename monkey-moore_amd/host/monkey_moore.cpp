@@ -39,6 +39,7 @@ mmh_ctx *thread_context()
       if (mmh_create(device, &holder.ctx) != MMH_OK) {
          throw_last_error("MI355X engine unavailable (there is no CPU fallback)");
       }
+      (void)mmh_set_timing(holder.ctx, 0);     // (nobody behind this API asks for device timings: ~4.5 us less per search)
    }
    return holder.ctx;
 }

@@ -212,6 +212,7 @@ void ensure_devices(DeviceSet &set, int n)
       if (mmh_create(listed.empty() ? first + i : listed[i], &c) != MMH_OK) {
          throw_last_error("MI355X engine unavailable (there is no CPU fallback)");
       }
+      (void)mmh_set_timing(c, 0);              // (nobody behind this API asks for device timings)
       set.ctx.push_back(c);
    }
    if (mmh_comm_init_all(set.ctx.data(), n) != MMH_OK) {

@@ -62,6 +62,8 @@ extern "C" int mmh_create(int device, mmh_ctx **out)
 
 extern "C" void mmh_destroy(mmh_ctx *c) { delete c; }
 
+extern "C" int mmh_set_timing(mmh_ctx *c, int) { return c ? MMH_OK : MMH_E_ARG; }     // (nothing to time here)
+
 extern "C" int mmh_rom_upload(mmh_ctx *c, const void *host, uint64_t nbytes)
 {
    c->rom.assign((const uint8_t *)host, (const uint8_t *)host + nbytes);

@@ -590,6 +590,40 @@ def test_scans_in_flight(mm, gpu_engine, oracle, depth):
         assert offs == want[i], kws[i]
 
 
+@pytest.mark.parametrize("mib", [2, 16, 80])
+def test_scans_without_timing_events(mm, gpu_engine, oracle, mib):
+    """mmh_set_timing(0): no start event on a scan's first dispatch (~4.5 us less per scan -- what the include/mmoore facade runs
+    with).  Same offsets through the single-launch kernel (2 MiB), the streaming + tail kernels (16 / 80 MiB) and the lanes; the
+    timing calls then report the kernel's own clock for single-launch scans and 0 otherwise, and everything again once switched
+    back on."""
+    rng = np.random.default_rng(500 + mib)
+    rom = _random_rom_with_plants(rng, mib << 20, 1, [ord(ch) for ch in "relativesrch"], False, nplants=40 * mib)
+    gpu_engine.upload(rom)
+    plan = mm.plan_relative(1, "relativesrch")
+    want = oracle.engine(oracle.plan(1, "relativesrch"), rom, 524288).tolist()
+    assert len(want) >= 30 * mib                               # (a few plants overwrite each other)
+    assert gpu_engine.scan(plan, block_bytes=524288).tolist() == want
+    timed = gpu_engine.timings()
+    assert timed["total_ms"] > 0 and timed["filter_ms"] > 0
+    gpu_engine.set_timing(False)
+    try:
+        for _ in range(3):
+            assert gpu_engine.scan(plan, block_bytes=524288).tolist() == want
+        t = gpu_engine.timings()
+        if mib <= 4:                                           # one launch: the kernel's own stamps
+            assert 0 < t["filter_ms"] <= t["total_ms"] < 1.0, t
+        else:
+            assert t["total_ms"] == 0 and t["filter_ms"] == 0, t
+        tickets = [gpu_engine.submit(plan, block_bytes=524288) for _ in range(3)]
+        for tk in tickets:
+            assert gpu_engine.collect(tk).tolist() == want
+    finally:
+        gpu_engine.set_timing(True)
+    assert gpu_engine.scan(plan, block_bytes=524288).tolist() == want
+    t = gpu_engine.timings()
+    assert t["total_ms"] > 0 and t["filter_ms"] > 0, t
+
+
 def test_offset_gather_on_rccl_world_of_one():
     # The collective plumbing bench.py uses at N > 1 (pinned staging, all_gather_into_tensor on
     # RCCL, one device-to-host copy), exercised on the one GPU this suite has.  In its own

@@ -9,6 +9,7 @@ int main(int argc, char **argv)
 {
    mmh_ctx *c; if (mmh_create(0, &c)) { printf("%s\n", mmh_last_error()); return 1; }
    uint64_t n = argc > 3 ? (uint64_t)atoll(argv[3]) << 20 : 4ull << 30;      // [reps] [plant] [MiB]
+   if (argc > 4) { mmh_set_timing(c, 0); }                                    // [reps] [plant] [MiB] [anything: no timing events]
    mmh_rom_alloc(c, n); mmh_rom_synth(c, 42, 0);
    mmh_plan_desc pl; uint32_t kw[12]; const char *k = "relativesrch"; for (int i = 0; i < 12; i++) kw[i] = k[i];
    mmh_plan_relative(1, kw, 12, 0, nullptr, 0, &pl);
