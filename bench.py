@@ -729,6 +729,20 @@ def main():
         filt_other, tot_other = eng.timing_history(min(args.steps, 64))
         other_parts = eng.timings().get("parts", 0)
         phase("other leg, %d ticket(s) outstanding" % other_depth)
+        # ... and, one scan at a time, once more WITHOUT the event at every scan's start (mmh_set_timing(0): what the include/mmoore
+        # facade runs with -- the reference API has no timings; the event costs a scan's first dispatch ~4.5 us)
+        elapsed_untimed, untimed_per_step = 0.0, []
+        if other_depth == 1:
+            eng.set_timing(False)
+            run_steps(max(args.warmup, 4), 1)
+            fence()
+            t1 = time.perf_counter()
+            offs_untimed = run_steps(args.steps, 1, per_step=untimed_per_step)
+            fence()
+            elapsed_untimed = time.perf_counter() - t1
+            eng.set_timing(True)
+            assert np.array_equal(offs_untimed, offs_other), "scans without timing events delivered another list"
+            phase("other leg again, no timing events")
     # The dominant kernel with the device to itself, ONE launch over the whole shard (MMH_ROUTE_NO_SPLIT: a synchronous scan
     # of a ROM of >= 1 GiB otherwise runs as a pipeline of parts whose kernels overlap): what `roofline` prices.
     def alone_scans(k, at=None):
@@ -761,9 +775,9 @@ def main():
             if not same:
                 sys.stderr.write("bench.py: NATIVE GATHER " + gather_check + "\n")
     if multi:
-        tmax = torch.tensor([elapsed, elapsed_other], dtype=torch.float64, device=cdev)
+        tmax = torch.tensor([elapsed, elapsed_other, elapsed_untimed if not args.no_other_depth else 0.0], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed, elapsed_other = float(tmax[0].item()), float(tmax[1].item())
+        elapsed, elapsed_other, elapsed_untimed = float(tmax[0].item()), float(tmax[1].item()), float(tmax[2].item())
 
     def over_ranks(x):
         """every rank's x, as a list on every rank"""
@@ -999,6 +1013,12 @@ def main():
                                  "of parts), scan_device_ms = the pipeline's wall time on the host" if other_depth == 1 and not args.no_split and shard >= (1 << 30)
                                  else "HIP events on the scan's own launches"),
                 "same_offsets": same,
+                **({"without_timing_events": {
+                    "ms_per_step": elapsed_untimed / args.steps * 1e3, "value": total * args.steps / elapsed_untimed / 1e9,
+                    "ms_per_step_median": float(np.median(untimed_per_step)) if untimed_per_step else None,
+                    "what": "the same K scans with mmh_set_timing(0): no HIP event at a scan's start (it costs the first dispatch ~4.5 us) -- "
+                            "how the include/mmoore facade runs; every other figure of this line is taken with the events on"}}
+                   if other_depth == 1 and elapsed_untimed > 0 else {}),
                 "note": "not the headline value: the same K steps " + (
                     "through mmh_scan_submit / mmh_scan_collect, %d tickets outstanding" % other_depth if other_depth > 1 else
                     "through mmh_scan, one scan at a time: the latency of a single 4 GiB scan as a caller sees it"),
