@@ -15,6 +15,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 
 
+# What a fresh GPU box executes first are the tests that pin the HIP path to the reference's own vectors and to the
+# BASELINE configurations at full size; the randomised sweeps follow, and the tests that start other programs (the C++
+# facade, the command line, several ranks on one GPU, bench.py) come last: under `-x` an environment-sensitive failure
+# in one of those then costs nothing in front of it.  Files not listed keep their alphabetical place ahead of these.
+GPU_FILE_ORDER = ["test_gpu_parity.py", "test_gpu_full_size.py", "test_gpu_tail_groups.py", "test_gpu_fuzz.py",
+                  "test_gpu_health.py", "test_facade.py", "test_result_utils.py", "test_gpu_multi.py", "test_gpu_bench.py"]
+
+
+def pytest_collection_modifyitems(session, config, items):
+    rank = {name: i for i, name in enumerate(GPU_FILE_ORDER)}
+    items.sort(key=lambda it: rank.get(os.path.basename(str(it.fspath)), -1))   # stable: order inside a file is kept
+
+
 def load_golden(name):
     with open(os.path.join(HERE, "golden", name), encoding="utf-8") as f:
         return json.load(f)

