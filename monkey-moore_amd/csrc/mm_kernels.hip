@@ -552,6 +552,127 @@ __device__ __forceinline__ uint32_t mm_f8_chunk(const uint4 &w, uint32_t back, c
    return h[0] | h[1] | h[2] | h[3];
 }
 
+// ---- WIDE 8-bit shapes (round 6): runs of two and three wildcards ---------------------------------------------------
+// The reference's wildcard loop compares every literal with the literal before it, however many wildcards lie between
+// (monkey_moore.cpp:425-546; its own vectors: `But**er`, `**に*行きますか`, tests/test_monkey_moore.cpp:194-246).  The shapes
+// above know gaps of 1 and 2 inside ONE dword of look-back (s + gap <= 4): `qz**mb` kept one condition, `q**k**x` none.
+// A wide shape keeps, on every byte, conditions 0 and 1 of
+//     (x[t - s_k] - x[t - s_k - g_k]) mod 256 == pat[k],      g_k in 1..4,   s_0 = 0,  s_1 = g_0
+// (condition 1 is the literal next to the anchor's left: its place follows from the anchor's gap, so (g_0, g_1) is all a
+// kernel is compiled for: 16 instantiations), over TWO dwords of look-back (s_1 + g_1 <= 8: the second one is lane l-1's
+// w.z through one more DPP move).  Stage 1 compares the LOW SEVEN BITS of the deltas only -- (a | 0x80) - (b & 0x7F) per
+// byte cannot borrow, and its low seven bits are those of a - b: 3 VALU operations instead of the 6 of an exact SWAR
+// subtraction, 14 per dword for two conditions with different gaps where the exact form costs 20 -- and lets 2^-14 instead
+// of 2^-16 of random positions through; stage 2 is exact.
+// Stage 2 (flagged pieces only) takes ALL conditions of the choice, any s_k and g_k with s_k + g_k <= MM_F8W_REACH, with
+// run-time places: condition k is a SWAR subtraction of two UNALIGNED 16-byte loads of the piece, x[.. - s_k] and
+// x[.. - s_k - g_k] (L2 / TCP hits: the piece was streamed a moment ago) -- no register shuffling, so one rolled copy
+// serves every shape.  sh[k] of the arguments carries s_k | g_k << 8 for these shapes.
+#define MM_F8_WIDE(shape) (((shape) >> 9) & 1)
+#define MM_F8W_G0(shape) ((((shape) >> 4) & 3) + 1)
+#define MM_F8W_G1(shape) ((((shape) >> 6) & 3) + 1)
+#define MM_F8W_SHAPE(g0, g1) (0x200 | 2 | (((g0) - 1) << 4) | (((g1) - 1) << 6))
+#define MM_F8W_BACK2(shape) (MM_F8W_G0(shape) + MM_F8W_G1(shape) > 4)      // stage 1 looks at the dword two in front
+constexpr uint32_t MM_F8W_REACH = 16;
+
+// the dword K bytes in front of `cur` (K = 0..8) out of cur and the two dwords before it
+template <int K>
+__device__ __forceinline__ uint32_t mm_bytes_back(uint32_t cur, uint32_t prev, uint32_t prev2)
+{
+   static_assert(K >= 0 && K <= 8, "two dwords of look-back");
+   if constexpr (K == 0) {
+      return cur;
+   }
+   else if constexpr (K < 4) {
+      return mm_alignbit(cur, prev, 32 - 8 * K);
+   }
+   else if constexpr (K == 4) {
+      return prev;
+   }
+   else if constexpr (K < 8) {
+      return mm_alignbit(prev, prev2, 32 - 8 * (K - 4));
+   }
+   else {
+      return prev2;
+   }
+}
+
+// per byte: low seven bits = those of (a - b); bit 7 is not meaningful
+__device__ __forceinline__ uint32_t mm_bytesub7(uint32_t a, uint32_t b)
+{
+   return (a | 0x80808080u) - (b & 0x7F7F7F7Fu);
+}
+
+// non-zero when some byte of the chunk passes the two stage-1 conditions on their low seven bits;
+// back / back2 = the dwords one / two in front of the chunk
+template <int SHAPE>
+__device__ __forceinline__ uint32_t mm_f8w_chunk_any(const uint4 &w, uint32_t back, uint32_t back2, const uint32_t (&pat)[4])
+{
+   constexpr int G0 = MM_F8W_G0(SHAPE), G1 = MM_F8W_G1(SHAPE);
+   const uint32_t r[6] = {back2, back, w.x, w.y, w.z, w.w};
+   uint32_t acc = 0x80808080u;                                      // bit 7 of a byte stays set while no dword had a hit there
+   if constexpr (G0 == G1) {
+      // one stream of deltas: condition 1 is condition 0's delta G0 bytes earlier
+      uint32_t dprev = mm_bytesub7(back, mm_bytes_back<G0>(back, back2, 0u));
+#pragma unroll
+      for (int j = 2; j < 6; j++) {
+         const uint32_t d = mm_bytesub7(r[j], mm_bytes_back<G0>(r[j], r[j - 1], 0u));
+         const uint32_t z = (d ^ pat[0]) | (mm_bytes_back<G0>(d, dprev, 0u) ^ pat[1]);
+         acc &= (z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;                    // bit 7 set where the seven bits are not all zero
+         dprev = d;
+      }
+   }
+   else {
+#pragma unroll
+      for (int j = 2; j < 6; j++) {
+         const uint32_t xa = mm_bytes_back<G0>(r[j], r[j - 1], r[j - 2]);
+         const uint32_t xb = mm_bytes_back<G0 + G1>(r[j], r[j - 1], r[j - 2]);
+         const uint32_t z = (mm_bytesub7(r[j], xa) ^ pat[0]) | (mm_bytesub7(xa, xb) ^ pat[1]);
+         acc &= (z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+      }
+   }
+   return ~acc & 0x80808080u;
+}
+
+// 16 bytes of the ROM from any byte address, zeros where the ROM is not (in front of it, behind it)
+__device__ __forceinline__ uint4 mm_load16_at(const uint8_t *rom, uint64_t nbytes, int64_t at)
+{
+   if (at >= 0 && (uint64_t)at + 16 <= nbytes) {
+      struct __attribute__((packed, aligned(1))) Unaligned { uint32_t x, y, z, w; };
+      const Unaligned v = *reinterpret_cast<const Unaligned *>(rom + at);   // global_load_dwordx4 at a byte address
+      return make_uint4(v.x, v.y, v.z, v.w);
+   }
+   uint32_t w[4] = {0, 0, 0, 0};
+   for (int k = 0; k < 16; k++) {
+      const int64_t i = at + k;
+      if (i >= 0 && (uint64_t)i < nbytes) {
+         w[k >> 2] |= (uint32_t)rom[i] << (8 * (k & 3));
+      }
+   }
+   return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// exact hit flags of the 16-byte chunk at byte0 for ALL conditions of a wide choice (run-time places)
+template <class A>
+__device__ __forceinline__ uint32_t mm_f8w_chunk(const A &a, uint64_t byte0, uint32_t (&h)[4])
+{
+   uint32_t z[4] = {0, 0, 0, 0};
+   for (uint32_t k = 0; k < a.ncond; k++) {                         // wave uniform
+      const uint32_t s = a.sh[k] & 0xFFu, g = a.sh[k] >> 8;
+      const uint4 x = mm_load16_at(a.t.g.rom, a.t.g.nbytes, (int64_t)byte0 - (int64_t)s);
+      const uint4 y = mm_load16_at(a.t.g.rom, a.t.g.nbytes, (int64_t)byte0 - (int64_t)(s + g));
+      z[0] |= mm_bytesub(x.x, y.x) ^ a.pat[k];
+      z[1] |= mm_bytesub(x.y, y.y) ^ a.pat[k];
+      z[2] |= mm_bytesub(x.z, y.z) ^ a.pat[k];
+      z[3] |= mm_bytesub(x.w, y.w) ^ a.pat[k];
+   }
+#pragma unroll
+   for (int j = 0; j < 4; j++) {
+      h[j] = mm_haszero8(z[j]);
+   }
+   return h[0] | h[1] | h[2] | h[3];
+}
+
 __device__ __forceinline__ uint32_t mm_f8_pack(const uint32_t (&h)[4])
 {
    return (h[0] >> 7) | (h[1] >> 6) | (h[2] >> 5) | (h[3] >> 4);   // bit 8*b + k <-> dword k, byte b
@@ -719,9 +840,14 @@ __device__ __forceinline__ void mm_edge_u8(const A &a, uint32_t block, uint32_t 
       uint32_t h[4] = {0, 0, 0, 0};
       uint32_t any = 0;
       if (c < nchunks) {
-         const uint4 w = mm_load_chunk(a.t.g.rom, a.t.g.nbytes, c * 16);
-         const uint32_t back = c ? *reinterpret_cast<const uint32_t *>(a.t.g.rom + c * 16 - 4) : 0u;
-         any = mm_f8_chunk<SHAPE>(w, back, a.pat, a.sh, h);
+         if constexpr (MM_F8_WIDE(SHAPE)) {
+            any = mm_f8w_chunk(a, c * 16, h);
+         }
+         else {
+            const uint4 w = mm_load_chunk(a.t.g.rom, a.t.g.nbytes, c * 16);
+            const uint32_t back = c ? *reinterpret_cast<const uint32_t *>(a.t.g.rom + c * 16 - 4) : 0u;
+            any = mm_f8_chunk<SHAPE>(w, back, a.pat, a.sh, h);
+         }
       }
       if (__ballot(any != 0) != 0) {
          mm_f8_survivors(a, c * 16, mm_f8_pack(h));
@@ -794,6 +920,10 @@ __device__ __forceinline__ void mm_stream_u8(const A &a)
       const uint64_t g0 = span * gps;
       const uint64_t g1 = g0 + gps < a.ngroups ? g0 + gps : a.ngroups;
       uint32_t carry = g0 ? rom1[g0 * 1024 - 1] : 0u;          // dword in front of the span (wave uniform)
+      uint32_t carry2 = 0;                                     // wide shapes: the dword in front of that one
+      if constexpr (MM_F8_WIDE(SHAPE) && MM_F8W_BACK2(SHAPE)) {
+         carry2 = g0 ? rom1[g0 * 1024 - 2] : 0u;
+      }
       uint4 w[DEPTH + 1][4];
 #pragma unroll
       for (int d = 0; d < DEPTH; d++) {
@@ -815,10 +945,24 @@ __device__ __forceinline__ void mm_stream_u8(const A &a)
                   // last dword of the previous 16 bytes: lane l-1's w.w; lane 0 keeps c
                   const uint32_t c = u == 0 ? carry : __builtin_amdgcn_readlane(w[s][u - 1].w, 63);
                   const uint32_t back = __builtin_amdgcn_update_dpp(c, w[s][u].w, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-                  const uint32_t any = mm_f8_chunk_any<SHAPE>(w[s][u], back, vpat, a.sh);
+                  uint32_t any;
+                  if constexpr (MM_F8_WIDE(SHAPE)) {
+                     uint32_t back2 = 0;
+                     if constexpr (MM_F8W_BACK2(SHAPE)) {
+                        const uint32_t c2 = u == 0 ? carry2 : __builtin_amdgcn_readlane(w[s][u - 1].z, 63);
+                        back2 = __builtin_amdgcn_update_dpp(c2, w[s][u].z, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                     }
+                     any = mm_f8w_chunk_any<SHAPE>(w[s][u], back, back2, vpat);
+                  }
+                  else {
+                     any = mm_f8_chunk_any<SHAPE>(w[s][u], back, vpat, a.sh);
+                  }
                   pending |= __ballot(any != 0) != 0 ? 1u << (4 * s + u) : 0u;
                }
                carry = __builtin_amdgcn_readlane(w[s][3].w, 63);
+               if constexpr (MM_F8_WIDE(SHAPE) && MM_F8W_BACK2(SHAPE)) {
+                  carry2 = __builtin_amdgcn_readlane(w[s][3].z, 63);
+               }
             }
          }
          // Rare (~1.6 % of the pieces on random bytes): all conditions on the flagged pieces.  One
@@ -829,10 +973,17 @@ __device__ __forceinline__ void mm_stream_u8(const A &a)
             const uint32_t bit = (uint32_t)__builtin_ctz(pending);
             pending &= pending - 1;
             const uint64_t byte0 = (g + (bit >> 2)) * 4096 + (uint64_t)(bit & 3) * 1024 + lane * 16;
-            const uint4 wu = *reinterpret_cast<const uint4 *>(a.t.g.rom + byte0);
-            const uint32_t back = byte0 ? *reinterpret_cast<const uint32_t *>(a.t.g.rom + byte0 - 4) : 0u;
             uint32_t h[4];
-            if (__ballot(mm_f8_chunk<SHAPE>(wu, back, a.pat, a.sh, h) != 0) != 0) {
+            uint32_t some;
+            if constexpr (MM_F8_WIDE(SHAPE)) {
+               some = mm_f8w_chunk(a, byte0, h);
+            }
+            else {
+               const uint4 wu = *reinterpret_cast<const uint4 *>(a.t.g.rom + byte0);
+               const uint32_t back = byte0 ? *reinterpret_cast<const uint32_t *>(a.t.g.rom + byte0 - 4) : 0u;
+               some = mm_f8_chunk<SHAPE>(wu, back, a.pat, a.sh, h);
+            }
+            if (__ballot(some != 0) != 0) {
                mm_f8_survivors(a, byte0, mm_f8_pack(h), a.bcount ? &Q : nullptr);
             }
          }
@@ -952,6 +1103,69 @@ __device__ __forceinline__ uint32_t mm_f16_chunk_any(const uint32_t (&r)[7], boo
    return acc & 0x80008000u;
 }
 
+// ---- WIDE 16-bit shapes (round 6): bit 9 set, bits 4-5 = gap of condition 0 minus one (1..4 elements: up to three
+// wildcards between the anchor and the literal before it).  Stage 1 is condition 0 on every byte position, exact, as above:
+// the element G0 places back is a quarter / half / three quarters / a whole of the dwords in front (r[0..2] reach 12 bytes
+// back: enough for the odd stream at gap 4).  Stage 2 takes every condition of the choice with run-time places, each a
+// v_pk_sub_u16 of two UNALIGNED 16-byte loads per byte alignment (see the wide 8-bit shapes); sh[k] = s_k | g_k << 8.
+#define MM_F16_WIDE(shape) (((shape) >> 9) & 1)
+#define MM_F16W_G0(shape) ((((shape) >> 4) & 3) + 1)
+#define MM_F16W_SHAPE(g0) (0x200 | 1 | (((g0) - 1) << 4))
+
+template <int SHAPE>
+__device__ __forceinline__ uint32_t mm_f16w_chunk_any(const uint32_t (&r)[7], bool be, const uint32_t (&pat)[4])
+{
+   constexpr int G0 = MM_F16W_G0(SHAPE);
+   uint32_t ev[7], od[7];
+#pragma unroll
+   for (int k = 1; k < 7; k++) {
+      ev[k] = be ? mm_bswap16x2(r[k]) : r[k];
+      const uint32_t o = mm_alignbit(r[k], r[k - 1], 24);
+      od[k] = be ? mm_bswap16x2(o) : o;
+   }
+   // the elements G0 places in front of those of dword k: 2 G0 bytes back
+   auto back = [](const uint32_t (&e)[7], int k) {
+      return G0 == 1 ? mm_alignbit(e[k], e[k - 1], 16) : G0 == 2 ? e[k - 1] : G0 == 3 ? mm_alignbit(e[k - 1], e[k - 2], 16) : e[k - 2];
+   };
+   uint32_t acc = 0;
+#pragma unroll
+   for (int k = 3; k < 7; k++) {
+      const uint32_t ze = mm_sub16x2(ev[k], back(ev, k)) ^ pat[0];
+      const uint32_t zo = mm_sub16x2(od[k], back(od, k)) ^ pat[0];
+      acc |= ((ze - 0x00010001u) & ~ze) | ((zo - 0x00010001u) & ~zo);
+   }
+   return acc & 0x80008000u;
+}
+
+// exact hit flags of the 16-byte chunk at byte0, both byte alignments, for ALL conditions of a wide choice
+template <class A>
+__device__ __forceinline__ uint32_t mm_f16w_chunk(const A &a, uint64_t byte0, bool be, uint32_t (&he)[4], uint32_t (&ho)[4])
+{
+   uint32_t ze[4] = {0, 0, 0, 0}, zo[4] = {0, 0, 0, 0};
+   for (uint32_t k = 0; k < a.ncond; k++) {                         // wave uniform
+      const int64_t s2 = 2 * (int64_t)(a.sh[k] & 0xFFu), g2 = 2 * (int64_t)(a.sh[k] >> 8);
+      const uint4 xe = mm_load16_at(a.t.g.rom, a.t.g.nbytes, (int64_t)byte0 - s2);
+      const uint4 ye = mm_load16_at(a.t.g.rom, a.t.g.nbytes, (int64_t)byte0 - s2 - g2);
+      const uint4 xo = mm_load16_at(a.t.g.rom, a.t.g.nbytes, (int64_t)byte0 - 1 - s2);     // the odd stream starts a byte earlier
+      const uint4 yo = mm_load16_at(a.t.g.rom, a.t.g.nbytes, (int64_t)byte0 - 1 - s2 - g2);
+      const uint32_t x[8] = {xe.x, xe.y, xe.z, xe.w, xo.x, xo.y, xo.z, xo.w};
+      const uint32_t y[8] = {ye.x, ye.y, ye.z, ye.w, yo.x, yo.y, yo.z, yo.w};
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+         ze[j] |= mm_sub16x2(be ? mm_bswap16x2(x[j]) : x[j], be ? mm_bswap16x2(y[j]) : y[j]) ^ a.pat[k];
+         zo[j] |= mm_sub16x2(be ? mm_bswap16x2(x[4 + j]) : x[4 + j], be ? mm_bswap16x2(y[4 + j]) : y[4 + j]) ^ a.pat[k];
+      }
+   }
+   uint32_t any = 0;
+#pragma unroll
+   for (int j = 0; j < 4; j++) {
+      he[j] = mm_haszero16(ze[j]);
+      ho[j] = mm_haszero16(zo[j]);
+      any |= he[j] | ho[j];
+   }
+   return any;
+}
+
 // 16 flags of a chunk: bit 4*j + 2*odd + half
 __device__ __forceinline__ uint32_t mm_f16_pack(const uint32_t (&he)[4], const uint32_t (&ho)[4])
 {
@@ -1063,12 +1277,17 @@ __device__ __forceinline__ void mm_edge_u16(const A &a, uint32_t block, uint32_t
       uint32_t he[4] = {0, 0, 0, 0}, ho[4] = {0, 0, 0, 0};
       uint32_t any = 0;
       if (c < nchunks) {
-         const uint4 w = mm_load_chunk(a.t.g.rom, a.t.g.nbytes, c * 16);
-         uint32_t r[7] = {0, 0, 0, w.x, w.y, w.z, w.w};
-         if (c) {
-            r[0] = rom1[c * 4 - 3]; r[1] = rom1[c * 4 - 2]; r[2] = rom1[c * 4 - 1];
+         if constexpr (MM_F16_WIDE(SHAPE)) {
+            any = mm_f16w_chunk(a, c * 16, be, he, ho);
          }
-         any = mm_f16_chunk<SHAPE>(r, be, a.pat, he, ho);
+         else {
+            const uint4 w = mm_load_chunk(a.t.g.rom, a.t.g.nbytes, c * 16);
+            uint32_t r[7] = {0, 0, 0, w.x, w.y, w.z, w.w};
+            if (c) {
+               r[0] = rom1[c * 4 - 3]; r[1] = rom1[c * 4 - 2]; r[2] = rom1[c * 4 - 1];
+            }
+            any = mm_f16_chunk<SHAPE>(r, be, a.pat, he, ho);
+         }
       }
       if (__ballot(any != 0) != 0) {
          mm_f16_survivors(a, c * 16, mm_f16_pack(he, ho));
@@ -1141,7 +1360,13 @@ __device__ __forceinline__ void mm_stream_u16(const A &a)
                   r[1] = __builtin_amdgcn_update_dpp(k2, w[s][u].z, 0x138, 0xf, 0xf, false);
                   r[2] = __builtin_amdgcn_update_dpp(k3, w[s][u].w, 0x138, 0xf, 0xf, false);
                   r[3] = w[s][u].x; r[4] = w[s][u].y; r[5] = w[s][u].z; r[6] = w[s][u].w;
-                  const uint32_t any = mm_f16_chunk_any<SHAPE>(r, be, vpat);
+                  uint32_t any;
+                  if constexpr (MM_F16_WIDE(SHAPE)) {
+                     any = mm_f16w_chunk_any<SHAPE>(r, be, vpat);
+                  }
+                  else {
+                     any = mm_f16_chunk_any<SHAPE>(r, be, vpat);
+                  }
                   flagged |= __ballot(any != 0) != 0 ? 1u << (first_bit + u) : 0u;
                }
                c1 = __builtin_amdgcn_readlane(w[s][3].y, 63);
@@ -1160,13 +1385,20 @@ __device__ __forceinline__ void mm_stream_u16(const A &a)
          const uint32_t bit = (uint32_t)__builtin_ctz(flagged);
          flagged &= flagged - 1;
          const uint64_t c = (g0 + (bit >> 2)) * 256 + (uint64_t)(bit & 3) * 64 + lane;     // 16-byte chunk number
-         const uint4 wu = rom4[c];
-         uint32_t r[7] = {0, 0, 0, wu.x, wu.y, wu.z, wu.w};
-         if (c) {
-            r[0] = rom1[c * 4 - 3]; r[1] = rom1[c * 4 - 2]; r[2] = rom1[c * 4 - 1];
-         }
          uint32_t he[4], ho[4];
-         if (__ballot(mm_f16_chunk<SHAPE>(r, be, a.pat, he, ho) != 0) != 0) {
+         uint32_t some;
+         if constexpr (MM_F16_WIDE(SHAPE)) {
+            some = mm_f16w_chunk(a, c * 16, be, he, ho);
+         }
+         else {
+            const uint4 wu = rom4[c];
+            uint32_t r[7] = {0, 0, 0, wu.x, wu.y, wu.z, wu.w};
+            if (c) {
+               r[0] = rom1[c * 4 - 3]; r[1] = rom1[c * 4 - 2]; r[2] = rom1[c * 4 - 1];
+            }
+            some = mm_f16_chunk<SHAPE>(r, be, a.pat, he, ho);
+         }
+         if (__ballot(some != 0) != 0) {
             mm_f16_survivors(a, c * 16, mm_f16_pack(he, ho), a.bcount ? &Q : nullptr);
          }
       }
@@ -1583,6 +1815,65 @@ bool choose_filter(const mmh_plan_desc &pl, FilterChoice *fc)
          best_uniform = uniform;
       }
    }
+   // Wide shapes (gaps up to 4, conditions up to MM_F8W_REACH places back; see MM_F8_WIDE / MM_F16_WIDE): where the shapes
+   // above leave the streaming loop or the resolver short -- fewer than 3 (8-bit) / 2 (16-bit) conditions -- and a wide choice
+   // has more.  Condition 1 of a wide choice is the literal next to the anchor's left (the kernels are compiled for the two
+   // gaps only); ties go to equal gaps (one stream of deltas on the hot path), then to short ones, then to the rightmost anchor.
+   if ((int)best.ncond < std::min(u8 ? 3 : 2, want) && !(getenv("MMOORE_FILTER_WIDE") && *getenv("MMOORE_FILTER_WIDE") == '0')) {
+      auto wide_gap = [&](int i) -> int {
+         if (i < 1 || pl.cmp_mask[i] == 0) {
+            return 0;
+         }
+         const int g = -(int)pl.bridge[i];
+         return g >= 1 && i - g >= 0 ? g : 0;
+      };
+      FilterChoice wbest;
+      wbest.ncond = 0;
+      int wbest_cost = 0;
+      for (int A = L - 1; A >= 1; --A) {
+         const int g0 = wide_gap(A);
+         if (g0 < 1 || g0 > 4) {
+            continue;
+         }
+         FilterChoice c;
+         c.ncond = 1; c.iA = (uint32_t)A; c.shape = 0;
+         c.pos[0] = (uint32_t)A; c.shift[0] = 0; c.gap[0] = (uint32_t)g0;
+         const int wwant = std::max(2, std::min(4, tuning().filter_max_conditions));
+         for (int i = A - 1; i >= 1 && (int)c.ncond < wwant; --i) {
+            const int g = wide_gap(i), s = A - i;
+            if (!g) {
+               continue;
+            }
+            if (u8 && c.ncond == 1 && (s != g0 || g > 4)) {
+               break;                                   // (the literal to the anchor's left IS g0 places from it; its own gap is compiled in)
+            }
+            if (s + g <= (int)MM_F8W_REACH) {
+               c.pos[c.ncond] = (uint32_t)i; c.shift[c.ncond] = (uint32_t)s; c.gap[c.ncond] = (uint32_t)g;
+               c.ncond++;
+            }
+         }
+         if (u8 && c.ncond < 2) {
+            continue;                                   // (one 7-bit condition flags every piece: not a filter)
+         }
+         const int cost = u8 ? (c.gap[0] == c.gap[1] ? 0 : 8) + (int)(c.gap[0] + c.gap[1]) : (int)c.gap[0];
+         if (c.ncond > wbest.ncond || (c.ncond == wbest.ncond && cost < wbest_cost)) {
+            wbest = c;
+            wbest_cost = cost;
+         }
+      }
+      if (wbest.ncond > best.ncond) {
+         *fc = wbest;
+         for (uint32_t k = 0; k < 4; k++) {
+            const bool used = k < fc->ncond;
+            fc->pat[k] = used ? ((uint32_t)pl.expected[fc->pos[k]] & emask) * rep : 0u;
+            if (!used) {
+               fc->pos[k] = 0; fc->shift[k] = 0; fc->gap[k] = 0;
+            }
+         }
+         fc->shape = u8 ? (uint32_t)MM_F8W_SHAPE(fc->gap[0], fc->gap[1]) : (uint32_t)MM_F16W_SHAPE(fc->gap[0]);
+         return true;
+      }
+   }
    if (best.ncond == 0) {
       fc->ncond = 0;
       return false;
@@ -1629,7 +1920,7 @@ bool filter_verifies(const mmh_plan_desc &pl, const FilterChoice &fc)
    if (fc.ncond >= compared) {
       return false;
    }
-   return !((pl.elem_bytes == 1 && fc.ncond >= 3) || (pl.elem_bytes == 2 && fc.ncond == 2));
+   return !((pl.elem_bytes == 1 && fc.ncond >= 3) || (pl.elem_bytes == 2 && fc.ncond >= 2));
 }
 
 // Launch geometry of the span kernels: 6 workgroups (24 waves) per CU, a wave streams spans of
@@ -1695,10 +1986,32 @@ static bool with_shape_u8_masks(uint32_t mask2, std::integer_sequence<int, M2...
    return ((mask2 == (uint32_t)M2 ? (f(mm_int<1>(), mm_int<NC | (M2 << 4) | 0x100>()), true) : false) || ...);
 }
 
+template <class F, int... G>
+static bool with_shape_u8_wide(uint32_t shape, std::integer_sequence<int, G...>, F &f)
+{
+   return ((shape == (uint32_t)MM_F8W_SHAPE(G / 4 + 1, G % 4 + 1) ? (f(mm_int<1>(), mm_int<MM_F8W_SHAPE(G / 4 + 1, G % 4 + 1)>()), true) : false) || ...);
+}
+
+template <class F, int... G>
+static bool with_shape_u16_wide(uint32_t shape, std::integer_sequence<int, G...>, F &f)
+{
+   return ((shape == (uint32_t)MM_F16W_SHAPE(G + 1) ? (f(mm_int<2>(), mm_int<MM_F16W_SHAPE(G + 1)>()), true) : false) || ...);
+}
+
 template <class F>
 static void with_shape(uint32_t elem_bytes, const FilterChoice &fc, F &&f)
 {
    const uint32_t shape = fc.shape;
+   if (shape & 0x200u) {
+      // wide shapes: 16 pairs of gaps (8-bit), 4 gaps (16-bit)
+      if (elem_bytes == 1) {
+         with_shape_u8_wide(shape, std::make_integer_sequence<int, 16>(), f);
+      }
+      else {
+         with_shape_u16_wide(shape, std::make_integer_sequence<int, 4>(), f);
+      }
+      return;
+   }
    if (elem_bytes == 1) {
       const uint32_t mask2 = MM_F8_MASK2(shape);
       if (!MM_F8_RT(shape)) {
@@ -1741,7 +2054,8 @@ static void fill_filter_args(A &a, const MmGeom &g, const mmh_plan_desc &pl, con
    a.verify = filter_verifies(pl, fc) ? 1u : 0u;
    for (int k = 0; k < 4; k++) {
       a.pat[k] = fc.pat[k];
-      a.sh[k] = 32u - 8u * fc.shift[k];
+      // (wide shapes: the place and the gap themselves, for the rolled second stage)
+      a.sh[k] = (fc.shape & 0x200u) ? (fc.shift[k] | fc.gap[k] << 8) : 32u - 8u * fc.shift[k];
    }
    a.cand = cand; a.list_count = ctrl + MM_CTRL_LISTS; a.list_cap = cand_cap / MM_CAND_LISTS;
    a.dom_count = nullptr; a.skip_bits = nullptr;
@@ -2128,7 +2442,7 @@ static void launch_forward(hipStream_t st, const MmGeom &g, const mmh_plan_desc 
    a.loud_shape = 0; a.loud_iA = 0; a.loud_pat[0] = a.loud_pat[1] = 0; a.loud_sh1 = 0;
    FilterChoice fc;
    const bool sweeps = choose_filter(pl, &fc) && !(getenv("MMOORE_FORWARD_SWEEP") && *getenv("MMOORE_FORWARD_SWEEP") == '0');
-   if (sweeps && a.fast) {
+   if (sweeps && a.fast && !(fc.shape & 0x200u)) {          // (its batch sweep knows the one-dword shapes only)
       const uint32_t nc = fc.ncond < 2 ? fc.ncond : 2;
       uint32_t mask2 = fc.gap[0] == 2 ? 1u : 0u;
       if (nc == 2) {

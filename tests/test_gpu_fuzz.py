@@ -38,6 +38,15 @@ def _keyword(rng, mode, L=None):
         lits = max(2, L - int(rng.integers(1, max(2, L // 2))))
         for i in rng.choice(L, L - lits, replace=False):
             kw[int(i)] = "*"
+        if L >= 6 and rng.integers(0, 4) == 0:
+            # one case in four: a RUN of two or three wildcards between literals (the reference's own `But**er` and
+            # `**に*行きますか`, tests/test_monkey_moore.cpp:194-246 -- the wide filter shapes, MM_F8_WIDE / MM_F16_WIDE)
+            run = int(rng.integers(2, 4))
+            at = int(rng.integers(1, L - run))
+            for i in range(at, at + run):
+                kw[i] = "*"
+            kw[at - 1] = kw[at - 1] if kw[at - 1] != "*" else "k"
+            kw[at + run] = kw[at + run] if kw[at + run] != "*" else "v"
         if kw[-1] == "*" and kw[0] == "*":
             kw[0] = "q"
         return "".join(kw), ord("*"), None

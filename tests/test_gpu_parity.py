@@ -426,6 +426,12 @@ def _wildcard_shapes(L):
     return out
 
 
+# runs of two and three wildcards (and longer ones, and every pair of gaps of the wide 8-bit shapes): `But**er` is the
+# reference's own (tests/test_monkey_moore.cpp:194-221; mixed case: the capital becomes a wildcard as well)
+WIDE_KEYWORDS = ["qz**mb", "q**k**x", "bu***er", "abc**de", "ab*c*d", "a***b***c", "ab***cd**ef", "a**bc***d*e", "a****bc", "a*b**c***d",
+                 "ab**c*d", "a***bc**d", "a**b*c", "a***b**c", "a***b*c", "a**b***c", "a*b***c", "ab***c", "a***bc", "a**b****c*d"]
+
+
 @pytest.mark.parametrize("elem,be", [(1, False), (2, False), (2, True)])
 def test_every_wildcard_placement(mm, gpu_engine, oracle, elem, be):
     # Sweeps the SWAR condition shapes of the streaming filter (adjacent and over-a-wildcard
@@ -433,7 +439,7 @@ def test_every_wildcard_placement(mm, gpu_engine, oracle, elem, be):
     # span kernel: ROMs of whole 4 KiB groups plus a ragged tail, matches planted all over.
     rng = np.random.default_rng(2024 + elem + int(be))
     paths = set()
-    for n, kw in enumerate(_wildcard_shapes(6) + ["ab*de*gh", "abc*efgh*jkl", "a*c*e*g", "*b*d*f*h", "ab**ef*hi"]):
+    for n, kw in enumerate(_wildcard_shapes(6) + ["ab*de*gh", "abc*efgh*jkl", "a*c*e*g", "*b*d*f*h", "ab**ef*hi"] + WIDE_KEYWORDS):
         vals = [None if ch == "*" else ord(ch) for ch in kw]
         rom = _random_rom_with_plants(rng, (96 << 10) + 4 * (n % 7) + 2, elem, vals, be)
         gpu_engine.upload(rom)

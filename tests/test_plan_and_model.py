@@ -130,18 +130,28 @@ def test_models_against_reference_engine_vectors(mm):
     # cost it one SWAR subtraction per dword instead of two, so the gap-1 condition three positions back moves up
     (1, "ab*de", [(4, 1), (1, 1), (3, 2)], False),
     (1, "ab*defg", [(6, 1), (5, 1), (4, 1)], False),                    # (the look-back ends 4 bytes behind the anchor)
-    (1, "a*cd*f", [(5, 2), (3, 1)], True),                              # (no choice: one of each)
-    (1, "a*c*ef*h", [(4, 2), (2, 2)], True),                            # ties between anchors: the one whose two conditions share the gap
+    # (two conditions is all one dword of look-back gives these two: the wide shapes take them, with the places beyond it)
+    (1, "a*cd*f", [(5, 2), (3, 1), (2, 2)], False),
+    (1, "a*c*ef*h", [(7, 2), (5, 1), (4, 2), (2, 2)], False),
     (1, "*bcde", [(4, 1), (3, 1), (2, 1)], False),
     (1, "abcd*", [(3, 1), (2, 1), (1, 1)], False),
     (1, "re*ative*ear*hxy", [(7, 1), (6, 1), (5, 1), (4, 1)], False),   # BASELINE C3
-    (1, "a*c*e*g", [(6, 2), (4, 2)], True),
-    (1, "a**d**g", [], None),
+    # the wide shapes (round 6): gaps up to 4 on the hot path, every further condition with run-time places
+    (1, "a*c*e*g", [(6, 2), (4, 2), (2, 2)], False),
+    (1, "a**d**g", [(6, 3), (3, 3)], False),
+    (1, "qz**mb", [(5, 1), (4, 3), (1, 1)], False),
+    (1, "abc**de", [(6, 1), (5, 3), (2, 1), (1, 1)], False),
+    (1, "a***b***c", [(8, 4), (4, 4)], False),
+    (1, "ab***cd**ef", [(10, 1), (9, 3), (6, 1), (5, 4)], False),
+    (1, "a**b", [], None),                                              # (two literals: one 7-bit condition is no filter)
+    (1, "a****bc", [(6, 1)], True),                                     # (a gap of 5: the one-dword shape's single condition)
+    (2, "q**k", [(3, 3)], False),
+    (2, "ab**cd", [(5, 1), (4, 3), (1, 1)], False),
     (2, "textsrch", [(7, 1), (6, 1)], False),                           # BASELINE C4
     (2, "ab*de", [(4, 1), (3, 2)], False),
     (2, "abc*e", [(2, 1), (1, 1)], False),                              # ties go to the contiguous run
     (2, "*bc*e", [(4, 2), (2, 1)], False),
-    (2, "a*c*e", [(4, 2)], True),
+    (2, "a*c*e", [(4, 2), (2, 2)], False),
 ])
 def test_filter_conditions_chosen(mm, elem, kw, conds, verify):
     info = mm.filter_shape(mm.plan_relative(elem, kw, ord("*")))
@@ -157,7 +167,8 @@ def test_filter_conditions_are_necessary_for_a_match(mm, oracle):
     match the oracle reports: the filter may only over-approximate the reference."""
     rng = np.random.default_rng(99)
     for elem in (1, 2):
-        for kw in ("ab*de", "a*c*e*g", "abc*efgh*jkl", "*b*d*f*h", "zyxwv", "ab**ef*hi"):
+        for kw in ("ab*de", "a*c*e*g", "abc*efgh*jkl", "*b*d*f*h", "zyxwv", "ab**ef*hi", "qz**mb", "q**k**x", "a***b***c",
+                   "ab***cd**ef", "a**bc***d*e", "a*b**c***d"):
             plan = mm.plan_relative(elem, kw, ord("*"))
             info = mm.filter_shape(plan)
             assert info["ncond"] >= 1

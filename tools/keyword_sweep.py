@@ -2,7 +2,7 @@
 """Dev probe (round 5): what a synchronous mmh_scan costs over KEYWORD CLASSES on one 4 GiB ROM (C2's recipe: random bytes,
 a planted match per MiB, 1 MiB runs of 0x00 / 0xFF / a ramp) -- lengths 2 .. 128, wildcards in every place, 8- and 16-bit:
 where the cliffs are (few conditions -> candidate floods -> flood paths / forward engine).
-    python tools/keyword_sweep.py        -> profiles/r05_keyword_sweep.log"""
+    python tools/keyword_sweep.py        -> profiles/r06_keyword_sweep.log"""
 import os
 import sys
 import time
@@ -19,9 +19,10 @@ mm.synth.RomSpec(42, N, "relativesrch", 1, None, False, BLOCK)
 eng.alloc(N)
 mm.synth.RomSpec(42, N, "relativesrch", 1, None, False, BLOCK).apply_device(eng)
 CASES = [(1, "relativesrch"), (1, "qz"), (1, "qzv"), (1, "qzvk"), (1, "qzvkm"), (1, "qzvkmbxw"), (1, "q*v"), (1, "qz*k"), (1, "q*vk"), (1, "mo*ke"),
-         (1, "*zvkm"), (1, "qzvk*"), (1, "q*v*m*x"), (1, "q**k**x"), (1, "qz**mb"), (1, "Qzvkm"), (1, "qzvkmbxwqzvkmbxwqzvkmbxwqzvkmbxwq"),
+         (1, "*zvkm"), (1, "qzvk*"), (1, "q*v*m*x"), (1, "q**k**x"), (1, "qz**mb"), (1, "Bu**er"), (1, "qzv**mb"), (1, "q***k***x"), (1, "qz***mb*x"), (1, "ab*de"), (1, "a*cd*f"),
+         (1, "Qzvkm"), (1, "qzvkmbxwqzvkmbxwqzvkmbxwqzvkmbxwq"),
          (1, "q" * 2 + "zvkmbxw" * 9), (1, "zvkmbxw" * 18), (1, "aaaa"), (1, "abcd"),
-         (2, "qz"), (2, "qzv"), (2, "qzvk"), (2, "textsrch"), (2, "q*vk"), (2, "qz*k"), (2, "q*v*m")]
+         (2, "qz"), (2, "qzv"), (2, "qzvk"), (2, "textsrch"), (2, "q*vk"), (2, "qz*k"), (2, "q*v*m"), (2, "q**k"), (2, "qz**mb"), (2, "q***k**x")]
 print("# synchronous mmh_scan over keyword classes: 4 GiB (C2's ROM), 512 KiB blocks; wall ms = median of 5 after 2 warm-up scans")
 for elem, kw in CASES:
     wc = ord("*") if "*" in kw else 0
