@@ -20,6 +20,7 @@ CORE_SO = os.path.join(LIB_DIR, "libmonkey-core.so")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 ROCM_LIB = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")
 ARCH = "gfx950"
+SHAPE_UNITS = 7          # MM_SHAPE_UNITS of csrc/mm_filter_shapes.h
 
 
 def _newer(target, sources):
@@ -62,17 +63,23 @@ def build_capi(force=False):
         return CAPI_SO
     obj_dir = os.path.join(LIB_DIR, "obj")
     os.makedirs(obj_dir, exist_ok=True)
-    units = ("mm_kernels.hip", "mm_capi.hip", "mm_multi.hip", "mm_ingest.hip", "mm_sort.hip", "mm_probe.hip", "mm_plan.cpp")
+    # (mm_filter_shapes.hip is compiled SHAPE_UNITS times, -DMM_FILTER_SHAPE_UNIT=k: the streaming kernels of one group of
+    # filter shapes each -- in one unit they took hipcc four minutes, side by side the slowest takes one)
+    units = [("mm_filter_shapes.hip", k) for k in range(SHAPE_UNITS)]
+    units += [(name, None) for name in ("mm_kernels.hip", "mm_capi.hip", "mm_multi.hip", "mm_ingest.hip", "mm_sort.hip", "mm_probe.hip", "mm_plan.cpp")]
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(ROOT, "include", "mmoore_hip.h")]
     flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
-    def compile_unit(name):
-        src, obj = os.path.join(CSRC, name), os.path.join(obj_dir, name + ".o")
+    def compile_unit(unit):
+        name, shape_unit = unit
+        src = os.path.join(CSRC, name)
+        obj = os.path.join(obj_dir, name + (".o" if shape_unit is None else ".%d.o" % shape_unit))
         if force or _newer(obj, [src] + headers):
-            _run([HIPCC, *flags, "-x", "hip", "-c", src, "-o", obj])
+            define = [] if shape_unit is None else ["-DMM_FILTER_SHAPE_UNIT=%d" % shape_unit]
+            _run([HIPCC, *flags, *define, "-x", "hip", "-c", src, "-o", obj])
         return obj
 
-    with ThreadPoolExecutor(max_workers=4) as pool:
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as pool:
         objs = list(pool.map(compile_unit, units))
     if force or _newer(CAPI_SO, objs):
         # librccl: the multi-GPU offset gather (mm_multi.hip) calls RCCL itself

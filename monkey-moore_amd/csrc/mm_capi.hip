@@ -2572,6 +2572,10 @@ extern "C" int mmh_filter_shape(const mmh_plan_desc *plan, uint32_t *info12)
    std::memset(info12, 0, 12 * sizeof(uint32_t));
    mm::FilterChoice fc;
    if (mm::choose_filter(*plan, &fc)) {
+      if (!mm::shape_known(plan->elem_bytes, fc.shape)) {
+         mmh_set_error("mmh_filter_shape: no streaming kernel of the chosen shape");
+         return MMH_E_STATE;
+      }
       info12[0] = fc.ncond; info12[1] = fc.iA; info12[2] = fc.shape;
       info12[3] = mm::filter_verifies(*plan, fc) ? 1u : 0u;
       for (uint32_t k = 0; k < fc.ncond; k++) {

@@ -607,6 +607,7 @@ __device__ __forceinline__ void mm_resolve_body(const MmResolveArgs &a, const Mm
    }
 }
 
+#ifndef MM_FILTER_SHAPE_UNIT   // (not a template: defined once, in mm_kernels.hip)
 __global__ __launch_bounds__(64 * MM_WAVES) void mm_resolve(MmResolveArgs a)
 {
    __shared__ MmPlanLds P;
@@ -616,6 +617,7 @@ __global__ __launch_bounds__(64 * MM_WAVES) void mm_resolve(MmResolveArgs a)
    mm_plan_to_lds(P, a.t.plan);                 // ends with a __syncthreads()
    mm_resolve_body(a, P, Wv[threadIdx.x >> 6], R);
 }
+#endif
 
 // --------------------------------------------------------------------------
 // second resolver: one workgroup per left-over candidate, waves in parallel
@@ -707,6 +709,7 @@ __device__ __forceinline__ void mm_resolve2_body(const MmResolve2Args &a, const 
    }
 }
 
+#ifndef MM_FILTER_SHAPE_UNIT   // (not a template: defined once, in mm_kernels.hip)
 __global__ __launch_bounds__(64 * MM_WAVES) void mm_resolve2(MmResolve2Args a)
 {
    __shared__ MmPlanLds P;
@@ -718,6 +721,7 @@ __global__ __launch_bounds__(64 * MM_WAVES) void mm_resolve2(MmResolve2Args a)
    mm_plan_to_lds(P, a.t.plan);
    mm_resolve2_body(a, P, Wv[threadIdx.x >> 6], maps);
 }
+#endif
 
 // --------------------------------------------------------------------------
 // hard resolver: MM_HARD_PARTS workgroups map a candidate's whole prefix
@@ -762,6 +766,7 @@ __device__ __forceinline__ void mm_hard_tiles(const MmHardArgs &a, const MmPlanL
    }
 }
 
+#ifndef MM_FILTER_SHAPE_UNIT   // (not a template: defined once, in mm_kernels.hip)
 __global__ __launch_bounds__(64 * MM_WAVES) void mm_hard_resolve(MmHardArgs a)
 {
    __shared__ MmPlanLds P;
@@ -865,5 +870,6 @@ __global__ __launch_bounds__(64 * MM_WAVES) void mm_hard_resolve(MmHardArgs a)
       a.out[a.hard_slot[i]] = mm_report_value(a.t.g, o, a.base_offset);
    }
 }
+#endif
 
 #endif

@@ -1,8 +1,9 @@
 #!/bin/bash
 # Dev probe (build container): register / LDS / scratch use of every kernel in a csrc unit.
 #   tools/kernel_resources.sh mm_kernels.hip [filter-regex]
+#   UNIT=4 tools/kernel_resources.sh mm_filter_shapes.hip "mm_filter_u8<"      (one of the streaming-kernel units, build.py)
 cd "$(dirname "$0")/.."
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Imonkey-moore_amd/csrc -x hip -c monkey-moore_amd/csrc/$1 -o /tmp/kr_$$.o \
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Imonkey-moore_amd/csrc ${UNIT:+-DMM_FILTER_SHAPE_UNIT=$UNIT} -x hip -c monkey-moore_amd/csrc/$1 -o /tmp/kr_$$.o \
    -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c "
 import sys, re
 rows, cur = [], None
