@@ -21,6 +21,19 @@ MASK64 = (1 << 64) - 1
 GOLDEN = 0x9E3779B97F4A7C15
 
 
+def bench_search_buffer(elem_bytes, nbytes, seed=42):
+    """The reference benchmark's own input (benchmarks/bench_search.cpp:11-22, BASELINE config C1): std::mt19937(seed), one
+    uniform_int_distribution<unsigned>(0, max(T)) draw per element -- with a 32-bit engine and a power-of-two range that is
+    the draw's top 8 / 16 bits.  Little-endian bytes of the elements.  (Checked against the compiled reference's own
+    generator in tests/test_oracle.py.)"""
+    bg = np.random.MT19937()
+    bg._legacy_seeding(seed)                                   # init_genrand(seed), what std::mt19937(seed) does
+    raw = bg.random_raw(nbytes // elem_bytes)
+    if elem_bytes == 1:
+        return (raw >> np.uint64(24)).astype(np.uint8)
+    return (raw >> np.uint64(16)).astype("<u2").view(np.uint8)
+
+
 def splitmix_word(seed, k):
     z = (seed + (k + 1) * GOLDEN) & MASK64
     z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & MASK64

@@ -35,7 +35,13 @@ def test_default_line_carries_the_other_baseline_configs():
     # only a fraction above the data-sheet peak would be a wrong clock, whatever the box)
     assert res["roofline"]["kernel"] == "mm_filter_u8<4>" and 0.0 < res["roofline"]["frac"] < 1.0
     other = res["other_configs"]
-    assert sorted(other) == ["C3", "C4", "C4BE"]
+    assert sorted(other) == ["C1", "C3", "C4", "C4BE"]
+    c1 = other.pop("C1")                                       # bench_search.cpp's own buffer and keywords, whole-buffer chain
+    assert sorted(c1["keywords"]) == ["abcde", "monkey"]
+    for kw, o in c1["keywords"].items():
+        assert "identical to" in o["parity"] and o["kernel_ms"] > 0 and o["synchronous"]["ms_per_scan"] > 0, (kw, o)
+        assert o["facade_search"]["ms_per_call"] > 0
+    assert c1["keywords"]["abcde"]["matches"] + c1["keywords"]["monkey"]["matches"] == 0   # (what the reference finds there)
     for name, o in other.items():
         assert 0.0 < o["frac"] < 1.0, (name, o)
         assert "identical to the oracle" in o["parity"]
