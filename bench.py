@@ -567,6 +567,15 @@ def main():
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
+    if world > 1 or args.force_gather or args.torch_gather:
+        # the gather's CHECKER (torch.distributed's all_gather of the same lists) lives with the tests: found now, before
+        # anything is timed, or the run stops here with a plain message -- not with an ImportError behind the timed region
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        try:
+            import _gather_double                                # noqa: F401
+        except ImportError:
+            raise SystemExit("bench.py: tests/_gather_double.py (the checker of the multi-rank offset gather) is not next to bench.py: "
+                             "run it from a checkout of the repository")
 
     # The RCCL stand-in of tests/shim only ever serves a run that asks for it: a figure measured through it is not RCCL's.
     shared = bool(args.allow_shared_device)

@@ -110,7 +110,7 @@ mm::ResolveBuffers resolve_buffers(const MmWorkspace &w)
 // cut into (mm::bucket_geom: <= 4096 buckets, 128 MiB for ROMs of >= 16 MiB; a 64 KiB ROM's 17 buckets take 544 KiB),
 // grown when a larger ROM arrives.  The counters are always there for all MM_MAX_BUCKETS (16 KiB: mm_scan_tail2 sums
 // them all).  (Until round 4 every workspace that met a ROM beyond the single-launch kernel's took the full 128 MiB.)
-int ensure_buckets(mmh_ctx *c, MmWorkspace &w, hipStream_t st, uint64_t rom_bytes)
+int ensure_buckets(mmh_ctx *c, MmWorkspace &w, hipStream_t st, uint64_t rom_bytes, bool clear = true)
 {
    const uint64_t need = mm::bucket_geom(rom_bytes).nb;
    if (!w.d_bcount) {
@@ -130,7 +130,7 @@ int ensure_buckets(mmh_ctx *c, MmWorkspace &w, hipStream_t st, uint64_t rom_byte
       HIP_TRY(hipMalloc(&w.d_bcand, want * MM_BUCKET_CAP * sizeof(uint64_t)));
       w.bcand_buckets = want;
    }
-   if (!w.buckets_clean) {
+   if (clear && !w.buckets_clean) {
       HIP_TRY(hipMemsetAsync(w.d_bcount, 0, mm::bucket_count_bytes(), st));
    }
    return MMH_OK;
@@ -212,6 +212,70 @@ void free_workspace(MmWorkspace &w)
 int mmh_workspace(mmh_ctx *c) { return ensure_workspace(c, c->ws[0], std::max<uint64_t>(c->ws[0].out_cap, kInitialCap)); }
 
 namespace {
+int grow(uint64_t **buf, uint64_t *cap, uint64_t need);
+int ensure_lane(mmh_ctx *c, int lane);
+
+// What the FIRST scan of a ROM would otherwise set up inside its own call (round 6: a ROM hacker scans a keyword once --
+// the first scan is the product; it cost 1.5 to 15 times a later one).  Every entry point that gives the context a ROM
+// ends here: the synchronous workspace; for a ROM in HBM its bucket store; for a ROM the split pipeline takes (>= 1 GiB)
+// the three lanes -- streams, events, workspaces, bucket stores --, result slots for the forward engine's lists at one match
+// in 128 positions (it ran twice when they overflowed: 36 ms for a first `aaaa`), the ordering buffers and the forward
+// engine's maps.  A 4 GiB ROM: ~1 GiB of the 288, once per context.  Nothing here is a memo: no scan leaves anything
+// behind that a later scan's route depends on.
+int prepare_scans(mmh_ctx *c)
+{
+   HIP_TRY(hipSetDevice(c->device));
+   const bool in_hbm = c->rom && c->rom != c->rom_host && c->rom_bytes != 0;
+   const bool big = in_hbm && c->rom_bytes >= kSplitMinBytes;
+   uint64_t out_cap = kInitialCap;
+   if (big) {
+      out_cap = std::min<uint64_t>(std::max<uint64_t>(c->rom_bytes / 128, kInitialCap), 1ull << 25);
+   }
+   int rc = ensure_workspace(c, c->ws[0], std::max<uint64_t>(c->ws[0].out_cap, out_cap));
+   if (rc != MMH_OK || !in_hbm) {
+      return rc;
+   }
+   if (c->rom_bytes > (4ull << 20)) {                      // (beyond the single-launch kernel's ROMs)
+      rc = ensure_buckets(c, c->ws[0], c->stream, c->rom_bytes, false);
+      if (rc != MMH_OK) {
+         return rc;
+      }
+   }
+   if (!big) {
+      return MMH_OK;
+   }
+   for (int lane = 0; lane < mmh_ctx::kLanes; lane++) {
+      rc = ensure_lane(c, lane);
+      if (rc == MMH_OK) {
+         rc = ensure_buckets(c, c->ws[1 + lane], c->stream, c->rom_bytes, false);
+      }
+      if (rc != MMH_OK) {
+         return rc;
+      }
+   }
+   rc = grow(&c->d_sort_in, &c->sort_in_cap, c->ws[0].out_cap);
+   if (rc == MMH_OK) {
+      rc = grow(&c->d_sort_out, &c->sort_out_cap, c->ws[0].out_cap);
+   }
+   if (rc != MMH_OK) {
+      return rc;
+   }
+   // the forward engine's maps: a look-back word and up to MMH_MAX_KEYWORD bytes of map per 32 Ki elements of every domain
+   const size_t dense = (size_t)(c->rom_bytes / 128 + (4u << 20));
+   if (dense > c->dense_bytes) {
+      if (c->d_dense) {
+         HIP_TRY(hipFree(c->d_dense));
+         c->d_dense = nullptr;
+         c->dense_bytes = 0;
+      }
+      HIP_TRY(hipMalloc(&c->d_dense, dense));
+      c->dense_bytes = dense;
+   }
+   return MMH_OK;
+}
+} // namespace
+
+namespace {
 
 // next slot of the event ring
 void begin_scan_events(mmh_ctx *c, bool has_filter)
@@ -227,7 +291,6 @@ void begin_scan_events(mmh_ctx *c, bool has_filter)
 void release_rom(mmh_ctx *c)
 {
    (void)mm_ingest_drain(c);                // (copies of an aborted file load may still be writing the ROM)
-   mm_rom_changed(c);
    if (c->rom_own) {
       (void)hipFree(c->rom_own);
    }
@@ -452,7 +515,6 @@ extern "C" int mmh_rom_alloc(mmh_ctx *c, uint64_t nbytes)
          return rc;
       }
    }
-   mm_rom_changed(c);
    uint64_t need = ((nbytes + 15) / 16) * 16 + 16;
    if (!(c->rom_own && c->rom_alloc >= need)) {
       release_rom(c);
@@ -465,7 +527,7 @@ extern "C" int mmh_rom_alloc(mmh_ctx *c, uint64_t nbytes)
    c->rom_bytes = nbytes;
    // the padding behind the ROM is never interpreted, but keep it defined
    HIP_TRY(hipMemsetAsync(c->rom + (nbytes / 16) * 16, 0, need - (nbytes / 16) * 16, c->stream));
-   return MMH_OK;
+   return prepare_scans(c);
 }
 
 extern "C" int mmh_rom_upload(mmh_ctx *c, const void *host, uint64_t nbytes)
@@ -489,12 +551,11 @@ extern "C" int mmh_rom_upload(mmh_ctx *c, const void *host, uint64_t nbytes)
          c->rom_host = static_cast<uint8_t *>(p);
       }
       // (nothing of an earlier scan still reads the buffer: scans are synchronous, lanes are collected before the ROM may change)
-      mm_rom_changed(c);
       std::memcpy(c->rom_host, host, nbytes);
       std::memset(c->rom_host + nbytes, 0, 32 + (16 - nbytes % 16) % 16);     // the padding behind the ROM stays defined
       c->rom = c->rom_host;
       c->rom_bytes = nbytes;
-      return MMH_OK;
+      return prepare_scans(c);
    }
    int rc = mmh_rom_alloc(c, nbytes);
    if (rc != MMH_OK) {
@@ -520,7 +581,7 @@ extern "C" int mmh_rom_attach(mmh_ctx *c, const void *device_ptr, uint64_t nbyte
    release_rom(c);
    c->rom = const_cast<uint8_t *>(static_cast<const uint8_t *>(device_ptr));
    c->rom_bytes = nbytes;
-   return MMH_OK;
+   return prepare_scans(c);
 }
 
 extern "C" int mmh_rom_download(mmh_ctx *c, uint64_t first_byte, void *host, uint64_t nbytes)
@@ -552,7 +613,6 @@ extern "C" int mmh_rom_synth(mmh_ctx *c, uint64_t seed, uint64_t rom_base_offset
          return rc;
       }
    }
-   mm_rom_changed(c);
    mm::launch_synth(c->stream, c->rom, c->rom_bytes, seed, rom_base_offset);
    HIP_TRY(hipGetLastError());
    return MMH_OK;
@@ -571,7 +631,6 @@ extern "C" int mmh_rom_poke(mmh_ctx *c, uint64_t first_byte, const void *host, u
          return rc;
       }
    }
-   mm_rom_changed(c);
    HIP_TRY(hipMemcpyAsync(c->rom + first_byte, host, nbytes, hipMemcpyDefault, c->stream));
    HIP_TRY(hipStreamSynchronize(c->stream));
    return MMH_OK;
@@ -590,7 +649,6 @@ extern "C" int mmh_rom_fill(mmh_ctx *c, uint64_t first_byte, uint64_t nbytes, in
          return rc;
       }
    }
-   mm_rom_changed(c);
    mm::launch_pattern_fill(c->stream, c->rom, first_byte, nbytes, value, ramp);
    HIP_TRY(hipGetLastError());
    return MMH_OK;
@@ -1342,6 +1400,7 @@ int run_dense(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, uint64_t bas
    HIP_TRY(hipMemsetAsync(c->ws[0].d_ctrl, 0, mm::ctrl_bytes(), st));
    c->ws[0].ctrl_clean = false;
    begin_scan_events(c, false);
+   c->ring_timed[(int)(c->scans_recorded % mmh_ctx::kRing)] = true;   // (this path records its start event whatever mmh_set_timing says)
    HIP_TRY(hipEventRecord(c->ev[0], st));
    HIP_TRY(hipEventRecord(c->ev[1], st));
    mm::launch_dense(st, g, pl, dg, db, base_offset, dom_list);
@@ -1632,27 +1691,6 @@ int check_scan_args(const mmh_ctx *c, const mmh_plan_desc *plan, const char *who
    return MMH_OK;
 }
 
-// identifies a search on this context: plan, block size, byte order, ROM (FNV-1a; 0 is never returned)
-uint64_t search_key(const mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian)
-{
-   uint64_t h = 1469598103934665603ull;
-   auto mix = [&](const void *p, size_t n) {
-      const unsigned char *b = static_cast<const unsigned char *>(p);
-      for (size_t i = 0; i < n; i++) {
-         h = (h ^ b[i]) * 1099511628211ull;
-      }
-   };
-   // (the plan's used part: header + L entries of each table)
-   mix(plan, offsetof(mmh_plan_desc, expected));
-   mix(plan->expected, plan->L * sizeof(int32_t));
-   mix(plan->cmp_mask, plan->L * sizeof(uint32_t));
-   mix(plan->bridge, plan->L);
-   mix(plan->wst, plan->L);
-   const uint64_t more[4] = {block_bytes, (uint64_t)(big_endian != 0), (uint64_t)reinterpret_cast<uintptr_t>(c->rom), c->rom_bytes};
-   mix(more, sizeof more);
-   return h ? h : 1;
-}
-
 MmGeom scan_geometry(const mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian, const MmPending *view = nullptr)
 {
    MmGeom g;
@@ -1690,8 +1728,11 @@ uint32_t candidate_limit(const MmWorkspace &w)
 namespace {
 // *kept: the list when it only exists in host memory (long lists, forward engine); *on_device: the
 // list sits ordered in ws[0].d_result[result_turn]
+// view (scan_split): the bytes [view_first, view_first + view_bytes) of the ROM, block-aligned, instead of all of it;
+// start_dense: the per-candidate path is known to overflow on them (this scan's own parts found out) -- forward engine at once
 int scan_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian, uint64_t base_offset, uint64_t *out,
-              uint64_t cap, uint64_t *out_count, std::vector<uint64_t> *kept, bool *on_device)
+              uint64_t cap, uint64_t *out_count, std::vector<uint64_t> *kept, bool *on_device, const MmPending *view = nullptr,
+              bool start_dense = false)
 {
    if (!c || !plan || !out_count || (!out && cap)) {
       mmh_set_error("mmh_scan: bad argument");
@@ -1707,7 +1748,7 @@ int scan_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int b
    if (rc != MMH_OK) {
       return rc;
    }
-   const MmGeom g = scan_geometry(c, plan, block_bytes, big_endian);
+   const MmGeom g = scan_geometry(c, plan, block_bytes, big_endian, view);
 
    rc = ensure_workspace(c, c->ws[0], std::max<uint64_t>(c->ws[0].out_cap, kInitialCap));
    if (rc != MMH_OK) {
@@ -1726,16 +1767,11 @@ int scan_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int b
    // (keywords beyond 32 symbols: the resolvers' phase sets do not hold their D > 31 phases)
    const bool narrow = plan->L <= MM_RESOLVER_MAX_KEYWORD;
    enum { FAST, SEQUENTIAL, DENSE } mode = c->engine == 1 ? SEQUENTIAL : (c->engine == 2 || !have_filter || !narrow) ? DENSE : FAST;
-   // A search that ended on the forward engine or a flood path last time goes to the forward engine at once (the passes
-   // that found the flood out -- bucketed scan, list-based scan, count pass, filtered pass: 3-4 times over the ROM -- cost
-   // more than the engine itself where its sweep works: 'the' on a ROM with 3 % of script, 6.2 -> ~2.5 ms per 4 GiB).
-   // Every 16th such scan takes the candidate path again: the ROM behind the pointer may have changed.
-   const uint64_t key = c->engine == 0 ? search_key(c, plan, block_bytes, big_endian) : 0;
-   bool hinted = false;
-   static const bool hints = [] { const char *e = getenv("MMOORE_FLOOD_HINT"); return !(e && *e == '0'); }();   // (tests: every scan takes the candidate path first)
-   if (hints && mode == FAST && key != 0 && c->flood_key == key && (++c->flood_uses & 15u) != 0) {
+   // (No memo of earlier scans: until round 5 a search that had ended on the forward engine went there at once the next
+   // time, and every first scan of such a search cost 1.2 to 6 times a later one.  What a scan learns it learns from its
+   // own first part, scan_split.)
+   if (start_dense && mode == FAST) {
       mode = DENSE;
-      hinted = true;
    }
    const uint32_t scan_limit = candidate_limit(c->ws[0]);
    uint32_t max_candidates = scan_limit;
@@ -1860,21 +1896,6 @@ int scan_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int b
    c->counters[1] = oc.matches;
    c->counters[2] = oc.tiles;
    c->counters[3] = mode == SEQUENTIAL ? 1 : (mode == DENSE ? 3 : (flooded_domains ? 5 : (flagged_domains ? 4 : (oc.hard ? 2 : 0))));
-   if (c->engine == 0) {
-      // (what mmh_scan_submit and the hint above go by: this search ended on the forward engine / a flood path -- or no
-      // longer does)
-      if (c->counters[3] >= 3) {
-         if (c->flood_key != key) {
-            c->flood_uses = 0;
-         }
-         c->flood_key = key;
-      }
-      else if (c->flood_key == key) {
-         c->flood_key = 0;
-      }
-   }
-   (void)hinted;
-
    *out_count = oc.matches;
    *on_device = !host_list;
    rc = MMH_OK;
@@ -1896,7 +1917,8 @@ int scan_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int b
 namespace {
 bool split_applies(const mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian);
 int scan_split(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian, uint64_t base_offset, uint64_t *out,
-               uint64_t cap, uint64_t *out_count, bool *settled);
+               uint64_t cap, uint64_t *out_count);
+void scan_timings(mmh_ctx *c, uint64_t k, float *ms4);
 }
 
 // mmh_scan proper + what the multi-GPU gather needs to know about its list (mm_multi.hip)
@@ -1913,12 +1935,7 @@ extern "C" int mmh_scan(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_by
    // (the memo keys hash plan->L entries of the plan's tables: a malformed plan is turned away by scan_impl, not read here)
    if (c && plan && out_count && (out || !cap) && c->rom && check_scan_args(c, plan, "mmh_scan") == MMH_OK &&
        split_applies(c, plan, block_bytes, big_endian)) {
-      bool settled = false;
-      const int rc = scan_split(c, plan, block_bytes, big_endian, base_offset, out, cap, out_count, &settled);
-      if (settled) {
-         return rc;
-      }
-      // (a part could not be settled on its lane, or the search turned sparse: one scan of the whole ROM, as ever)
+      return scan_split(c, plan, block_bytes, big_endian, base_offset, out, cap, out_count);
    }
    std::vector<uint64_t> host_list;
    bool on_device = false;
@@ -1985,6 +2002,30 @@ extern "C" int mmh_scan_submit(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t b
 }
 
 namespace {
+// a lane's workspace and events, the lanes' two streams and the fence event (first use, or ahead of it: prepare_scans)
+int ensure_lane(mmh_ctx *c, int lane)
+{
+   MmWorkspace &w = c->ws[1 + lane];
+   const int rc = ensure_workspace(c, w, std::max<uint64_t>(w.out_cap, kInitialCap));
+   if (rc != MMH_OK) {
+      return rc;
+   }
+   for (int k = 0; k < 2; k++) {
+      if (!c->lane_stream[k]) {
+         HIP_TRY(hipStreamCreateWithFlags(&c->lane_stream[k], hipStreamNonBlocking));
+      }
+   }
+   if (!c->lane_fence) {
+      HIP_TRY(hipEventCreateWithFlags(&c->lane_fence, hipEventDisableTiming));
+   }
+   for (auto &e : c->lane_ev[lane]) {
+      if (!e) {
+         HIP_TRY(hipEventCreate(&e));
+      }
+   }
+   return MMH_OK;
+}
+
 int submit_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian, uint64_t base_offset, int *ticket,
                 bool view, uint64_t view_first, uint64_t view_bytes)
 {
@@ -2008,48 +2049,16 @@ int submit_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int
       return rc;
    }
    MmWorkspace &w = c->ws[1 + lane];
-   rc = ensure_workspace(c, w, std::max<uint64_t>(w.out_cap, kInitialCap));
+   rc = ensure_lane(c, lane);
    if (rc != MMH_OK) {
       return rc;
    }
-   // Which streams a lane scan's kernels go to (MMOORE_LANE_MODE, development knob):
-   //   0  two streams, scan t's streaming kernel AND tail kernel on stream t % 2 (round 2's arrangement)
-   //   1  every streaming kernel on stream 0, back to back; the tail kernels on stream 1, each behind its streaming
-   //      kernel's end event: the next scan's streaming kernel never waits for a tail kernel
-   //   2  streaming kernels alternate between streams 0 and 1, tail kernels on stream 2
-   static const int lane_mode = [] { const char *e = getenv("MMOORE_LANE_MODE"); return e && *e ? atoi(e) : 0; }();
-   const int sidx = lane_mode == 1 ? 0 : c->next_ticket % 2;
-   const int tidx = lane_mode == 1 ? 1 : lane_mode == 2 ? 2 : sidx;
-   for (int k : {sidx, tidx}) {
-      if (!c->lane_stream[k]) {
-         HIP_TRY(hipStreamCreateWithFlags(&c->lane_stream[k], hipStreamNonBlocking));
-      }
-   }
-   const hipStream_t lane_st = c->lane_stream[sidx];
-   const hipStream_t tail_st = c->lane_stream[tidx];
+   // Two streams: scan t's streaming kernel AND tail kernel on stream t % 2.  (Measured and dropped, r03: every streaming
+   // kernel on one stream with the tails on a second; streaming kernels alternating with the tails on a third.)
+   const hipStream_t lane_st = c->lane_stream[c->next_ticket % 2];
+   const hipStream_t tail_st = lane_st;
    c->pending_tail_stream[lane] = tail_st;
-   if (!c->lane_fence) {
-      HIP_TRY(hipEventCreateWithFlags(&c->lane_fence, hipEventDisableTiming));
-   }
-   // Scans in flight share the device best a good part of a streaming kernel apart: the tail kernel of one runs while
-   // the other streams.  From an empty pipeline the first two scans start together; MMOORE_LANE_GATE=p (development
-   // knob) holds the second scan of a burst back by a gate -- one sleeping wave in front of its streaming kernel -- for
-   // p percent of the time a streaming kernel takes.  Measured with round 3's lean tail kernel over five runs per
-   // setting (profiles/r03_lane_gate_repeats.log): 0 / 35 / 50 / 65 / 80 / 100 percent give 0.725-0.735 ms per scan
-   // over the first 20 scans on a box whose steady state is 0.70 -- no difference that shows through the +-1 % run-to-run
-   // spread (the lean tail lets the stagger form within two or three scans by itself).  Default: off -- a burst of
-   // two scans would only finish later for it.
-   int others = 0;
-   bool behind_first = false;
-   for (const MmPending &q : c->pending) {
-      if (q.active) {
-         others++;
-         behind_first = behind_first || (q.first_of_burst && !q.needs_rescan && q.ticket + 1 == c->next_ticket);
-      }
-   }
    p = MmPending();
-   p.first_of_burst = others == 0;
-   const bool gated = others == 1 && behind_first;
    p.ticket = c->next_ticket;
    p.plan = *plan;
    p.block_bytes = block_bytes;
@@ -2063,37 +2072,24 @@ int submit_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int
    const MmGeom g = scan_geometry(c, plan, block_bytes, big_endian, &p);
    mm::FilterChoice fc;
    const bool have_filter = mm::choose_filter(*plan, &fc);
-   if (c->engine != 0 || !have_filter || g.nbytes == 0 || plan->L > MM_RESOLVER_MAX_KEYWORD ||
-       (!view && c->flood_key != 0 && c->flood_key == search_key(c, plan, block_bytes, big_endian) &&
-        !(getenv("MMOORE_FLOOD_HINT") && *getenv("MMOORE_FLOOD_HINT") == '0'))) {
+   if (c->engine != 0 || !have_filter || g.nbytes == 0 || plan->L > MM_RESOLVER_MAX_KEYWORD) {
       p.needs_rescan = true;                    // collect runs mmh_scan
    }
    else {
       // The ROM may still be in the making on the context's stream (upload, synth, poke; a stream the caller gave us: whatever
       // it put there): the lane waits for that -- when there is something to wait for.  An idle stream (one query, no packet)
       // spares the scan an event record, a marker on that stream and a barrier packet in front of its streaming kernel:
-      // ~6 us of a synchronous scan's first part (round 5; MMOORE_LANE_FENCE=always: as before).
-      static const bool fence_always = [] { const char *e = getenv("MMOORE_LANE_FENCE"); return e && *e == 'a'; }();
-      bool idle = false;
-      if (!fence_always) {
-         const hipError_t q = hipStreamQuery(c->stream);
-         idle = q == hipSuccess;
-         if (q != hipSuccess && q != hipErrorNotReady) {
-            (void)hip_ok(q, "hipStreamQuery (the context's stream)");
-            return MMH_E_DEVICE;
-         }
-         if (!idle) {
-            (void)hipGetLastError();                // (hipErrorNotReady is sticky for hipGetLastError)
-         }
+      // ~6 us of a synchronous scan's first part (round 5).
+      const hipError_t q = hipStreamQuery(c->stream);
+      const bool idle = q == hipSuccess;
+      if (q != hipSuccess && q != hipErrorNotReady) {
+         (void)hip_ok(q, "hipStreamQuery (the context's stream)");
+         return MMH_E_DEVICE;
       }
       if (!idle) {
+         (void)hipGetLastError();                   // (hipErrorNotReady is sticky for hipGetLastError)
          HIP_TRY(hipEventRecord(c->lane_fence, c->stream));
          HIP_TRY(hipStreamWaitEvent(lane_st, c->lane_fence, 0));
-      }
-      static const int gate_percent = [] { const char *e = getenv("MMOORE_LANE_GATE"); return e && *e ? atoi(e) : 0; }();
-      if (gated && gate_percent > 0) {
-         // (a streaming kernel reads ~6 TB/s)
-         mm::launch_gate(lane_st, (double)g.nbytes / 6.0e9 * gate_percent / 100.0);
       }
       // How scans in flight share the device (MMOORE_LANE_TRACE=1; rocprofv3 kernel trace, tools/lane_trace.sh).  Scan t
       // starts behind scan t-2 (same stream) and runs beside scan t-1: its streaming kernel begins on the wave slots
@@ -2110,16 +2106,11 @@ int submit_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int
       // kernels of one stream leave ~17 us between them, and nothing overlaps a kernel's drain); streaming kernels
       // alternating on two streams with the tails on a third (0.73-0.75); a scan's filter waiting for the previous
       // scan's "filter done" event (0.77-0.91); holding scan t back until the streaming kernel of t-1 is 60 .. 95 %
-      // through its rounds (0.725-0.76); a gate in front of the second scan of a burst (above: no measurable difference).
+      // through its rounds (0.725-0.76); a gate in front of the second scan of a burst (no measurable difference).
       // What did help in round 3: a tail kernel that fits beside a streaming kernel (mm_scan_tail2, 61 VGPRs) on a
       // small grid (512 workgroups) -- 0.71-0.735 ms per scan over the first 20 scans from an empty pipeline over
       // boxes and runs (round 2: 0.745-0.76).  Round 4: the grouped tail (80 / 96 VGPRs) on 1024 workgroups, 0.698-0.707.
       settle_lane_timing(c, lane);             // (before the lane's events are recorded again)
-      for (auto &e : c->lane_ev[lane]) {
-         if (!e) {
-            HIP_TRY(hipEventCreate(&e));
-         }
-      }
       std::copy(c->lane_ev[lane], c->lane_ev[lane] + 3, p.ev);
       // (filter + tail kernel, the end polled in the lane's own pinned block; never the single-launch kernel:
       // its grid barrier wants the device to itself)
@@ -2252,21 +2243,23 @@ namespace {
 // submit lanes: part k's tail kernel and host work run while part k + 1 streams, consecutive streaming kernels overlap
 // on the lanes' two streams, and what is left in the open is the last part's tail.
 //
-// Round 4 only did this from the SECOND scan of a search it had seen to be dense (a memo keyed on plan + ROM); a ROM
-// hacker scans a keyword once.  Now the first scan decides by itself: the first two parts are an eighth of the ROM each
-// (0.09 ms of streaming at 4 GiB); by the time the first one is collected its candidate count tells what the search is
-// like, and the rest goes as ONE part (sparse: C2's 4223 candidates -- every part costs ~10 us of launches and ramp), as
-// two (tens of thousands of candidates) or in eighths (hundreds of thousands: th*s, 251 K candidates per 4 GiB, 1.33 ->
-// 1.06 ms).  Measured per part count on first scans, profiles/r05_first_scan_knobs.log.
-//
-// A part whose bucketed store overflows (a flood: more than 4096 candidates in one bucket -- 1 MiB of a 4 GiB part) gives
-// the pipeline up; the scan starts over in parts of a sixteenth of the unit (narrower buckets: 'the' on the text-like ROM,
-// 0.76 M matches, 6.3 -> 1.8 ms through the candidate path instead of the flood path), and only when that overflows as
-// well does the whole ROM go the usual way (scan_impl: list-based kernels, flood paths, forward engine).
+// Every scan decides by itself, from its own parts -- nothing is remembered from one scan to the next (rounds 4 and 5
+// kept memos keyed on plan + ROM: "sparse", "floods the usual parts", "floods"; a ROM hacker scans a keyword once, and a
+// first scan cost 1.2 to 15 times a later one):
+//   1. the first two parts are an eighth and three eighths of the ROM; by the time the first one is collected its
+//      candidate count tells what the search is like, and the rest goes as ONE part (sparse: C2's 4223 candidates -- every
+//      part costs ~10 us of launches and ramp), as two (tens of thousands of candidates) or in eighths (hundreds of
+//      thousands: th*s, 251 K candidates per 4 GiB, 1.33 -> 1.06 ms);
+//   2. a part whose bucketed store overflows (a flood: more than 4096 candidates in one bucket -- 1 MiB of a 4 GiB part)
+//      ends stage 1 THERE: what the parts in front of it delivered stays, and the ROM from that part on goes in parts of a
+//      sixteenth (narrower buckets: 'the' on a text-like ROM, 0.76 M matches, through the candidate path);
+//   3. where those overflow as well -- or a part needs what the lanes do not run -- the REST of the ROM is one synchronous
+//      scan (scan_impl on a view): the forward engine at once after an overflow, its usual route otherwise.
+// Parts are collected in ROM order, so a stage's good parts are a prefix of the list.
 bool split_applies(const mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian)
 {
-   static const bool on = [] { const char *e = getenv("MMOORE_DENSE_SPLIT"); return !(e && *e == '0'); }();
-   if (!on || (routes_off(c) & MMH_ROUTE_NO_SPLIT) || c->engine != 0 || block_bytes == 0 || !c->rom || c->rom == c->rom_host ||
+   (void)big_endian;
+   if ((routes_off(c) & MMH_ROUTE_NO_SPLIT) || c->engine != 0 || block_bytes == 0 || !c->rom || c->rom == c->rom_host ||
        c->rom_bytes < kSplitMinBytes || (block_bytes & 15) != 0 || block_bytes > kSplitUnitMin || plan->L > MM_RESOLVER_MAX_KEYWORD) {
       return false;
    }
@@ -2276,64 +2269,50 @@ bool split_applies(const mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_b
       }
    }
    mm::FilterChoice fc;
-   if (!mm::choose_filter(*plan, &fc)) {
-      return false;                                 // no SWAR key: the forward engine's
-   }
-   // (a search known to flood goes straight to the forward engine: scan_impl's hint)
-   return !(c->flood_key != 0 && c->flood_key == search_key(c, plan, block_bytes, big_endian));
+   return mm::choose_filter(*plan, &fc);            // (no SWAR key: the forward engine's)
 }
 
-// one attempt at the pipeline with parts of `unit` blocks (adaptive: see above); *overflowed: it was given up because a
-// part's bucketed store overflowed
-int scan_split_try(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian, uint64_t base_offset, uint64_t *out,
-                   uint64_t cap, uint64_t *out_count, bool *settled, uint64_t unit, bool adaptive, bool *overflowed, uint32_t *parts_run,
-                   bool *sparse)
+// what a split scan has so far: the blocks [0, done_blocks) are settled, their `total` offsets at the head of the caller's buffer
+struct SplitProgress {
+   uint64_t done_blocks = 0, total = 0, candidates = 0, tiles = 0;
+   uint32_t parts = 0;
+   bool hard = false;
+};
+
+// One stage of the pipeline: parts of `unit` blocks from pg->done_blocks on (adaptive: see 1. above) until the ROM's end
+// or the first part that does not settle; *overflowed: that part's bucketed store overflowed.  Returns an error only for
+// failures of the device / arguments; a part that does not settle just ends the stage (pg says how far it got).
+int split_stage(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian, uint64_t base_offset, uint64_t *out,
+                uint64_t cap, SplitProgress *pg, uint64_t unit, bool adaptive, bool *overflowed)
 {
-   *settled = false;
    *overflowed = false;
-   *out_count = 0;
    const uint64_t N = c->rom_bytes, S = plan->elem_bytes;
    const uint64_t nblocks = (N + block_bytes - 1) / block_bytes;
    const uint64_t overlap = (uint64_t)(plan->L - 1) * S;
-   static const uint64_t forced_parts = [] { const char *e = getenv("MMOORE_SPLIT_PARTS"); return (uint64_t)(e && *e ? atoi(e) : 0); }();
-   if (forced_parts) {                              // (development knob: equal parts, nothing adaptive)
-      unit = std::max<uint64_t>(1, (nblocks + forced_parts - 1) / forced_parts);
-      adaptive = false;
-   }
    int tickets[mmh_ctx::kLanes];
+   uint64_t ends[mmh_ctx::kLanes];                  // the block behind ticket k's part
    int outstanding = 0;
-   uint64_t total = 0, candidates = 0, tiles = 0;
-   uint64_t next_block = 0, step = unit, collected = 0, submitted = 0;
-   bool failed = false, hard = false;
+   uint64_t next_block = pg->done_blocks, step = unit, collected = 0, submitted = 0;
+   bool failed = false;
    int error = MMH_OK;
-   const uint64_t first_recorded = c->scans_recorded;
-   const auto t_start = std::chrono::steady_clock::now();
-   // MMOORE_SPLIT_TRACE=1 (development): when the host was done with every submit and collect of the pipeline
-   static const bool split_trace = getenv("MMOORE_SPLIT_TRACE") != nullptr;
-   char trace_line[512];
-   size_t trace_len = 0;
-   auto trace = [&](const char *what) {
-      if (split_trace && trace_len + 48 < sizeof(trace_line)) {
-         trace_len += (size_t)snprintf(trace_line + trace_len, sizeof(trace_line) - trace_len, " %s %.1f", what,
-                                       std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() * 1e6);
-      }
-   };
    auto collect_oldest = [&]() {
       uint64_t n = 0;
       bool unsettled = false, overflow = false;
-      const uint64_t room = total <= cap ? cap - total : 0;
+      // (behind a part that did not settle the later ones are only taken off their lanes: the next stage scans them again)
+      const uint64_t room = failed ? 0 : (pg->total <= cap ? cap - pg->total : 0);
       uint64_t nowhere = 0;                         // (no room left: the part is only counted)
       c->device_idle_hint = next_block >= nblocks;       // (everything is submitted: what is still collected lies in the open)
-      int rc = collect_impl(c, tickets[0], room ? out + total : &nowhere, room, &n, &unsettled, &overflow);
+      int rc = collect_impl(c, tickets[0], room ? out + pg->total : &nowhere, room, &n, &unsettled, &overflow);
       c->device_idle_hint = false;
-      trace("collected");
       if (rc == MMH_E_CAPACITY) {
          // (the part's list is in its lane's block; only the count matters now: the caller comes back with more room)
          c->pending[((tickets[0] % mmh_ctx::kLanes) + mmh_ctx::kLanes) % mmh_ctx::kLanes].active = false;
          rc = MMH_OK;
       }
+      const uint64_t end = ends[0];
       for (int k = 1; k < outstanding; k++) {
          tickets[k - 1] = tickets[k];
+         ends[k - 1] = ends[k];
       }
       outstanding--;
       if (rc != MMH_OK) {
@@ -2341,15 +2320,19 @@ int scan_split_try(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, 
          failed = true;
          return;
       }
+      if (failed) {
+         return;
+      }
       if (unsettled) {
-         *overflowed = *overflowed || overflow;
+         *overflowed = overflow;
          failed = true;
          return;
       }
-      total += n;
-      candidates += c->counters[0];
-      tiles += c->counters[2];
-      hard = hard || c->counters[3] == 2;
+      pg->total += n;
+      pg->done_blocks = end;
+      pg->candidates += c->counters[0];
+      pg->tiles += c->counters[2];
+      pg->hard = pg->hard || c->counters[3] == 2;
       if (adaptive && collected++ == 0) {
          // What the search is like, from the first eighth: the second half of the ROM in one part, in two, or in eighths.
          // (thresholds in candidates per unit; 4 GiB: < 2 K = 16 K per ROM: one; < 25 K = 200 K per ROM: two)
@@ -2357,7 +2340,6 @@ int scan_split_try(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, 
          const uint64_t left = nblocks > next_block ? nblocks - next_block : 0;
          step = per_unit < 2048 ? left : per_unit < 25600 ? (left + 1) / 2 : unit;
          step = std::max<uint64_t>(step, 1);
-         *sparse = per_unit < 2048;
       }
    };
    while (next_block < nblocks && !failed) {
@@ -2376,111 +2358,104 @@ int scan_split_try(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, 
       const uint64_t bytes = std::min((b1 - b0) * block_bytes + overlap, N - first);
       int t = 0;
       const int rc = submit_impl(c, plan, block_bytes, big_endian, base_offset + first, &t, true, first, bytes);
-      trace("submitted");
       if (rc != MMH_OK) {
          error = rc;
          failed = true;
          break;
       }
-      tickets[outstanding++] = t;
+      tickets[outstanding] = t;
+      ends[outstanding++] = b1;
       next_block = b1;
-      (*parts_run)++;
+      pg->parts++;
    }
    while (outstanding) {
       collect_oldest();                             // (also behind a failure: no ticket stays outstanding)
    }
-   // The parts' timings as ONE entry of the history: [streaming kernels of all parts, summed -- they overlap, so the sum
-   // exceeds their share of the wall time --, the pipeline's wall time on the host].  (Each collected part left an entry
-   // of its own: mmh_last_timings after a split scan described one eighth of the ROM)
    for (int lane = 0; lane < mmh_ctx::kLanes; lane++) {
       settle_lane_timing(c, lane);
    }
-   if (split_trace) {
-      trace("timings settled");
-      fprintf(stderr, "mmh_scan pipeline of %u parts, host clock in us from its start:%s\n", *parts_run, trace_line);
+   return error;
+}
+
+int scan_split(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian, uint64_t base_offset, uint64_t *out,
+               uint64_t cap, uint64_t *out_count)
+{
+   *out_count = 0;
+   const uint64_t N = c->rom_bytes;
+   const uint64_t nblocks = (N + block_bytes - 1) / block_bytes;
+   // an eighth of the ROM, but no less than 256 MiB (a 1 GiB ROM: quarters)
+   const uint64_t unit = std::max<uint64_t>(std::max<uint64_t>((nblocks + 7) / 8, (kSplitUnitMin + block_bytes - 1) / block_bytes), 1);
+   // ... and half of that for the ROM behind a flood (a sixteenth, at least 64 MiB: a part's buckets are a 4096th of it wide)
+   const uint64_t fine = std::max<uint64_t>(unit / 2, ((64ull << 20) + block_bytes - 1) / block_bytes);
+   const uint64_t first_recorded = c->scans_recorded;
+   const auto t_start = std::chrono::steady_clock::now();
+   SplitProgress pg;
+   bool overflowed = false;
+   int rc = split_stage(c, plan, block_bytes, big_endian, base_offset, out, cap, &pg, unit, true, &overflowed);
+   if (rc == MMH_OK && pg.done_blocks < nblocks && overflowed && fine < unit) {
+      rc = split_stage(c, plan, block_bytes, big_endian, base_offset, out, cap, &pg, fine, false, &overflowed);
    }
+   uint64_t path = pg.hard ? 2 : 0;
+   std::vector<uint64_t> rest_list;                 // (what scan_impl keeps of a list that only exists on the host: not needed here)
+   if (rc == MMH_OK && pg.done_blocks < nblocks) {
+      // the rest of the ROM in one synchronous scan
+      MmPending view;
+      view.view = true;
+      view.view_first = pg.done_blocks * block_bytes;
+      view.view_bytes = N - view.view_first;
+      const uint64_t room = pg.total <= cap ? cap - pg.total : 0;
+      uint64_t nowhere = 0, n = 0;
+      bool on_device = false;
+      rc = scan_impl(c, plan, block_bytes, big_endian, base_offset + view.view_first, room ? out + pg.total : &nowhere, room, &n, &rest_list,
+                     &on_device, &view, overflowed);
+      if (rc == MMH_E_CAPACITY) {
+         rc = MMH_OK;                               // (counted below against the caller's whole buffer)
+      }
+      pg.total += n;
+      pg.candidates += c->counters[0];
+      pg.tiles += c->counters[2];
+      path = c->counters[3] ? c->counters[3] : path;
+      pg.parts++;
+      pg.done_blocks = nblocks;
+   }
+   // The parts' timings as ONE entry of the history: [streaming kernels of all parts, summed -- they overlap, so the sum
+   // exceeds their share of the wall time --, the scan's wall time on the host].
    if (c->scans_recorded > first_recorded && c->scans_recorded - first_recorded <= mmh_ctx::kRing) {
       float filter_sum = 0;
       for (uint64_t k = first_recorded; k < c->scans_recorded; k++) {
-         const int slot = (int)(k % mmh_ctx::kRing);
-         filter_sum += c->ring_is_ms[slot] ? c->ring_ms[slot][0] : 0.0f;
+         float t[4] = {0, 0, 0, 0};
+         scan_timings(c, k, t);
+         filter_sum += t[0];
       }
       const int slot = (int)(first_recorded % mmh_ctx::kRing);
       c->ring_is_ms[slot] = true;
       c->ring_ms[slot][0] = filter_sum;
       c->ring_ms[slot][1] = (float)(std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() * 1e3);
-      c->ring_parts[slot] = *parts_run;
+      c->ring_parts[slot] = pg.parts;
       c->scans_recorded = first_recorded + 1;
    }
-   if (error != MMH_OK) {
-      *settled = true;
-      return error;
+   if (rc != MMH_OK) {
+      return rc;
    }
-   if (failed) {
-      return MMH_OK;
-   }
-   *settled = true;
-   *out_count = total;
-   c->counters[0] = candidates;
-   c->counters[1] = total;
-   c->counters[2] = tiles;
-   c->counters[3] = hard ? 2 : 0;
+   *out_count = pg.total;
+   c->counters[0] = pg.candidates;
+   c->counters[1] = pg.total;
+   c->counters[2] = pg.tiles;
+   c->counters[3] = path;
    // the list exists in the caller's buffer only (a gather that wants it: from the host)
    c->mg.last_src = nullptr;
    c->mg.last_end = nullptr;
    c->mg.last_slots = 0;
-   c->mg.last_count = total;
+   c->mg.last_count = pg.total;
    c->mg.last_list.clear();
-   if (total > cap) {
-      mmh_set_error("mmh_scan: %llu matches do not fit the caller's buffer of %llu", (unsigned long long)total, (unsigned long long)cap);
+   if (pg.total > cap) {
+      mmh_set_error("mmh_scan: %llu matches do not fit the caller's buffer of %llu", (unsigned long long)pg.total, (unsigned long long)cap);
       return MMH_E_CAPACITY;
    }
    if (c->mg.comm) {
-      c->mg.last_list.assign(out, out + total);
+      c->mg.last_list.assign(out, out + pg.total);
    }
    return MMH_OK;
-}
-
-int scan_split(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian, uint64_t base_offset, uint64_t *out,
-               uint64_t cap, uint64_t *out_count, bool *settled)
-{
-   const uint64_t nblocks = (c->rom_bytes + block_bytes - 1) / block_bytes;
-   // an eighth of the ROM, but no less than 256 MiB (a 1 GiB ROM: quarters)
-   const uint64_t unit = std::max<uint64_t>(std::max<uint64_t>((nblocks + 7) / 8, (kSplitUnitMin + block_bytes - 1) / block_bytes), 1);
-   bool overflowed = false, sparse = false;
-   uint32_t parts = 0;
-   int rc = MMH_OK;
-   const uint64_t key = search_key(c, plan, block_bytes, big_endian);
-   if (c->fine_key == key) {
-      overflowed = true;                            // (known to flood parts of the usual width: the finer ones at once)
-   }
-   else if (c->sparse_key == key) {
-      // known to be sparse (the verdict of its first scan, until the ROM changes): two halves -- nothing to find out, and
-      // every further part costs ~10 us of launches and ramp (profiles/r05_first_scan_adaptive.log: 0.743 against 0.760 ms)
-      rc = scan_split_try(c, plan, block_bytes, big_endian, base_offset, out, cap, out_count, settled, (nblocks + 1) / 2, false, &overflowed,
-                          &parts, &sparse);
-   }
-   else {
-      rc = scan_split_try(c, plan, block_bytes, big_endian, base_offset, out, cap, out_count, settled, unit, true, &overflowed, &parts, &sparse);
-      if (*settled && sparse) {
-         c->sparse_key = key;
-      }
-   }
-   if (*settled || !overflowed) {
-      return rc;
-   }
-   // a flood for buckets of this width: equal parts of half a unit (a sixteenth of the ROM, at least 64 MiB: a part's
-   // buckets are a 4096th of it wide), remembered for this search until the ROM changes
-   const uint64_t fine = std::max<uint64_t>(unit / 2, ((64ull << 20) + block_bytes - 1) / block_bytes);
-   if (fine >= unit) {
-      return rc;
-   }
-   parts = 0;
-   rc = scan_split_try(c, plan, block_bytes, big_endian, base_offset, out, cap, out_count, settled, fine, false, &overflowed, &parts, &sparse);
-   if (*settled && rc == MMH_OK) {
-      c->fine_key = key;
-   }
-   return rc;
 }
 
 } // namespace

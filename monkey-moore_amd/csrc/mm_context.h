@@ -139,7 +139,6 @@ struct MmComm {
 struct MmPending {
    bool active = false;
    bool needs_rescan = false;       // plan / engine choice the lanes do not run: collect scans synchronously
-   bool first_of_burst = false;     // it was submitted into an empty pipeline
    int ticket = 0;
    mmh_plan_desc plan{};
    uint64_t block_bytes = 0;
@@ -215,14 +214,6 @@ struct mmh_ctx {
    MmPending pending[kLanes];
    int next_ticket = 0;
    int engine = 0;
-   // What the last synchronous scan that went to the forward engine or a flood path (counters[3] >= 3) looked like: a
-   // ticket submitted for the same search is not put on a lane at all -- its streaming + tail kernels would be thrown
-   // away and collect would scan again synchronously (round 3 measured floods SLOWER in flight than one at a time).
-   uint64_t flood_key = 0;
-   uint32_t flood_uses = 0;         // synchronous scans that took the hint since (every 16th tries the candidate path again)
-   uint64_t sparse_key = 0;         // the last search the split pipeline's first part found sparse: scanned again in two halves
-   uint64_t fine_key = 0;           // the last search whose candidates overflowed the buckets of the split pipeline's usual parts
-                                    // and were settled by narrower ones (scan_split): the next scan of it starts with those
    bool fused_ok = true;            // cleared for good when a fused scan's grid barrier ever timed out on this context
    uint32_t route_off = 0;          // MMH_ROUTE_* bits switched off on this context (mmh_set_route); the process-wide ones come on top
    MmHealth health;
@@ -230,17 +221,6 @@ struct mmh_ctx {
    MmIngest ingest;
    MmComm mg;
 };
-
-// The ROM's bytes (or the ROM itself) are about to change: what the context remembers about earlier searches of it --
-// "this search floods" (flood_key) -- is keyed on plan + ROM pointer + size, not on the contents, and must not outlive
-// them (every mmh_rom_* entry point that writes the ROM calls this).
-inline void mm_rom_changed(mmh_ctx *c)
-{
-   c->flood_key = 0;
-   c->flood_uses = 0;
-   c->fine_key = 0;
-   c->sparse_key = 0;
-}
 
 // defined in mm_capi.hip
 int mmh_workspace(mmh_ctx *c);

@@ -33,6 +33,9 @@
 // cross-check.
 //
 // No MFMA anywhere: the path is integer byte comparison (BASELINE.json).
+#include <atomic>
+#include <cstdio>
+
 #include "mm_filter.h"
 #include "mm_filter_shapes.h"
 
@@ -672,16 +675,19 @@ static void launch_loud(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl
 // compute units of the current device (cached per device: the attribute query costs a few hundred nanoseconds)
 static unsigned device_cus()
 {
-   static int cached[64] = {};
+   // (mmh_scan_multi runs one host thread per device through here: relaxed atomics -- racing threads store the same value)
+   static std::atomic<int> cached[64];
    int device = 0;
    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) {
       return 256;
    }
-   if (cached[device] == 0) {
+   int have = cached[device].load(std::memory_order_relaxed);
+   if (have == 0) {
       int cus = 0;
-      cached[device] = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0 ? cus : 256;
+      have = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0 ? cus : 256;
+      cached[device].store(have, std::memory_order_relaxed);
    }
-   return (unsigned)cached[device];
+   return (unsigned)have;
 }
 
 static unsigned fused_resident_blocks()

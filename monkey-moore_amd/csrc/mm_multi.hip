@@ -383,6 +383,16 @@ extern "C" void mmh_comm_destroy(mmh_ctx *c)
 
 namespace {
 
+// After a failure the slots' next gathers send the WIDE record whatever their previous ones saw: a rank that left a gather
+// early (a time-out, an error between two contexts' steps) no longer knows what its peers saw, and ranks that disagree
+// about the width would issue all-gathers of different counts.
+void gather_reset_width(mmh_ctx *c)
+{
+   for (MmGatherSlot &s : c->mg.slot) {
+      s.last_longest = ~0ull;
+   }
+}
+
 // step 1: the record to send.  offsets == nullptr: the list of the most recent mmh_scan -- in
 // place in HBM when the scan ordered it there, else from the host copy the scan kept.
 int gather_prepare(mmh_ctx *c, const uint64_t *offsets, uint64_t n, const uint64_t **send)
@@ -399,8 +409,9 @@ int gather_prepare(mmh_ctx *c, const uint64_t *offsets, uint64_t n, const uint64
    }
    HIP_TRY(hipSetDevice(c->device));
    const double t0 = now_s();
-   static const bool adaptive = [] { const char *e = getenv("MMOORE_GATHER_NARROW"); return !(e && *e == '0'); }();
-   s.limit = adaptive && s.last_longest <= kNarrowKeep ? kNarrowSlots : (uint32_t)MM_MAX_RANK_SORT;
+   // (the width is the slot's state, the same on every rank while every rank completes every gather: what the previous
+   // gather's table said.  A failure anywhere puts the slots back to the wide record, gather_reset_width.)
+   s.limit = s.last_longest <= kNarrowKeep ? kNarrowSlots : (uint32_t)MM_MAX_RANK_SORT;
    s.from_host = true;
    s.kept = false;                                  // (of the slot's previous gather)
    if (!offsets && n == 0) {
@@ -664,6 +675,9 @@ extern "C" int mmh_gather_start(mmh_ctx *c, const uint64_t *offsets, uint64_t n,
    if (rc == MMH_OK) {
       rc = gather_pack(c, want_list);
    }
+   if (rc != MMH_OK && rc != MMH_E_STATE) {                  // (MMH_E_STATE: refused before anything was touched)
+      gather_reset_width(c);
+   }
    return rc;
 }
 
@@ -678,6 +692,9 @@ extern "C" int mmh_gather_finish(mmh_ctx *c, uint64_t *out, uint64_t cap, uint64
    uint64_t total = 0, longest = 0;
    int rc = gather_wait(c, &total, &longest);
    if (rc != MMH_OK) {
+      if (rc != MMH_E_STATE) {
+         gather_reset_width(c);
+      }
       return rc;
    }
    MmGatherSlot &s = c->mg.slot[c->mg.oldest];
@@ -689,10 +706,15 @@ extern "C" int mmh_gather_finish(mmh_ctx *c, uint64_t *out, uint64_t cap, uint64
          rc = long_collective(c, longest);
       }
       if (rc != MMH_OK) {
+         gather_reset_width(c);
          return rc;
       }
    }
-   return gather_deliver(c, out, cap, out_count, t0);
+   rc = gather_deliver(c, out, cap, out_count, t0);
+   if (rc != MMH_OK && rc != MMH_E_CAPACITY) {               // (MMH_E_CAPACITY: the gather stays outstanding, nothing is lost)
+      gather_reset_width(c);
+   }
+   return rc;
 }
 
 extern "C" int mmh_last_gather_timings(mmh_ctx *c, float *ms2)
@@ -763,6 +785,9 @@ extern "C" int mmh_selftest_gather_pack(mmh_ctx *c, const uint64_t *records, int
 // one process, several GPUs
 // --------------------------------------------------------------------------
 
+static int scan_multi_checked(mmh_ctx *const *ctxs, int n, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian,
+                              const uint64_t *base_offsets, uint64_t *out, uint64_t cap, uint64_t *out_count);
+
 extern "C" int mmh_scan_multi(mmh_ctx *const *ctxs, int n, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian,
                               const uint64_t *base_offsets, uint64_t *out, uint64_t cap, uint64_t *out_count)
 {
@@ -777,6 +802,19 @@ extern "C" int mmh_scan_multi(mmh_ctx *const *ctxs, int n, const mmh_plan_desc *
          return MMH_E_STATE;
       }
    }
+   const int rc = scan_multi_checked(ctxs, n, plan, block_bytes, big_endian, base_offsets, out, cap, out_count);
+   if (rc != MMH_OK && rc != MMH_E_CAPACITY) {
+      // a step failed after some contexts had taken it: their slots no longer agree about the record width
+      for (int i = 0; i < n; i++) {
+         gather_reset_width(ctxs[i]);
+      }
+   }
+   return rc;
+}
+
+static int scan_multi_checked(mmh_ctx *const *ctxs, int n, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian,
+                              const uint64_t *base_offsets, uint64_t *out, uint64_t cap, uint64_t *out_count)
+{
    // the scans: one host thread per device (a scan ends in a host wait); nothing is exchanged
    std::vector<int> rcs(n, MMH_OK);
    std::vector<std::string> errors(n);

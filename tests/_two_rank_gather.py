@@ -26,10 +26,16 @@ BLOCK = 524288
 
 def main():
     rank, nranks, rdv = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
-    assert ctypes.CDLL(None).fake_rccl_loaded() == 1, "the RCCL stand-in is not preloaded"
+    # MM_RANK_OWN_GPU=1: one rank per GPU over librccl itself (tests/test_gpu_multi.py arms that on a node with >= 2 GPUs)
+    own_gpu = os.environ.get("MM_RANK_OWN_GPU") == "1"
+    try:
+        stand_in = ctypes.CDLL(None).fake_rccl_loaded() == 1
+    except (AttributeError, OSError):
+        stand_in = False
+    assert stand_in != own_gpu, "the RCCL stand-in is %s" % ("preloaded, and RCCL itself was asked for" if stand_in else "not preloaded")
     mm = load_package()
     orc = Oracle()
-    eng = mm.Engine(0)
+    eng = mm.Engine(rank if own_gpu else 0)
     assert eng.comm_info() == (0, 0)
 
     # rendezvous: rank 0 makes the id, the others read it from the file

@@ -263,10 +263,8 @@ def test_fuzz_with_a_small_candidate_limit(tmp_path):
     import subprocess
     import sys
     report = tmp_path / "paths.json"
-    # (MMOORE_FLOOD_HINT=0: every scan takes the candidate path first -- with the hint a search that flooded once goes to
-    # the forward engine at once when it is scanned again, and paths 4 / 5 are only what first scans take)
     env = dict(os.environ, MMOORE_MAX_CANDIDATES="16384", MM_FUZZ_SEEDS="48", MM_FUZZ_MEDIUM="32", MM_FUZZ_LONG="1",
-               MM_FUZZ_REPORT=str(report), MMOORE_FLOOD_HINT="0")
+               MM_FUZZ_REPORT=str(report))
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_fuzz.py"), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
                         "-k", "against_oracle or medium_roms or reached_every"], env=env, capture_output=True, text=True, timeout=1500,

@@ -276,14 +276,18 @@ def test_native_gather_next_to_torch_nccl():
     assert "native gather ok" in r.stdout
 
 
-def _run_ranks(script, nranks, extra_env=None, timeout=420):
-    """nranks processes of a tests/_*.py script on GPU 0 under the RCCL stand-in; every one must exit 0.  Returns their output."""
+def _run_ranks(script, nranks, extra_env=None, timeout=420, stand_in=True):
+    """nranks processes of a tests/_*.py script on GPU 0 under the RCCL stand-in (stand_in=False: no preload -- librccl itself,
+    the script puts every rank on a GPU of its own); every one must exit 0.  Returns their output."""
     import glob
     import tempfile
     from conftest import build_fake_rccl
-    shim = build_fake_rccl()
     rdv = tempfile.mkdtemp(prefix="mm_rdv_")
-    env = dict(os.environ, LD_PRELOAD=shim, MMOORE_GATHER_TIMEOUT_S="60", **(extra_env or {}))
+    env = dict(os.environ, MMOORE_GATHER_TIMEOUT_S="60", **(extra_env or {}))
+    if stand_in:
+        env["LD_PRELOAD"] = build_fake_rccl()
+    else:
+        env.pop("LD_PRELOAD", None)
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", script), str(r), str(nranks), rdv], stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True, env=env, cwd=ROOT) for r in range(nranks)]
     outs, failed = [], False
@@ -328,6 +332,55 @@ def test_native_gather_two_ranks_one_gpu(mm, nranks):
     outs = _run_ranks("_two_rank_gather.py", nranks)
     for r, o in enumerate(outs):
         assert "rank %d of %d ok: rccl_ranks %d" % (r, nranks, nranks) in o, o[-2000:]
+
+
+def _visible_gpus(mm):
+    return mm.device_count()
+
+
+@pytest.mark.parametrize("want", [2, 8])
+def test_native_gather_over_rccl_one_rank_per_gpu(mm, want):
+    """ARMS ITSELF on a node with >= 2 GPUs (skipped on the one-GPU pool): the same script, one rank per GPU, NO stand-in --
+    the library's communicator and gathers over librccl and xGMI.  The contract is the reference dispatcher's and merge's
+    (src/core/search_engine.cpp:66-188, :193-197): every block searched once, the merged list ascending -- every gathered
+    list against the oracle over the WHOLE ROM, on every rank.  want = 2, and as many ranks as there are GPUs (at most 8)."""
+    have = _visible_gpus(mm)
+    if have < 2:
+        pytest.skip("%d GPU visible: RCCL refuses ranks that share a device (the stand-in tests above cover N > 1 here)" % have)
+    nranks = 2 if want == 2 else min(8, have)
+    if want == 8 and nranks == 2:
+        pytest.skip("2 GPUs: the two-rank run above is all there is")
+    outs = _run_ranks("_two_rank_gather.py", nranks, extra_env={"MM_RANK_OWN_GPU": "1"}, timeout=900, stand_in=False)
+    for r, o in enumerate(outs):
+        assert "rank %d of %d ok: rccl_ranks %d" % (r, nranks, nranks) in o, o[-2000:]
+
+
+@pytest.mark.parametrize("want", [2, 8])
+def test_bench_over_rccl_one_rank_per_gpu(mm, want):
+    """ARMS ITSELF on a node with >= 2 GPUs: `bench.py --gpus N` the way the driver launches it (one rank per GPU, librccl,
+    no stand-in) -- rccl_ranks == N on every rank, the native gather identical to the torch.distributed double's, weak and
+    strong legs, rank 0's merged list holding every partition's plants."""
+    import json
+    have = _visible_gpus(mm)
+    if have < 2:
+        pytest.skip("%d GPU visible" % have)
+    nranks = 2 if want == 2 else min(8, have)
+    if want == 8 and nranks == 2:
+        pytest.skip("2 GPUs: the two-rank run above is all there is")
+    env = dict(os.environ, MASTER_PORT=str(29300 + os.getpid() % 300))
+    env.pop("LD_PRELOAD", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nranks), "--gib-per-gpu", "0.25", "--steps", "6",
+                        "--warmup", "2", "--prewarm-s", "0.02", "--no-cpu-baseline"], capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, r.stdout[-2000:]
+    res = json.loads(line[0])
+    assert res["n_gpus"] == nranks and res["value"] > 0 and "shared_device" not in res
+    assert res["rccl_ranks"] == {"min": nranks, "max": nranks, "expected": nranks}
+    assert "librccl" in res["gather_backend"]
+    assert "identical" in res["gather_check"] and "%d ranks" % nranks in res["gather_check"]
+    assert res["config"]["matches"] > 250 * nranks
+    assert res["strong"]["n_gpus"] == nranks and res["strong"]["matches"] > 250
 
 
 @pytest.mark.parametrize("n", [2, 4, 8])
