@@ -214,6 +214,8 @@ int mmh_workspace(mmh_ctx *c) { return ensure_workspace(c, c->ws[0], std::max<ui
 namespace {
 int grow(uint64_t **buf, uint64_t *cap, uint64_t need);
 int ensure_lane(mmh_ctx *c, int lane);
+int ensure_fetch_ring(mmh_ctx *c);
+int ensure_sort_temp(mmh_ctx *c, uint64_t n);
 
 // What the FIRST scan of a ROM would otherwise set up inside its own call (round 6: a ROM hacker scans a keyword once --
 // the first scan is the product; it cost 1.5 to 15 times a later one).  Every entry point that gives the context a ROM
@@ -256,6 +258,12 @@ int prepare_scans(mmh_ctx *c)
    rc = grow(&c->d_sort_in, &c->sort_in_cap, c->ws[0].out_cap);
    if (rc == MMH_OK) {
       rc = grow(&c->d_sort_out, &c->sort_out_cap, c->ws[0].out_cap);
+   }
+   if (rc == MMH_OK) {
+      rc = ensure_sort_temp(c, c->ws[0].out_cap);
+   }
+   if (rc == MMH_OK) {
+      rc = ensure_fetch_ring(c);
    }
    if (rc != MMH_OK) {
       return rc;
@@ -382,6 +390,74 @@ bool selftest_enabled()
 
 } // namespace
 
+namespace {
+int sort_on_device(mmh_ctx *c, const uint64_t *keys, uint64_t n);
+int fetch_device_list(mmh_ctx *c, const uint64_t *d_list, uint64_t n, uint64_t *dst, uint64_t cap, uint64_t *matches);
+std::once_flag g_warm_once[kSelftestDevices];
+
+// Once per device and process, at the first mmh_create: what the HIP runtime does lazily at a first use, done before any
+// caller's scan is on the clock (round 6, tools/first_scan_fresh.py: a first scan cost 1.5 to 16 times a later one; the
+// API trace, profiles/r06_first_scan_api_trace.txt, shows where: the code object of a translation unit is loaded at the
+// first launch of one of its kernels -- 1.5 to 3 ms per unit of streaming kernels, 23 ms for rocPRIM's radix sort --, the
+// first asynchronous device-to-host copy sets up its engine in 9 ms, the first streams take 3 to 9 ms each).
+// A scratch context scans an 8 MiB synthetic ROM through every engine and element width and sorts a list; every other
+// unit's kernels are looked up once (which loads their code objects).  Failures here are not errors: a caller's scan
+// then simply pays what this would have paid.
+void warm_device(int device)
+{
+   mmh_ctx *t = nullptr;
+   if (create_context(device, &t) != MMH_OK) {
+      return;
+   }
+   mm::preload_kernels();
+   const uint64_t n = 8ull << 20;
+   uint32_t kw[65];
+   for (int i = 0; i < 65; i++) {
+      kw[i] = (uint32_t)('a' + (i * 7) % 26);
+   }
+   std::vector<uint64_t> out(4096);
+   uint64_t count = 0;
+   if (mmh_rom_alloc(t, n) == MMH_OK && mmh_rom_synth(t, 0x6d6d6f6f7265ull, 0) == MMH_OK) {
+      for (int engine : {0, 2}) {
+         (void)mmh_set_engine(t, engine);
+         for (uint32_t elem : {1u, 2u}) {
+            for (uint32_t len : {12u, 65u}) {
+               mmh_plan_desc plan;
+               if (mmh_plan_relative(elem, kw, len, 0, nullptr, 0, &plan) == MMH_OK) {
+                  (void)mmh_scan(t, &plan, 524288, 0, 0, out.data(), out.size(), &count);
+               }
+            }
+         }
+      }
+      (void)mmh_set_engine(t, 0);
+      // three scans in flight: the lanes' streams
+      mmh_plan_desc plan;
+      int tickets[mmh_ctx::kLanes];
+      if (mmh_plan_relative(1, kw, 12, 0, nullptr, 0, &plan) == MMH_OK) {
+         int have = 0;
+         for (; have < mmh_ctx::kLanes && mmh_scan_submit(t, &plan, 524288, 0, 0, &tickets[have]) == MMH_OK; have++) {
+         }
+         for (int k = 0; k < have; k++) {
+            (void)mmh_scan_collect(t, tickets[k], out.data(), out.size(), &count);
+         }
+      }
+      // long lists: both of the radix sort's regimes, the pinned pieces, an asynchronous copy to the host
+      if (grow(&t->d_sort_in, &t->sort_in_cap, 1u << 20) == MMH_OK &&
+          hipMemsetAsync(t->d_sort_in, 0x5a, (1u << 20) * sizeof(uint64_t), t->stream) == hipSuccess) {
+         uint64_t kept = 0;
+         for (uint64_t keys : {4096ull, 1ull << 20}) {
+            if (sort_on_device(t, t->d_sort_in, keys) == MMH_OK) {
+               (void)fetch_device_list(t, t->d_sort_out, std::min<uint64_t>(keys, 65536), out.data(), out.size(), &kept);
+            }
+         }
+      }
+      (void)hipStreamSynchronize(t->stream);
+   }
+   (void)hipGetLastError();
+   mmh_destroy(t);
+}
+} // namespace
+
 extern "C" int mmh_create(int device, mmh_ctx **out)
 {
    if (!out) {
@@ -391,6 +467,9 @@ extern "C" int mmh_create(int device, mmh_ctx **out)
    const int rc = create_context(device, out);
    if (rc != MMH_OK) {
       return rc;
+   }
+   if (device < kSelftestDevices) {
+      std::call_once(g_warm_once[device], [device] { warm_device(device); });
    }
    if (selftest_enabled() && device < kSelftestDevices) {
       std::call_once(g_selftest_once[device], [device] {
@@ -1271,15 +1350,9 @@ int sort_on_device(mmh_ctx *c, const uint64_t *keys, uint64_t n)
    if (rc != MMH_OK) {
       return rc;
    }
-   const size_t tmp = mm::sort_temp_bytes(n);
-   if (tmp > c->sort_tmp_bytes) {
-      if (c->d_sort_tmp) {
-         HIP_TRY(hipFree(c->d_sort_tmp));
-         c->d_sort_tmp = nullptr;
-         c->sort_tmp_bytes = 0;
-      }
-      HIP_TRY(hipMalloc(&c->d_sort_tmp, tmp + tmp / 4));
-      c->sort_tmp_bytes = tmp + tmp / 4;
+   rc = ensure_sort_temp(c, n);
+   if (rc != MMH_OK) {
+      return rc;
    }
    HIP_TRY(mm::sort_keys(c->stream, keys, c->d_sort_out, n, c->d_sort_tmp, c->sort_tmp_bytes));
    return MMH_OK;
@@ -1290,17 +1363,45 @@ int sort_on_device(mmh_ctx *c, const uint64_t *keys, uint64_t n)
 // hipMemcpyAsync write straight into a freshly value-initialised std::vector, pageable memory: 134 MB of offsets reached the
 // caller at 1.6 GB/s, through three passes over them.)  dst may be null or too small: then the keys are only counted.
 // *matches = keys in front of the first hole.
-int fetch_device_list(mmh_ctx *c, const uint64_t *d_list, uint64_t n, uint64_t *dst, uint64_t cap, uint64_t *matches)
+constexpr uint64_t kPiece = 1u << 20;                        // keys per piece of a long list's way to the host: 8 MiB
+
+// the two pinned pieces long lists come to the host through (first use, or ahead of it: prepare_scans)
+int ensure_fetch_ring(mmh_ctx *c)
 {
-   constexpr uint64_t kPiece = 1u << 20;                     // keys per piece: 8 MiB
-   *matches = 0;
-   if (n == 0) {
-      return MMH_OK;
-   }
    for (int k = 0; k < 2; k++) {
       if (!c->h_ring[k]) {
          HIP_TRY(hipHostMalloc(&c->h_ring[k], kPiece * sizeof(uint64_t), hipHostMallocDefault));
          HIP_TRY(hipEventCreateWithFlags(&c->ring_ev[k], hipEventDisableTiming));
+      }
+   }
+   return MMH_OK;
+}
+
+int ensure_sort_temp(mmh_ctx *c, uint64_t n)
+{
+   const size_t tmp = mm::sort_temp_bytes(n);
+   if (tmp > c->sort_tmp_bytes) {
+      if (c->d_sort_tmp) {
+         HIP_TRY(hipFree(c->d_sort_tmp));
+         c->d_sort_tmp = nullptr;
+         c->sort_tmp_bytes = 0;
+      }
+      HIP_TRY(hipMalloc(&c->d_sort_tmp, tmp + tmp / 4));
+      c->sort_tmp_bytes = tmp + tmp / 4;
+   }
+   return MMH_OK;
+}
+
+int fetch_device_list(mmh_ctx *c, const uint64_t *d_list, uint64_t n, uint64_t *dst, uint64_t cap, uint64_t *matches)
+{
+   *matches = 0;
+   if (n == 0) {
+      return MMH_OK;
+   }
+   {
+      const int rc = ensure_fetch_ring(c);
+      if (rc != MMH_OK) {
+         return rc;
       }
    }
    const uint64_t pieces = (n + kPiece - 1) / kPiece;

@@ -34,6 +34,8 @@ struct FilterChoice {
 bool choose_filter(const mmh_plan_desc &pl, FilterChoice *fc);
 // whether a streaming kernel of that shape exists (mm_filter_shapes.h; every shape choose_filter hands out must)
 bool shape_known(uint32_t elem_bytes, uint32_t shape);
+// every streaming kernel looked up once (loads the units' code objects ahead of a first scan)
+void preload_kernels();
 // true: the filter kernel runs the full compare loop on its survivors; false: mm_resolve does
 bool filter_verifies(const mmh_plan_desc &pl, const FilterChoice &fc);
 

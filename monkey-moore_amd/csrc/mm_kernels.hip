@@ -603,6 +603,23 @@ static const ShapeKernels *find_shape(uint32_t elem_bytes, uint32_t shape)
 
 bool shape_known(uint32_t elem_bytes, uint32_t shape) { return find_shape(elem_bytes, shape) != nullptr; }
 
+// Looks every streaming kernel up once: the HIP runtime loads a translation unit's code object at the first use of one of
+// its kernels (1.5 - 3 ms per unit, measured inside first scans), and resolves every kernel at its first launch.
+void preload_kernels()
+{
+   static const ShapeKernels *const units[MM_SHAPE_UNITS] = {shape_unit_0(), shape_unit_1(), shape_unit_2(), shape_unit_3(),
+                                                             shape_unit_4(), shape_unit_5(), shape_unit_6()};
+   hipFuncAttributes attr;
+   for (const ShapeKernels *unit : units) {
+      for (const ShapeKernels *k = unit; k->elem_bytes; k++) {
+         (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(k->span));
+         (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(k->edge));
+         (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(k->fused));
+      }
+   }
+   (void)hipGetLastError();
+}
+
 static const ShapeKernels &shape_kernels(uint32_t elem_bytes, const FilterChoice &fc)
 {
    const ShapeKernels *k = find_shape(elem_bytes, fc.shape);

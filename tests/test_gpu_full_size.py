@@ -202,17 +202,18 @@ def test_big_rom_split_pipeline(mm, oracle):
             sparse = eng.scan(other, block_bytes=BLOCK, big_endian=be)
             assert sparse.tolist() == oracle_engine_parallel(oracle, oracle.plan(elem, "zqxjkvbwpy"[: len(kw)]), rom, BLOCK, be).tolist()
             assert eng.timings()["parts"] == 3, eng.timings()
-            # ... and scanned again: known to be sparse, two halves -- until the ROM changes
-            assert eng.scan(other, block_bytes=BLOCK, big_endian=be).tolist() == sparse.tolist() and eng.timings()["parts"] == 2, eng.timings()
+            # ... and scanned again: the same route -- a scan leaves nothing behind that the next one's route depends on (round 6)
+            assert eng.scan(other, block_bytes=BLOCK, big_endian=be).tolist() == sparse.tolist() and eng.timings()["parts"] == 3, eng.timings()
             eng.poke(5, rom[5:6])
             assert eng.scan(other, block_bytes=BLOCK, big_endian=be).tolist() == sparse.tolist() and eng.timings()["parts"] == 3, eng.timings()
             assert eng.health()["fallbacks"] == 0
 
 
 def test_flood_in_a_part_takes_finer_parts_then_the_flood_paths(mm, oracle):
-    """A part of the pipeline whose bucketed store overflows gives the pipeline up: the scan starts over in parts a
-    sixteenth as wide (narrower buckets: the candidate path still does it), and a search that floods those as well goes the
-    whole-ROM way (list-based kernels, flood paths, forward engine) -- and is remembered, until the ROM changes."""
+    """A part of the pipeline whose bucketed store overflows ends the stage THERE: what the parts in front of it delivered
+    stays, the ROM from that part on goes in parts a sixteenth as wide (narrower buckets: the candidate path still does it),
+    and where those flood as well the rest of the ROM is one synchronous scan on the forward engine.  Nothing is remembered:
+    the second scan of a search takes the route of the first."""
     rng = np.random.default_rng(5)
     nbytes = (1 << 30) + 524288 * 5
     rom = rng.integers(0, 256, nbytes, dtype=np.uint8)
@@ -229,10 +230,12 @@ def test_flood_in_a_part_takes_finer_parts_then_the_flood_paths(mm, oracle):
             got = eng.scan(mm.plan_relative(1, kw), block_bytes=BLOCK, cap=1 << 22)
             assert got.tolist() == want.tolist() and len(want) > 100000
             assert eng.counters()["path"] in path_set, (kw, eng.counters(), eng.timings())
+            parts, path = eng.timings()["parts"], eng.counters()["path"]
             if kw == "the":
-                assert eng.timings()["parts"] > 8, eng.timings()                            # the finer parts settled it
-            again = eng.scan(mm.plan_relative(1, kw), block_bytes=BLOCK, cap=1 << 22)       # (a flood: remembered, straight to the forward engine)
+                assert parts > 8, eng.timings()                                              # the finer parts settled it
+            again = eng.scan(mm.plan_relative(1, kw), block_bytes=BLOCK, cap=1 << 22)
             assert again.tolist() == want.tolist()
+            assert (eng.timings()["parts"], eng.counters()["path"]) == (parts, path)         # the same route again
         eng.poke(0, rom[:1])                                                                 # the ROM "changed": nothing is remembered
         assert eng.scan(mm.plan_relative(1, "aaa"), block_bytes=BLOCK, cap=1 << 22).tolist() == want.tolist()
         assert eng.health()["fallbacks"] == 0
