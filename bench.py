@@ -254,54 +254,60 @@ def cpu_baseline(mm, eng, shard_bytes, cfg, want_bytes, warmups, runs, with_end_
                                      "(benchmarks/bench_search.cpp shape), 3 warm-ups, 10 runs"), offs, n, e2e
 
 
-def measure_pmc_traffic(kernel):
-    """HBM bytes per launch of the dominant kernel, COUNTED in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE
-    (separate passes, nothing else traced) around two short child runs of this script -- started before this process has
-    touched the GPU, the program itself directly behind `--`.  FETCH_SIZE is doubled per the gfx950 rule of
-    MI355X_MICROARCH.md (it reports half of a wide coalesced streaming read), both counters are KiB.
-    Returns (bytes per launch or None, how it was obtained / why not)."""
+def measure_pmc_traffic(kernel, config="C2"):
+    """HBM bytes per launch of the dominant kernel and its instruction mix, COUNTED in this run: rocprofv3 --pmc FETCH_SIZE,
+    --pmc WRITE_SIZE and --pmc SQ_INSTS_VALU SQ_INSTS_LDS (three passes, nothing else traced) around short child runs of this
+    script on the same configuration -- started before this process has touched the GPU, the program itself directly behind
+    `--`.  FETCH_SIZE is doubled per the gfx950 rule of MI355X_MICROARCH.md (it reports half of a wide coalesced streaming
+    read), both byte counters are KiB; the SQ counters count wave instructions (x 64 lanes).
+    Returns (bytes per launch or None, how it was obtained / why not, {counter: mean per launch})."""
     import csv
     import glob
     import subprocess
     import tempfile
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
-        return None, "rocprofv3 not found: not measured in this run"
-    child = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--depth", "1", "--no-cpu-baseline",
+        return None, "rocprofv3 not found: not measured in this run", {}
+    child = [sys.executable, os.path.abspath(__file__), "--config", config, "--steps", "3", "--warmup", "1", "--depth", "1", "--no-cpu-baseline",
              "--no-other-depth", "--no-other-configs", "--no-strong", "--no-read-probe", "--no-pmc", "--no-split", "--prewarm-s", "0.05"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     env["TMPDIR"] = "/tmp"
     got = {}
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    for counters in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_INSTS_VALU", "SQ_INSTS_LDS")):
         d = tempfile.mkdtemp(prefix="mm_pmc_", dir="/tmp")
         try:
-            r = subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
-                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=90)
-            vals = []
+            r = subprocess.run([exe, "--pmc", *counters, "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=120)
+            rows = []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
-                    vals += [float(row["Counter_Value"]) for row in csv.DictReader(fh)
-                             if row.get("Counter_Name") == counter and row["Kernel_Name"].startswith("void " + kernel + "(")]
-            if r.returncode != 0 or not vals:
-                return None, "rocprofv3 --pmc %s: rc %d, %d launches of %s counted (%s): not measured in this run" % (
-                    counter, r.returncode, len(vals), kernel, (r.stderr or "").strip().splitlines()[-1][:120] if r.stderr else "")
-            got[counter] = (sum(vals) / len(vals) * 1024.0, len(vals))
+                    rows += [row for row in csv.DictReader(fh) if row["Kernel_Name"].startswith("void " + kernel + "(")]
+            for counter in counters:
+                vals = [float(row["Counter_Value"]) for row in rows if row.get("Counter_Name") == counter]
+                if r.returncode != 0 or not vals:
+                    if counter.startswith("SQ_"):
+                        continue                              # (the instruction mix is an extra: the traffic figure stands without it)
+                    return None, "rocprofv3 --pmc %s: rc %d, %d launches of %s counted (%s): not measured in this run" % (
+                        counter, r.returncode, len(vals), kernel, (r.stderr or "").strip().splitlines()[-1][:120] if r.stderr else ""), {}
+                got[counter] = (sum(vals) / len(vals), len(vals))
         except Exception as e:                                # noqa: BLE001 -- a box without counters must not cost the line
-            return None, "rocprofv3 --pmc %s failed (%s: %s): not measured in this run" % (counter, type(e).__name__, e)
+            if counters[0].startswith("SQ_"):
+                continue
+            return None, "rocprofv3 --pmc %s failed (%s: %s): not measured in this run" % (counters[0], type(e).__name__, e), {}
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    fetch, write = got["FETCH_SIZE"], got["WRITE_SIZE"]
+    fetch, write = (got["FETCH_SIZE"][0] * 1024.0, got["FETCH_SIZE"][1]), (got["WRITE_SIZE"][0] * 1024.0, got["WRITE_SIZE"][1])
     return 2 * fetch[0] + write[0], (
         "counted in this run: rocprofv3 --pmc FETCH_SIZE (%d launches of %s, %.0f bytes each, doubled per the gfx950 rule) and "
-        "--pmc WRITE_SIZE (%d launches, %.0f bytes each) around two child runs of this script (--steps 3 --depth 1, the same "
-        "4 GiB ROM and keyword, --no-split: every launch covers the whole ROM), started before this process touched the GPU" % (
-            fetch[1], kernel, fetch[0], write[1], write[0]))
+        "--pmc WRITE_SIZE (%d launches, %.0f bytes each) around child runs of this script (--config %s --steps 3 --depth 1, the same "
+        "ROM and keyword, --no-split: every launch covers the whole ROM), started before this process touched the GPU" % (
+            fetch[1], kernel, fetch[0], write[1], write[0], config)), {k: v[0] for k, v in got.items()}
 
 
 def pmc_traffic(mm, shard):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes -- only when they were taken
     with THIS device code (the summary carries the hash of the library's sources), else null."""
-    for name in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
+    for name in ("r06_pmc_summary.json", "r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -555,10 +561,15 @@ def main():
 
     # `roofline.traffic` counted in the run itself: the driver's own command line only (N = 1, C2 at full size, nothing
     # switched off), and before anything here touches the GPU
-    live_traffic = (None, None)
-    if (world == 1 and args.config == "C2" and args.gib_per_gpu is None and not args.force_gather and not args.no_pmc
-            and not args.no_cpu_baseline and not args.no_other_configs):
-        live_traffic = measure_pmc_traffic("mm_filter_u8<4>")
+    live_traffic = (None, None, {})
+    if (world == 1 and args.gib_per_gpu is None and not args.force_gather and not args.no_pmc
+            and (args.config != "C2" or (not args.no_cpu_baseline and not args.no_other_configs))):
+        # (host only: the kernel the timed configuration's keyword selects)
+        from __graft_entry__ import load_package as _load
+        _mm = _load()
+        _cfg = CONFIGS[args.config]
+        _shape = _mm.filter_shape(_mm.plan_relative(_cfg["elem"], _cfg["keyword"], _cfg["wildcard"] or 0))["shape"]
+        live_traffic = measure_pmc_traffic("mm_filter_u%d<%d>" % (8 * _cfg["elem"], _shape), args.config)
 
     # (the pool's host driver only supports dmabuf IPC: RCCL across processes needs this; exported on the boxes already)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -963,7 +974,7 @@ def main():
         assert float(np.mean(filt_ms)) > 0
         achieved = shard / (filt * 1e-3) / 1e9
         # (C3 runs the same kernel instantiation with other constants: the same traffic per byte in all likelihood, but not what was counted)
-        traffic, traffic_src = live_traffic if live_traffic[0] is not None else pmc_traffic(mm, shard) if kernel_name == "mm_filter_u8<4>" and args.config in ("C2", "C5") else (
+        traffic, traffic_src = live_traffic[:2] if live_traffic[0] is not None else pmc_traffic(mm, shard) if kernel_name == "mm_filter_u8<4>" and args.config in ("C2", "C5") else (
             None, "the committed PMC passes were taken on mm_filter_u8<4> under C2's workload (C5: the same scan on a bigger shard), not on %s under %s" % (
                 kernel_name, args.config))
         res = {
@@ -994,7 +1005,9 @@ def main():
                     (" (synchronous)" if args.sync_gather else ", overlapped with the next scan")),
                 "scans_in_flight": args.depth,
                 "step": ("mmh_scan_submit + mmh_scan_collect of an earlier ticket: K scans submitted and K results delivered "
-                         "inside the timed region, %d tickets outstanding (two scans at work on the device)" % args.depth
+                         "inside the timed region, %d tickets outstanding (two scans at work on the device) -- `value` is the PERIOD of "
+                         "scans in flight; what ONE scan takes a caller of the reference's synchronous API is "
+                         "`synchronous.without_timing_events` (mmh_scan, one at a time)" % args.depth
                          if args.depth > 1 else "mmh_scan: every step waits for its own result"),
                 "prewarm_scans": prewarm_scans,
                 "launches_by_phase": launches_by_phase,
@@ -1010,6 +1023,9 @@ def main():
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "traffic_over_algorithmic": (traffic / shard) if traffic else None,
+                # SURVEY 8(d)'s secondary ceilings, counted like the traffic (wave instructions x 64 lanes / ROM bytes of a launch)
+                "valu_lane_ops_per_byte": (live_traffic[2]["SQ_INSTS_VALU"] * 64.0 / shard) if "SQ_INSTS_VALU" in live_traffic[2] else None,
+                "lds_lane_reads_per_byte": (live_traffic[2]["SQ_INSTS_LDS"] * 64.0 / shard) if "SQ_INSTS_LDS" in live_traffic[2] else None,
                 **({"traffic_not_counted_in_this_run": live_traffic[1]} if live_traffic[0] is None and live_traffic[1] else {}),
                 "measured_read_ceiling_GBps": (read_probe or {}).get("mean_GBps"),
                 "frac_of_measured": (achieved / read_probe["mean_GBps"]) if read_probe and read_probe.get("mean_GBps") else None,

@@ -34,6 +34,8 @@ def test_default_line_carries_the_other_baseline_configs():
     # (what the line says is checked for shape and consistency here; how fast the box was is the line's business --
     # only a fraction above the data-sheet peak would be a wrong clock, whatever the box)
     assert res["roofline"]["kernel"] == "mm_filter_u8<4>" and 0.0 < res["roofline"]["frac"] < 1.0
+    assert "valu_lane_ops_per_byte" in res["roofline"] and "lds_lane_reads_per_byte" in res["roofline"]
+    assert "synchronous.without_timing_events" in res["config"]["step"]
     other = res["other_configs"]
     assert sorted(other) == ["C1", "C3", "C4", "C4BE"]
     c1 = other.pop("C1")                                       # bench_search.cpp's own buffer and keywords, whole-buffer chain
@@ -59,6 +61,22 @@ def test_config_flag_times_that_configuration(name, dtype):
     assert res["roofline"]["kernel"].startswith("mm_filter_" + dtype)
     assert res["roofline"]["traffic"] is None                 # the PMC passes are C2's kernel's
     assert res["synchronous"]["same_offsets"] is True
+
+
+def test_config_flag_at_full_size_counts_its_own_traffic():
+    """`--config C3` at BASELINE's size: roofline.traffic and the instruction mix are counted for C3's own kernel in this run
+    (rocprofv3 --pmc children; where a box has no counters the line says why and carries null)."""
+    r, lines = _bench(["--config", "C3", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    roof = lines[0]["roofline"]
+    assert roof["kernel"].startswith("mm_filter_u8<")
+    if roof["traffic"] is None:
+        assert roof.get("traffic_not_counted_in_this_run"), roof
+        return
+    assert "counted in this run" in roof["traffic_source"] and "--config C3" in roof["traffic_source"]
+    assert 0.9 < roof["traffic_over_algorithmic"] < 1.5, roof            # (counters, not clocks: every ROM byte is read once)
+    assert roof["valu_lane_ops_per_byte"] and roof["valu_lane_ops_per_byte"] > 1.0
+    assert roof["lds_lane_reads_per_byte"] is not None
 
 
 def test_more_ranks_than_gpus_is_refused_not_faked():

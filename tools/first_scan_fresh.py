@@ -34,8 +34,15 @@ def child(item):
         n = len(r)
     steady = float(np.median(wall[3:]))
     ctr, tm = eng.counters(), eng.timings()
-    print("%2d-bit %-18s %9d matches path %d parts %d | first %8.3f ms, second %8.3f, steady (median of 4..10) %8.3f | first / steady %.2f" % (
-        8 * elem, kw[:18], n, ctr["path"], tm.get("parts", 0), wall[0], wall[1], steady, wall[0] / steady), flush=True)
+    # the same scan after the device has sat idle for half a second (clocks down): what part of "first" is just "after a pause"
+    idle = []
+    for _ in range(3):
+        time.sleep(0.5)
+        t0 = time.perf_counter()
+        eng.scan(plan, block_bytes=BLOCK, cap=1 << 25)
+        idle.append((time.perf_counter() - t0) * 1e3)
+    print("%2d-bit %-18s %9d matches path %d parts %d | first %8.3f ms, second %8.3f, steady (median of 4..10) %8.3f | first / steady %.2f | after 0.5 s idle %8.3f ms (%.2f x steady)" % (
+        8 * elem, kw[:18], n, ctr["path"], tm.get("parts", 0), wall[0], wall[1], steady, wall[0] / steady, float(np.median(idle)), float(np.median(idle)) / steady), flush=True)
 
 
 if __name__ == "__main__":
