@@ -110,9 +110,11 @@ mm::ResolveBuffers resolve_buffers(const MmWorkspace &w)
 // cut into (mm::bucket_geom: <= 4096 buckets, 128 MiB for ROMs of >= 16 MiB; a 64 KiB ROM's 17 buckets take 544 KiB),
 // grown when a larger ROM arrives.  The counters are always there for all MM_MAX_BUCKETS (16 KiB: mm_scan_tail2 sums
 // them all).  (Until round 4 every workspace that met a ROM beyond the single-launch kernel's took the full 128 MiB.)
+// (clear = false, prepare_scans: the store for ANY ROM or part of one -- a part of a big ROM is cut into more buckets than
+// the ROM itself, 3073 for three eighths of 4 GiB against 2049 -- and no memset on a stream the scan does not run on)
 int ensure_buckets(mmh_ctx *c, MmWorkspace &w, hipStream_t st, uint64_t rom_bytes, bool clear = true)
 {
-   const uint64_t need = mm::bucket_geom(rom_bytes).nb;
+   const uint64_t need = clear ? mm::bucket_geom(rom_bytes).nb : (uint64_t)MM_MAX_BUCKETS;
    if (!w.d_bcount) {
       HIP_TRY(hipSetDevice(c->device));
       HIP_TRY(hipMalloc(&w.d_bcount, mm::bucket_count_bytes()));
@@ -255,6 +257,25 @@ int prepare_scans(mmh_ctx *c)
          return rc;
       }
    }
+   // A stream gets its hardware queue at its first submission and an event its signal at its first record (0.1 - 0.2 ms
+   // each, inside a first scan): one fill of a control word per lane stream, every lane event recorded once, now.
+   for (int lane = 0; lane < mmh_ctx::kLanes; lane++) {
+      const hipStream_t st = c->lane_stream[lane % 2];
+      HIP_TRY(hipMemsetAsync(c->ws[1 + lane].d_ctrl, 0, sizeof(unsigned long long), st));
+      for (auto &e : c->lane_ev[lane]) {
+         HIP_TRY(hipEventRecord(e, st));
+      }
+   }
+   for (auto &triple : c->ring) {
+      for (auto &e : triple) {
+         HIP_TRY(hipEventRecord(e, c->stream));
+      }
+   }
+   HIP_TRY(hipEventRecord(c->lane_fence, c->stream));
+   for (int k = 0; k < 2; k++) {
+      HIP_TRY(hipStreamSynchronize(c->lane_stream[k]));
+   }
+   HIP_TRY(hipStreamSynchronize(c->stream));
    rc = grow(&c->d_sort_in, &c->sort_in_cap, c->ws[0].out_cap);
    if (rc == MMH_OK) {
       rc = grow(&c->d_sort_out, &c->sort_out_cap, c->ws[0].out_cap);
