@@ -2286,7 +2286,8 @@ int collect_impl(mmh_ctx *c, int ticket, uint64_t *out, uint64_t cap, uint64_t *
          return rc;
       }
       if (overflow) {
-         *overflow = oc.bucket_overflow;
+         // (more candidates than the lane takes: narrower parts hold fewer, like narrower buckets)
+         *overflow = oc.bucket_overflow || oc.candidates > w.out_cap || oc.candidates > oc.limit;
       }
       rescan = oc.candidates > w.out_cap || oc.candidates > oc.limit || oc.hard_overflow || !oc.sorted_on_device;
       static const bool lane_trace = getenv("MMOORE_LANE_TRACE") != nullptr;     // development: where the lanes' kernels lie in time
@@ -2404,17 +2405,19 @@ struct SplitProgress {
 // One stage of the pipeline: parts of `unit` blocks from pg->done_blocks on (adaptive: see 1. above) until the ROM's end
 // or the first part that does not settle; *overflowed: that part's bucketed store overflowed.  Returns an error only for
 // failures of the device / arguments; a part that does not settle just ends the stage (pg says how far it got).
+// probe: the stage's first part goes alone -- behind a part that flooded the next one may well flood too, and parts in
+// flight behind a part that does not settle are scanned for nothing.
 int split_stage(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian, uint64_t base_offset, uint64_t *out,
-                uint64_t cap, SplitProgress *pg, uint64_t unit, bool adaptive, bool *overflowed)
+                uint64_t cap, SplitProgress *pg, uint64_t unit, bool adaptive, bool *overflowed, bool probe = false, uint64_t stop_block = ~0ull)
 {
    *overflowed = false;
    const uint64_t N = c->rom_bytes, S = plan->elem_bytes;
-   const uint64_t nblocks = (N + block_bytes - 1) / block_bytes;
+   const uint64_t nblocks = std::min<uint64_t>((N + block_bytes - 1) / block_bytes, stop_block);    // (stop_block: the stage ends there)
    const uint64_t overlap = (uint64_t)(plan->L - 1) * S;
    int tickets[mmh_ctx::kLanes];
    uint64_t ends[mmh_ctx::kLanes];                  // the block behind ticket k's part
    int outstanding = 0;
-   uint64_t next_block = pg->done_blocks, step = unit, collected = 0, submitted = 0;
+   uint64_t next_block = pg->done_blocks, step = unit, collected = 0, submitted = 0, good = 0;
    bool failed = false;
    int error = MMH_OK;
    auto collect_oldest = [&]() {
@@ -2450,6 +2453,7 @@ int split_stage(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int
          failed = true;
          return;
       }
+      good++;
       pg->total += n;
       pg->done_blocks = end;
       pg->candidates += c->counters[0];
@@ -2465,7 +2469,7 @@ int split_stage(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int
       }
    };
    while (next_block < nblocks && !failed) {
-      if (outstanding == mmh_ctx::kLanes || (adaptive && collected == 0 && outstanding == 2)) {
+      if (outstanding == mmh_ctx::kLanes || (adaptive && collected == 0 && outstanding == 2) || (probe && good == 0 && outstanding == 1)) {
          collect_oldest();                          // (adaptive: the third part waits for the first one's verdict)
          if (failed) {
             break;
@@ -2505,6 +2509,7 @@ int scan_split(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int 
    *out_count = 0;
    const uint64_t N = c->rom_bytes;
    const uint64_t nblocks = (N + block_bytes - 1) / block_bytes;
+   const uint64_t overlap = (uint64_t)(plan->L - 1) * plan->elem_bytes;
    // an eighth of the ROM, but no less than 256 MiB (a 1 GiB ROM: quarters)
    const uint64_t unit = std::max<uint64_t>(std::max<uint64_t>((nblocks + 7) / 8, (kSplitUnitMin + block_bytes - 1) / block_bytes), 1);
    // ... and half of that for the ROM behind a flood (a sixteenth, at least 64 MiB: a part's buckets are a 4096th of it wide)
@@ -2514,32 +2519,69 @@ int scan_split(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int 
    SplitProgress pg;
    bool overflowed = false;
    int rc = split_stage(c, plan, block_bytes, big_endian, base_offset, out, cap, &pg, unit, true, &overflowed);
-   if (rc == MMH_OK && pg.done_blocks < nblocks && overflowed && fine < unit) {
-      rc = split_stage(c, plan, block_bytes, big_endian, base_offset, out, cap, &pg, fine, false, &overflowed);
-   }
-   uint64_t path = pg.hard ? 2 : 0;
+   uint64_t path = 0;
    std::vector<uint64_t> rest_list;                 // (what scan_impl keeps of a list that only exists on the host: not needed here)
-   if (rc == MMH_OK && pg.done_blocks < nblocks) {
-      // the rest of the ROM in one synchronous scan
+   // [first block, behind the last) in one synchronous scan, its list behind what the parts delivered
+   auto scan_rest = [&](uint64_t b0, uint64_t b1, bool dense) {
       MmPending view;
       view.view = true;
-      view.view_first = pg.done_blocks * block_bytes;
-      view.view_bytes = N - view.view_first;
+      view.view_first = b0 * block_bytes;
+      view.view_bytes = std::min((b1 - b0) * block_bytes + overlap, N - view.view_first);
       const uint64_t room = pg.total <= cap ? cap - pg.total : 0;
       uint64_t nowhere = 0, n = 0;
       bool on_device = false;
-      rc = scan_impl(c, plan, block_bytes, big_endian, base_offset + view.view_first, room ? out + pg.total : &nowhere, room, &n, &rest_list,
-                     &on_device, &view, overflowed);
-      if (rc == MMH_E_CAPACITY) {
-         rc = MMH_OK;                               // (counted below against the caller's whole buffer)
+      int r = scan_impl(c, plan, block_bytes, big_endian, base_offset + view.view_first, room ? out + pg.total : &nowhere, room, &n, &rest_list,
+                        &on_device, &view, dense);
+      if (r == MMH_E_CAPACITY) {
+         r = MMH_OK;                                // (counted below against the caller's whole buffer)
       }
       pg.total += n;
       pg.candidates += c->counters[0];
       pg.tiles += c->counters[2];
-      path = c->counters[3] ? c->counters[3] : path;
+      path = std::max<uint64_t>(path, c->counters[3]);
       pg.parts++;
-      pg.done_blocks = nblocks;
+      pg.done_blocks = b1;
+      return r;
+   };
+   // (stage 1 above; from here on: behind every flood the coarse parts again)
+   int floods = 0;                                  // parts that went to the forward engine on their own
+   while (rc == MMH_OK && pg.done_blocks < nblocks) {
+      if (!overflowed) {
+         // a part needs what the lanes do not run (left-overs beyond the resolvers, ...): the rest of the ROM the usual way
+         rc = scan_rest(pg.done_blocks, nblocks, false);
+         break;
+      }
+      // The coarse part at done_blocks flooded: ITS extent in parts half as wide (narrower buckets), the first one alone.
+      const uint64_t coarse_end = std::min(nblocks, pg.done_blocks + unit);
+      bool other = false;                           // a fine part failed for another reason than a flood
+      while (rc == MMH_OK && pg.done_blocks < coarse_end && !other) {
+         if (fine < unit) {
+            rc = split_stage(c, plan, block_bytes, big_endian, base_offset, out, cap, &pg, fine, false, &overflowed, true, coarse_end);
+            if (rc != MMH_OK || pg.done_blocks >= coarse_end) {
+               break;
+            }
+            if (!overflowed) {
+               other = true;
+               break;
+            }
+         }
+         // The part at done_blocks floods the narrow buckets as well (padding that matches the keyword wholesale: a few MiB
+         // of a ROM): the forward engine on THAT part -- 256 MiB of a 4 GiB ROM, not all of it -- and the candidate path
+         // again behind it.  A ROM that floods everywhere (a two-symbol keyword) stops being asked after two such parts.
+         floods++;
+         rc = scan_rest(pg.done_blocks, floods > 2 ? nblocks : std::min(nblocks, pg.done_blocks + std::min(fine, unit)), true);
+      }
+      if (rc != MMH_OK || pg.done_blocks >= nblocks) {
+         break;
+      }
+      if (other) {
+         overflowed = false;
+         continue;                                  // (-> the rest of the ROM the usual way)
+      }
+      // behind the flooded part: coarse parts again, the adaptive way (the first one alone: it may flood as well)
+      rc = split_stage(c, plan, block_bytes, big_endian, base_offset, out, cap, &pg, unit, true, &overflowed, true);
    }
+   path = path ? path : (pg.hard ? 2 : 0);
    // The parts' timings as ONE entry of the history: [streaming kernels of all parts, summed -- they overlap, so the sum
    // exceeds their share of the wall time --, the scan's wall time on the host].
    if (c->scans_recorded > first_recorded && c->scans_recorded - first_recorded <= mmh_ctx::kRing) {
