@@ -564,12 +564,18 @@ def main():
     live_traffic = (None, None, {})
     if (world == 1 and args.gib_per_gpu is None and not args.force_gather and not args.no_pmc
             and (args.config != "C2" or (not args.no_cpu_baseline and not args.no_other_configs))):
-        # (host only: the kernel the timed configuration's keyword selects)
-        from __graft_entry__ import load_package as _load
-        _mm = _load()
+        # the kernel the timed configuration's keyword selects (host only -- and asked of a child: this process loads
+        # nothing of HIP before the counting children have come and gone)
+        import subprocess
         _cfg = CONFIGS[args.config]
-        _shape = _mm.filter_shape(_mm.plan_relative(_cfg["elem"], _cfg["keyword"], _cfg["wildcard"] or 0))["shape"]
-        live_traffic = measure_pmc_traffic("mm_filter_u%d<%d>" % (8 * _cfg["elem"], _shape), args.config)
+        _probe = subprocess.run([sys.executable, "-c",
+                                 "import sys; sys.path.insert(0, %r)\nfrom __graft_entry__ import load_package\nmm = load_package()\n"
+                                 "print(mm.filter_shape(mm.plan_relative(%d, %r, %d))['shape'])" % (ROOT, _cfg["elem"], _cfg["keyword"], _cfg["wildcard"] or 0)],
+                                capture_output=True, text=True, timeout=300)
+        if _probe.returncode == 0 and _probe.stdout.strip().isdigit():
+            live_traffic = measure_pmc_traffic("mm_filter_u%d<%s>" % (8 * _cfg["elem"], _probe.stdout.strip()), args.config)
+        else:
+            live_traffic = (None, "the filter shape of %s could not be asked of the library: %s" % (args.config, (_probe.stderr or "").strip()[-200:]), {})
 
     # (the pool's host driver only supports dmabuf IPC: RCCL across processes needs this; exported on the boxes already)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

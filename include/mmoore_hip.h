@@ -23,6 +23,18 @@
  * never throw; mmh_last_error() describes the last failure on the calling
  * thread.  There is NO CPU fallback: without a usable HIP device every device
  * entry point fails with MMH_E_DEVICE.
+ *
+ * Environment (everything the library and the facade read; nothing else changes their behaviour):
+ *   MMOORE_HIP_DEVICE        facade: the first device it uses (default 0)
+ *   MMOORE_HIP_DEVICES       facade: at most this many devices for one SearchEngine<T>::run (default: all visible)
+ *   MMOORE_HIP_DEVICE_LIST   facade: the devices themselves, comma separated (tests name one GPU twice)
+ *   MMOORE_HIP_MULTI         facade: 1 = take the multi-device path whatever the file's size
+ *   MMOORE_GATHER_TIMEOUT_S  how long mmh_gather_finish waits for a peer rank before it fails (default 120)
+ *   MMOORE_SELFTEST          0 = skip the first-use known-answer test of mmh_create ("route health" below)
+ *   MMOORE_TRACE             diagnostics on stderr: sync, split, lanes, fused, floods, ingest, selftest -- a comma-separated
+ *                            list, or 1 for all of them
+ *   MMOORE_MAX_CANDIDATES    (tests) where the per-candidate path hands a scan to the flood paths (default 1048576)
+ *   MMOORE_TAIL_SUB, MMOORE_TAIL_QUAD_MAXL   (tests) force the tail kernel's candidates-per-wave variant
  */
 #ifndef MMOORE_HIP_H
 #define MMOORE_HIP_H
@@ -36,7 +48,7 @@ extern "C" {
 /* Longest keyword a plan holds.  The reference has no explicit limit, but its wildcard-path tables
  * store keyword_len - 1 in a char (src/core/monkey_moore.cpp:250-253, :270-272): from 129 symbols
  * on that wraps negative and its skip arithmetic changes meaning, so 128 is where parity ends.
- * Keywords of up to 32 symbols take the streaming filter + per-candidate resolvers; longer ones
+ * Keywords of up to 64 symbols take the streaming filter + per-candidate resolvers; longer ones
  * always run on the forward engine (csrc/mm_forward.h), whose phase maps are sized for 127 phases. */
 #define MMH_MAX_KEYWORD 128
 
@@ -268,7 +280,7 @@ int mmh_last_counters(mmh_ctx *ctx, uint64_t *c4);
  *     no slot still holding the poison the host left there, offsets strictly ascending and inside the ROM); a
  *     violation reruns the scan through the plain kernels and is remembered (sticky) -- never a wrong list in silence;
  *   * mmh_set_route switches routes off at run time, so that a caller (tests/test_gpu_fuzz.py on a mismatch,
- *     tools/soak_fuzz.sh) can scan the same ROM every way in one process and see which routes disagree.
+ *     a soak run) can scan the same ROM every way in one process and see which routes disagree.
  * MonkeyMoore<Ty>::search at the reference benchmark's sizes (benchmarks/bench_search.cpp:67-105 -> src/core/
  * monkey_moore.cpp:41-49) takes exactly these routes. */
 enum {

@@ -10,6 +10,8 @@
 #include <atomic>
 #include <memory>
 #include <thread>
+#include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "mmoore_hip.h"
@@ -221,6 +223,20 @@ struct mmh_ctx {
    MmIngest ingest;
    MmComm mg;
 };
+
+// MMOORE_TRACE: diagnostics on stderr, by topic -- a comma-separated list of sync, split, lanes, fused, floods, ingest,
+// selftest, or 1 / all for every one of them.  (One switch: rounds 2-5 had one variable per topic.)
+inline bool mm_trace(const char *topic)
+{
+   static const std::string want = [] { const char *e = getenv("MMOORE_TRACE"); return std::string(e ? e : ""); }();
+   if (want.empty() || want == "0") {
+      return false;
+   }
+   if (want == "1" || want == "all") {
+      return true;
+   }
+   return ("," + want + ",").find(std::string(",") + topic + ",") != std::string::npos;
+}
 
 // defined in mm_capi.hip
 int mmh_workspace(mmh_ctx *c);

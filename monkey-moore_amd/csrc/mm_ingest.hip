@@ -319,7 +319,7 @@ extern "C" int mmh_rom_load_file_watched(mmh_ctx *c, const char *path, uint64_t 
    in.last_bytes = nbytes;
    in.last_threads = threads;
    if (aborted) {
-      static const bool trace = getenv("MMOORE_INGEST_TRACE") != nullptr;
+      static const bool trace = mm_trace("ingest");
       if (trace) {
          fprintf(stderr, "mmh_rom_load_file: aborted after %.2f ms, %d of %d readers still busy\n", in.last_seconds * 1e3,
                  job->running.load(), threads);

@@ -10,14 +10,14 @@
 namespace mm {
 
 struct Tuning {
-   int filter_max_conditions;        // MMOORE_FILTER_MAXCOND   (4)
-   uint64_t filter_blocks;           // MMOORE_FILTER_BLOCKS    (1536 workgroups: 6 of the 8 workgroup slots of a CU)
-   uint32_t filter_groups_per_span;  // MMOORE_FILTER_GPS       (7 groups of 4 KiB)
-   unsigned resolve_blocks;          // MMOORE_RESOLVE_BLOCKS   (4096 workgroups)
-   unsigned tail_blocks;             // MMOORE_TAIL_BLOCKS      (2048 workgroups of mm_scan_tail; mm_scan_tail2: 1280 - 2048 by variant unless set)
-   unsigned lane_tail_blocks;        // MMOORE_LANE_TAIL_BLOCKS (workgroups of mm_scan_tail2 behind a scan of the submit lanes)
-   uint32_t max_candidates;          // MMOORE_MAX_CANDIDATES   (1048576 per scan: the bucketed store, csrc/mm_tail2.h)
-   uint32_t list_candidates;         // MMOORE_LIST_CANDIDATES  (262144 per scan: the list-based kernels)
+   int filter_max_conditions;        // 4 SWAR conditions at most
+   uint64_t filter_blocks;           // 1536 workgroups: 6 of the 8 workgroup slots of a CU
+   uint32_t filter_groups_per_span;  // 7 groups of 4 KiB
+   unsigned resolve_blocks;          // 4096 workgroups
+   unsigned tail_blocks;             // 2048 workgroups of mm_scan_tail (mm_scan_tail2: the device's CUs x the variant's waves per SIMD)
+   unsigned lane_tail_blocks;        // 1024 workgroups of mm_scan_tail2 behind a scan of the submit lanes
+   uint32_t max_candidates;          // 1048576 per scan: the bucketed store, csrc/mm_tail2.h (MMOORE_MAX_CANDIDATES, tests)
+   uint32_t list_candidates;         // 262144 per scan: the list-based kernels
 };
 const Tuning &tuning();
 
@@ -144,7 +144,6 @@ void launch_rank_sort(hipStream_t st, const uint64_t *in, unsigned long long *ct
 size_t sort_temp_bytes(uint64_t n);
 hipError_t sort_keys(hipStream_t st, const uint64_t *in, uint64_t *out, uint64_t n, void *temp, size_t temp_bytes);
 // holds the stream back for `ms` milliseconds (one sleeping wave)
-void launch_gate(hipStream_t st, double ms);
 void launch_synth(hipStream_t st, uint8_t *rom, uint64_t nbytes, uint64_t seed, uint64_t base_offset);
 void launch_gather(hipStream_t st, const uint8_t *rom, uint64_t nbytes, const uint64_t *offsets, uint64_t n, uint32_t each,
                    uint8_t *out);

@@ -312,44 +312,30 @@ __global__ __launch_bounds__(256) void mm_publish_list(const uint64_t *src, uint
    }
 }
 
-__global__ __launch_bounds__(64) void mm_gate(unsigned long long ticks)
-{
-   const unsigned long long t0 = wall_clock64();
-   while (wall_clock64() - t0 < ticks) {
-      __builtin_amdgcn_s_sleep(64);
-   }
-}
-
 // --------------------------------------------------------------------------
 // launch wrappers (called from mm_capi.hip)
 // --------------------------------------------------------------------------
 
 namespace mm {
 
-// Experiment knobs, read once per process.  They exist for the tuning probes under tools/
-// (launch geometry sweeps, condition-count sweeps); production runs leave them unset.
+// Launch geometry and limits (the measured choices; DESIGN.md section 4 has the sweeps behind them).  One of them can be
+// set from outside, for tests: MMOORE_MAX_CANDIDATES, where the per-candidate path hands a scan over to the flood paths.
 const Tuning &tuning()
 {
    static const Tuning t = [] {
-      auto number = [](const char *name, long fallback) {
-         const char *v = getenv(name);
-         return v && *v ? std::max(1L, atol(v)) : fallback;
-      };
       Tuning k;
-      k.filter_max_conditions = (int)number("MMOORE_FILTER_MAXCOND", 4);
-      k.filter_blocks = (uint64_t)number("MMOORE_FILTER_BLOCKS", 256 * 6);
-      k.filter_groups_per_span = (uint32_t)std::min<long>(number("MMOORE_FILTER_GPS", 7), 8);   // (a span's flagged pieces are 32 bits)
-      k.resolve_blocks = (unsigned)number("MMOORE_RESOLVE_BLOCKS", 4096);
+      k.filter_max_conditions = 4;
+      k.filter_blocks = 256 * 6;
+      k.filter_groups_per_span = 7;               // (at most 8: a span's flagged pieces are 32 bits)
+      k.resolve_blocks = 4096;
       // (mm_arrive_last counts arrivals in MM_ARRIVE_LINES - 1 groups of MM_ARRIVE_FAN: more workgroups would spill into the next lines)
-      k.tail_blocks = (unsigned)std::min<long>(number("MMOORE_TAIL_BLOCKS", 2048), (long)MM_ARRIVE_FAN * (MM_ARRIVE_LINES - 1));
-      // (scans in flight: a small tail grid beside the next scan's streaming kernel -- 512 workgroups: 0.687-0.689 ms per 4 GiB
-      // scan in the steady state against 0.695-0.696 with 2048, profiles/r03_lane_gate_and_span_tickets.log)
-      // (round 4, grouped candidates: between 512 and 1536 workgroups the sparse steady state is the same 0.689-0.691 ms, and
-      // dense searches in flight like 1024 best -- `water` 0.775 -> 0.757 ms, `th*s` 0.934 -> 0.91; 2048 costs the split
-      // pipeline's synchronous caller 0.09 ms: profiles/r04_lane_tail_blocks_sweep.log, r04_candidate_density_lane_tail.log)
-      k.lane_tail_blocks = (unsigned)std::min<long>(number("MMOORE_LANE_TAIL_BLOCKS", 1024), (long)MM_ARRIVE_FAN * (MM_ARRIVE_LINES - 1));
-      k.max_candidates = (uint32_t)number("MMOORE_MAX_CANDIDATES", 1048576);
-      k.list_candidates = (uint32_t)number("MMOORE_LIST_CANDIDATES", 262144);
+      k.tail_blocks = (unsigned)std::min<long>(2048, (long)MM_ARRIVE_FAN * (MM_ARRIVE_LINES - 1));
+      // (scans in flight: a small tail grid beside the next scan's streaming kernel -- between 512 and 1536 workgroups the
+      // sparse steady state is the same, dense searches in flight like 1024 best, r03 / r04 sweeps)
+      k.lane_tail_blocks = (unsigned)std::min<long>(1024, (long)MM_ARRIVE_FAN * (MM_ARRIVE_LINES - 1));
+      const char *v = getenv("MMOORE_MAX_CANDIDATES");
+      k.max_candidates = (uint32_t)(v && *v ? std::max(1L, atol(v)) : 1048576L);
+      k.list_candidates = 262144;
       return k;
    }();
    return t;
@@ -430,7 +416,7 @@ bool choose_filter(const mmh_plan_desc &pl, FilterChoice *fc)
    // above leave the streaming loop or the resolver short -- fewer than 3 (8-bit) / 2 (16-bit) conditions -- and a wide choice
    // has more.  Condition 1 of a wide choice is the literal next to the anchor's left (the kernels are compiled for the two
    // gaps only); ties go to equal gaps (one stream of deltas on the hot path), then to short ones, then to the rightmost anchor.
-   if ((int)best.ncond < std::min(u8 ? 3 : 2, want) && !(getenv("MMOORE_FILTER_WIDE") && *getenv("MMOORE_FILTER_WIDE") == '0')) {
+   if ((int)best.ncond < std::min(u8 ? 3 : 2, want)) {
       auto wide_gap = [&](int i) -> int {
          if (i < 1 || pl.cmp_mask[i] == 0) {
             return 0;
@@ -733,26 +719,11 @@ static void fill_tail_args(MmFusedArgs &a, const ResolveBuffers &rb, uint64_t ba
    a.ctrl_words = (uint32_t)(ctrl_bytes() / sizeof(unsigned long long));
    a.seq = seq;
    a.timeout_ticks = 20000000;                    // 200 ms of the 100 MHz wall clock
-   {
-      // (tests: MMOORE_FUSED_TIMEOUT_TICKS=1 makes every grid barrier give up -- the route behind it, finish_pipeline's
-      // hand-over to the plain kernels, is otherwise only taken when something keeps workgroups out for 200 ms)
-      static const long forced = [] { const char *e = getenv("MMOORE_FUSED_TIMEOUT_TICKS"); return e && *e ? atol(e) : 0L; }();
-      if (forced > 0) {
-         a.timeout_ticks = (uint64_t)forced;
-      }
-   }
 }
 
 // ROMs up to this size take the single-launch kernel (tools/fused_probe.py: 128 KiB .. 2 MiB 11 us
 // on the device against 20; 16 MiB with candidates 32 against 27; 4 GiB 782 against 738)
-static uint64_t fused_max_bytes()
-{
-   static const uint64_t v = [] {
-      const char *e = getenv("MMOORE_FUSED_MAX_MIB");
-      return (uint64_t)(e && *e ? atol(e) : 4) << 20;
-   }();
-   return v;
-}
+static uint64_t fused_max_bytes() { return 4ull << 20; }
 
 bool fused_applies(const MmGeom &g) { return g.nbytes <= fused_max_bytes() && fused_resident_blocks() != 0; }
 
@@ -843,32 +814,26 @@ void launch_tail2(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, cons
    a.nbuckets = bucket_geom(g.nbytes).nb;
    // (never beyond what the host re-poisons between scans, note_dirty_slots in mm_capi.hip: a direct slot above that
    // could pass for an offset after a late PCIe write)
-   static const uint32_t direct_limit = [] {
-      const char *e = getenv("MMOORE_DIRECT_PUBLISH");
-      return std::min<uint32_t>((uint32_t)(e && *e ? atol(e) : MM_DIRECT_PUBLISH), MM_MAX_RANK_SORT);
-   }();
-   a.direct_limit = direct_limit;
+   a.direct_limit = std::min<uint32_t>(MM_DIRECT_PUBLISH, MM_MAX_RANK_SORT);
    a.has_edge = 0;
    // Several candidates per wave (mm_resolve_sub): two for keywords of up to 16 symbols, four up to 13, eight up to 4
    // (profiles/r04_candidate_density.log; 64 / 48 more registers than one per wave: 6 / 5 waves per SIMD instead of 8,
    // which costs nothing -- with 7 the compiler spills and every row of the log was slower).
-   // MMOORE_TAIL_SUB=1: one, as before (2, 4: at most that many); MMOORE_TAIL_QUAD_MAXL: the longest keyword that gets four
+   // Test hooks (tests/test_gpu_tail_groups.py runs every width on every keyword length): MMOORE_TAIL_SUB=1: one per wave
+   // (2, 4: at most that many); MMOORE_TAIL_QUAD_MAXL: the longest keyword that gets four.
    static const int sub = [] { const char *e = getenv("MMOORE_TAIL_SUB"); return e && *e ? atoi(e) : 8; }();
    static const int quad_maxl = [] { const char *e = getenv("MMOORE_TAIL_QUAD_MAXL"); const int v = e && *e ? atoi(e) : 13; return v > 13 ? 13 : v; }();
    // The grid of a scan with the device to itself: as many workgroups as are resident at once at the variant's waves per
    // SIMD (the device's CUs x occupancy; 256 CUs on the MI355X) -- with 2048 for all of them a quarter of the 6-per-SIMD variants' waves started when the
    // first ones ended and a dense search's tail took half as long again (`water`, 90 K candidates in one launch: 96 -> 61 us;
    // `and` 126 -> 73 with 1280 for the 5-per-SIMD variant; profiles/r04_candidate_density_tail_grid.log).
-   // MMOORE_TAIL_BLOCKS overrides.
    const int occ = (sub >= 8 && pl.L <= 4) ? 5 : (sub >= 2 && pl.L <= 16) ? 6 : 8;
-   static const bool grid_set = [] { const char *e = getenv("MMOORE_TAIL_BLOCKS"); return e && *e; }();
-   const dim3 grid(tail_blocks ? tail_blocks : grid_set ? tuning().tail_blocks : device_cus() * (unsigned)occ), block(64 * MM_WAVES);
-   static const long group_min = [] { const char *e = getenv("MMOORE_TAIL_GROUP_MIN"); return e && *e ? atol(e) : -1L; }();
+   const dim3 grid(tail_blocks ? tail_blocks : device_cus() * (unsigned)occ), block(64 * MM_WAVES);
    // (grouped from an eighth of the grid's waves on: at the bench's 4223 candidates the tail takes 24 us instead of 29 and a
    // synchronous scan 0.768 ms instead of 0.79 -- fewer walks to the buckets; any threshold between 0 and 4096 measures
    // the same, profiles/r04_tail_blocks_sweep.log.  Below that a wave's candidates would only wait for each other where
    // they fall back to the one-per-wave resolver)
-   a.group_min = group_min >= 0 ? (uint32_t)group_min : grid.x * MM_WAVES / 8;
+   a.group_min = grid.x * MM_WAVES / 8;
    if (sub >= 8 && pl.L <= 4) {
       launch_timed(mm_scan_tail2<5, 8>, grid, block, st, nullptr, stop, a);    // (96 registers: with 80 it spills, and is slower)
    }
@@ -991,8 +956,7 @@ static void launch_forward(hipStream_t st, const MmGeom &g, const mmh_plan_desc 
    while (i1 >= 0 && pl.cmp_mask[i1] == 0) {
       i1--;
    }
-   if (pl.elem_bytes == 1 && i1 >= 1 && pl.bridge[i1] <= -1 && pl.bridge[i1] >= -4 && i1 + pl.bridge[i1] >= 0 &&
-       !(getenv("MMOORE_FORWARD_SLOW") && *getenv("MMOORE_FORWARD_SLOW") == '1')) {
+   if (pl.elem_bytes == 1 && i1 >= 1 && pl.bridge[i1] <= -1 && pl.bridge[i1] >= -4 && i1 + pl.bridge[i1] >= 0) {
       a.fast = 1; a.i1 = (uint32_t)i1; a.g1 = (uint32_t)(-pl.bridge[i1]);
       int i2 = i1 - 1;
       while (i2 >= 0 && pl.cmp_mask[i2] == 0) {
@@ -1008,7 +972,7 @@ static void launch_forward(hipStream_t st, const MmGeom &g, const mmh_plan_desc 
    a.loud = nullptr;
    a.loud_shape = 0; a.loud_iA = 0; a.loud_pat[0] = a.loud_pat[1] = 0; a.loud_sh1 = 0;
    FilterChoice fc;
-   const bool sweeps = choose_filter(pl, &fc) && !(getenv("MMOORE_FORWARD_SWEEP") && *getenv("MMOORE_FORWARD_SWEEP") == '0');
+   const bool sweeps = choose_filter(pl, &fc);
    if (sweeps && a.fast && !(fc.shape & 0x200u)) {          // (its batch sweep knows the one-dword shapes only)
       const uint32_t nc = fc.ncond < 2 ? fc.ncond : 2;
       uint32_t mask2 = fc.gap[0] == 2 ? 1u : 0u;
@@ -1035,7 +999,7 @@ static void launch_forward(hipStream_t st, const MmGeom &g, const mmh_plan_desc 
    a.quiet16 = 0;
    a.q16_bloom[0] = a.q16_bloom[1] = a.q16_bloom[2] = 0;
    if (pl.elem_bytes == 2 && !a.fast && !capped && i1 >= 1 && pl.bridge[i1] == -1 && pl.cmp_mask[i1] == 0xFFFFFFFFu &&
-       pl.default_skip == (int32_t)pl.L - 1 && !(getenv("MMOORE_FORWARD_QUIET16") && *getenv("MMOORE_FORWARD_QUIET16") == '0')) {
+       pl.default_skip == (int32_t)pl.L - 1) {
       a.quiet16 = 1;
       a.i1 = (uint32_t)i1;
       auto add = [&](int32_t d) {
@@ -1053,9 +1017,8 @@ static void launch_forward(hipStream_t st, const MmGeom &g, const mmh_plan_desc 
       // A workgroup's block of batches (mm_forward.h): four -- one per wave, as round 2 handed them out.  Bigger blocks are
       // slower, and badly so (1 GiB, wildcard keyword: 4 / 8 / 16 / 32 batches -> 0.31 / 0.67 / 0.94 / 1.19 ms): the
       // workgroups then work 4 x 32 KiB at a time out of regions 8 x ... 32 x 32 KiB apart, and at any moment the reads of
-      // the whole grid land on a fraction of the memory channels.  (MMOORE_FWD_CHUNK: that experiment.)
-      const char *e = getenv("MMOORE_FWD_CHUNK");
-      a.chunk = e && atoi(e) >= 4 ? (uint32_t)atoi(e) : 4u;
+      // the whole grid land on a fraction of the memory channels.
+      a.chunk = 4u;
    }
    (void)hipMemsetAsync(db.maps, 0, dg.status_bytes + (prepass ? dg.loud_bytes : 0), st);
    if (prepass) {
@@ -1126,11 +1089,6 @@ void launch_publish_list(hipStream_t st, const uint64_t *src, uint64_t *dst, uin
 {
    const unsigned blocks = std::max(1u, std::min(256u, (n + 1023u) / 1024u));
    hipLaunchKernelGGL(mm_publish_list, dim3(blocks), dim3(256), 0, st, src, dst, n, arrive, flag, seq);
-}
-
-void launch_gate(hipStream_t st, double ms)
-{
-   hipLaunchKernelGGL(mm_gate, dim3(1), dim3(64), 0, st, (unsigned long long)(ms * 1e5));
 }
 
 void launch_synth(hipStream_t st, uint8_t *rom, uint64_t nbytes, uint64_t seed, uint64_t base_offset)

@@ -23,7 +23,7 @@ BOX="$(hostname 2>/dev/null)-$(cat /proc/sys/kernel/random/boot_id 2>/dev/null |
 for p in $(seq 1 "$PROCS"); do
    LOG="$OUT/${TAG}_p${p}.log"
    T0=$(date +%s)
-   MM_FUZZ_SEEDS=$SEEDS MM_FUZZ_MEDIUM=$MEDIUM MM_FUZZ_LONG=$LONG MMOORE_SELFTEST_TRACE=1 \
+   MM_FUZZ_SEEDS=$SEEDS MM_FUZZ_MEDIUM=$MEDIUM MM_FUZZ_LONG=$LONG MMOORE_TRACE=selftest \
       timeout 3000 python3 -m pytest tests/test_gpu_tail_groups.py tests/test_gpu_fuzz.py -m gpu -x --tb=short -q -p no:cacheprovider -s \
       -k "grouped_candidates or against_oracle or medium_roms or long_keywords or left_the_routes" >"$LOG" 2>&1
    RC=$?

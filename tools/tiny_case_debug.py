@@ -25,4 +25,4 @@ for i, c in enumerate(engine):
         if bad <= 12:
             print(i, "L", len(c["keyword"]), "kw", "".join(chr(x) for x in c["keyword"]), "block", c["block_size"], "elem", c["elem_bytes"], "be", c["big_endian"],
                   "n", len(c["file"]), "expect", c["expect"][:8], {k: (v[:8] if isinstance(v, list) else v) for k, v in res.items()}, mm.filter_shape(plan), flush=True)
-print("engine cases with a mismatch:", bad, "of", len(engine), "fused", os.environ.get("MMOORE_FUSED", "1"))
+print("engine cases with a mismatch:", bad, "of", len(engine))
