@@ -284,6 +284,9 @@ def measure_pmc_traffic(kernel, config="C2"):
                     rows += [row for row in csv.DictReader(fh) if row["Kernel_Name"].startswith("void " + kernel + "(")]
             for counter in counters:
                 vals = [float(row["Counter_Value"]) for row in rows if row.get("Counter_Name") == counter]
+                # (the library's device warm-up at mmh_create launches the same kernel on an 8 MiB ROM: only the launches
+                # over the bench ROM count -- everything within half of the largest)
+                vals = [v for v in vals if v >= 0.5 * max(vals)] if vals else vals
                 if r.returncode != 0 or not vals:
                     if counter.startswith("SQ_"):
                         continue                              # (the instruction mix is an extra: the traffic figure stands without it)
