@@ -89,6 +89,9 @@ def counter_avgs(dirname, counter):
                 continue
             name = row["Kernel_Name"].split("(")[0]
             per.setdefault(name, []).append(float(row["Counter_Value"]))
+    # (round 6: the library's device warm-up at mmh_create launches the streaming kernels on an 8 MiB ROM -- only the
+    # launches over the bench ROM count: everything within half of the kernel's largest value)
+    per = {k: [x for x in v if x >= 0.5 * max(v)] for k, v in per.items()}
     return {k: (sum(v) / len(v), len(v)) for k, v in per.items()}
 
 
