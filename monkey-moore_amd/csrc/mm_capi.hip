@@ -600,7 +600,7 @@ int scan_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int b
    // pattern, candidate sets too dense, prefixes too long) go to the forward "dense" engine,
    // whose cost is linear in the ROM.  1 / 2 force the sequential / dense engine (tests).
    // (keywords beyond 32 symbols: the resolvers' phase sets do not hold their D > 31 phases)
-   const bool narrow = plan->L <= MM_RESOLVER_MAX_KEYWORD;
+   const bool narrow = plan->L <= MM_CANDIDATE_MAX_KEYWORD;
    enum { FAST, SEQUENTIAL, DENSE } mode = c->engine == 1 ? SEQUENTIAL : (c->engine == 2 || !have_filter || !narrow) ? DENSE : FAST;
    // (No memo of earlier scans: until round 5 a search that had ended on the forward engine went there at once the next
    // time, and every first scan of such a search cost 1.2 to 6 times a later one.  What a scan learns it learns from its

@@ -120,7 +120,7 @@ int submit_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int
    const MmGeom g = scan_geometry(c, plan, block_bytes, big_endian, &p);
    mm::FilterChoice fc;
    const bool have_filter = mm::choose_filter(*plan, &fc);
-   if (c->engine != 0 || !have_filter || g.nbytes == 0 || plan->L > MM_RESOLVER_MAX_KEYWORD) {
+   if (c->engine != 0 || !have_filter || g.nbytes == 0 || plan->L > MM_CANDIDATE_MAX_KEYWORD) {
       p.needs_rescan = true;                    // collect runs mmh_scan
    }
    else {

@@ -70,7 +70,9 @@ int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev,
    // (the event at a scan's start costs its first dispatch ~4.5 us: only for callers that ask for timings, mmh_set_timing)
    hipEvent_t const ev_start = c->timing ? ev[0] : nullptr;
    const bool polled = allow_polled && !sequential && !skip_bits && !(off & MMH_ROUTE_NO_POLLED);
-   const bool single_launch = polled && allow_single_launch && c->fused_ok && !(off & MMH_ROUTE_NO_SINGLE_LAUNCH) && mm::fused_applies(g);
+   // (keywords beyond 64 symbols: the single-launch kernel is not instantiated for their two-phases-per-lane resolver)
+   const bool single_launch = polled && allow_single_launch && c->fused_ok && !(off & MMH_ROUTE_NO_SINGLE_LAUNCH) && mm::fused_applies(g) &&
+                              pl.L <= MM_RESOLVER_MAX_KEYWORD;
    const bool bucketed = polled && !single_launch && !(off & MMH_ROUTE_NO_BUCKETS);
    // Only the bucketed store takes the full limit: the list-based kernels keep round 2's (their lists share d_cand, and the
    // callers read "more candidates than this" as "a flood: take it apart domain by domain").
@@ -413,7 +415,12 @@ int finish_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev, 
       return MMH_OK;
    }
    w.ctrl_clean = false;                        // kept for the second phase
-   if (leftovers > mm::mid_cap() || oc->candidates > w.out_cap || oc->candidates > max_candidates) {
+   // (keywords beyond 64 symbols: the first resolver counts what it cannot settle but hands nothing on -- the second
+   // phase's stored maps are 64 bytes --: any left-over is "more than the second phase takes", csrc/mm_tiles.h)
+   if (pl.L > MM_RESOLVER_MAX_KEYWORD) {
+      oc->hard_overflow = true;
+   }
+   if (oc->hard_overflow || leftovers > mm::mid_cap() || oc->candidates > w.out_cap || oc->candidates > max_candidates) {
       return MMH_OK;                            // the caller switches engines (hard_overflow / too many candidates)
    }
    const mm::ResolveBuffers rb = resolve_buffers(w);

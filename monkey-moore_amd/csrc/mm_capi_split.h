@@ -33,7 +33,7 @@ bool split_applies(const mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_b
 {
    (void)big_endian;
    if ((routes_off(c) & MMH_ROUTE_NO_SPLIT) || c->engine != 0 || block_bytes == 0 || !c->rom || c->rom == c->rom_host ||
-       c->rom_bytes < kSplitMinBytes || (block_bytes & 15) != 0 || block_bytes > kSplitUnitMin || plan->L > MM_RESOLVER_MAX_KEYWORD) {
+       c->rom_bytes < kSplitMinBytes || (block_bytes & 15) != 0 || block_bytes > kSplitUnitMin || plan->L > MM_CANDIDATE_MAX_KEYWORD) {
       return false;
    }
    for (const MmPending &q : c->pending) {

@@ -198,7 +198,7 @@ __device__ __forceinline__ void mm_tail_keys(const MmFusedArgs &a, unsigned long
    }
 }
 
-template <bool SAME_LAUNCH>
+template <bool SAME_LAUNCH, bool LONG = false>
 __device__ __forceinline__ void mm_scan_tail_phase(const MmFusedArgs &a, const MmPlanLds &P, MmWaveLdsShort *Wv, MmResolveLds &R,
                                                    MmTailLds &T, bool together)
 {
@@ -262,7 +262,7 @@ __device__ __forceinline__ void mm_scan_tail_phase(const MmFusedArgs &a, const M
          int verdict = 0;
          int64_t hi = 0; mm_set_t set = 0; uint64_t dom = 0;
          if (live) {
-            verdict = mm_resolve_candidate(a, P, Wv[wave], o, lane, &walked, &hi, &set, &dom);
+            verdict = mm_resolve_any<LONG>(a, P, Wv[wave], o, lane, &walked, &hi, &set, &dom);
          }
          // Ranking: offsets are unique, so a candidate's place in the ascending list is the number of
          // candidates with a smaller offset.  The workgroup's 256 threads share out the candidate set
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(64 * MM_WAVES, 4) void mm_scan_fused(MmFusedArgs a)
 // its own, leaner launch and all the wave slots; this one replaces mm_resolve, mm_rank_count and
 // mm_rank_scatter -- one dependent launch instead of three).
 // OCC waves per SIMD: 5 (<= 96 VGPRs) keeps the 1056 workgroups the bench ROM's candidates need resident at once
-template <int OCC>
+template <int OCC, bool LONG = false>
 __global__ __launch_bounds__(64 * MM_WAVES, OCC) void mm_scan_tail(MmFusedArgs a)
 {
    __shared__ MmPlanLds P;
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(64 * MM_WAVES, OCC) void mm_scan_tail(MmFusedArgs a
    __shared__ MmResolveLds R;
    __shared__ MmTailLds T;
    mm_plan_to_lds(P, a.t.plan);
-   mm_scan_tail_phase<false>(a, P, Wv, R, T, true);
+   mm_scan_tail_phase<false, LONG>(a, P, Wv, R, T, true);
 }
 
 #endif

@@ -36,10 +36,15 @@ struct MmGeom {
    uint32_t whole;         // 1 = whole-buffer mode (results are element indices)
 };
 
-// keywords longer than this never take the streaming filter + per-candidate resolvers (their phase
-// sets are one 64-bit word -- one bit per lane of a wave --, their stored phase maps 64 bytes): they run on the forward
-// engine.  (32 until round 5: 32-bit sets, although a map always had a lane per phase.)
+// The per-candidate machinery holds a phase set in one 64-bit word -- one bit per lane of a wave -- and stores phase maps
+// of 64 bytes: keywords of up to this many symbols (D <= 63).  (32 until round 5.)  Longer keywords take the streaming
+// filter and the first resolver too since round 6 (two phases per lane, csrc/mm_tiles.h mm_resolve_candidate_long), but
+// neither the single-launch kernel nor the second-phase resolvers: what the look-back windows leave open goes to the
+// forward engine.
 constexpr uint32_t MM_RESOLVER_MAX_KEYWORD = 64;
+// ... and the longest keyword of the candidate path as a whole
+constexpr uint32_t MM_CANDIDATE_MAX_KEYWORD = 128;
+static_assert(MM_CANDIDATE_MAX_KEYWORD == MMH_MAX_KEYWORD, "every keyword a plan holds has a candidate path");
 
 // layout of the block a scan publishes (pinned host memory and its device-side copies):
 // MM_RESULT_HEADER_WORDS counters, then the ordered matches.  Header words: [0] candidates (= result

@@ -763,6 +763,10 @@ void launch_tail(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, const
    a.has_edge = 0;
    // one wave per candidate for up to 8 K of them in one round (the count is only known on the device)
    // (5 waves per SIMD measured best: 6 and 8 spill and run 4-15 us longer; 1280 .. 4096 workgroups: no difference)
+   if (pl.L > MM_RESOLVER_MAX_KEYWORD) {
+      launch_timed(mm_scan_tail<5, true>, dim3(tuning().tail_blocks), dim3(64 * MM_WAVES), st, nullptr, stop, a);
+      return;
+   }
    launch_timed(mm_scan_tail<5>, dim3(tuning().tail_blocks), dim3(64 * MM_WAVES), st, nullptr, stop, a);
 }
 
@@ -827,14 +831,17 @@ void launch_tail2(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, cons
    // SIMD (the device's CUs x occupancy; 256 CUs on the MI355X) -- with 2048 for all of them a quarter of the 6-per-SIMD variants' waves started when the
    // first ones ended and a dense search's tail took half as long again (`water`, 90 K candidates in one launch: 96 -> 61 us;
    // `and` 126 -> 73 with 1280 for the 5-per-SIMD variant; profiles/r04_candidate_density_tail_grid.log).
-   const int occ = (sub >= 8 && pl.L <= 4) ? 5 : (sub >= 2 && pl.L <= 16) ? 6 : 8;
+   const int occ = (sub >= 8 && pl.L <= 4) ? 5 : ((sub >= 2 && pl.L <= 16) || pl.L > MM_RESOLVER_MAX_KEYWORD) ? 6 : 8;
    const dim3 grid(tail_blocks ? tail_blocks : device_cus() * (unsigned)occ), block(64 * MM_WAVES);
    // (grouped from an eighth of the grid's waves on: at the bench's 4223 candidates the tail takes 24 us instead of 29 and a
    // synchronous scan 0.768 ms instead of 0.79 -- fewer walks to the buckets; any threshold between 0 and 4096 measures
    // the same, profiles/r04_tail_blocks_sweep.log.  Below that a wave's candidates would only wait for each other where
    // they fall back to the one-per-wave resolver)
    a.group_min = grid.x * MM_WAVES / 8;
-   if (sub >= 8 && pl.L <= 4) {
+   if (pl.L > MM_RESOLVER_MAX_KEYWORD) {
+      launch_timed(mm_scan_tail2<6, 64, true>, grid, block, st, nullptr, stop, a);   // (keywords of 65 .. 128 symbols: two phases per lane)
+   }
+   else if (sub >= 8 && pl.L <= 4) {
       launch_timed(mm_scan_tail2<5, 8>, grid, block, st, nullptr, stop, a);    // (96 registers: with 80 it spills, and is slower)
    }
    else if (sub >= 4 && (int)pl.L <= quad_maxl) {
@@ -881,6 +888,10 @@ void launch_resolve(hipStream_t st, const MmGeom &g, const mmh_plan_desc &pl, co
    a.mid_off = rb.mid_off; a.mid_hi = rb.mid_hi; a.mid_set = rb.mid_set; a.mid_slot = rb.mid_slot;
    a.mid_count = reinterpret_cast<unsigned int *>(rb.ctrl + MM_CTRL_MID);
    a.flag_bits = flag_bits;
+   if (pl.L > MM_RESOLVER_MAX_KEYWORD) {
+      hipLaunchKernelGGL(mm_resolve_long, dim3(tuning().resolve_blocks), dim3(64 * MM_WAVES), 0, st, a);
+      return;
+   }
    hipLaunchKernelGGL(mm_resolve, dim3(tuning().resolve_blocks), dim3(64 * MM_WAVES), 0, st, a);
 }
 

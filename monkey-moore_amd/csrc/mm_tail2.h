@@ -150,7 +150,7 @@ __device__ __forceinline__ void mm_resolve_sub(const A &a, const MmPlanLds &P, M
    }
 }
 
-template <int OCC, int SUBW>
+template <int OCC, int SUBW, bool LONG = false>
 __global__ __launch_bounds__(64 * MM_WAVES, OCC) void mm_scan_tail2(MmFusedArgs a)
 {
    __shared__ MmPlanLds P;
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(64 * MM_WAVES, OCC) void mm_scan_tail2(MmFusedArgs 
             rank += (uint32_t)__popcll(__ballot(mk < o));
          }
          int64_t hi = 0; mm_set_t set = 0; uint64_t dom = 0;
-         const int verdict = mm_resolve_candidate(a, P, Wv[wave], o, lane, &walked, &hi, &set, &dom);
+         const int verdict = mm_resolve_any<LONG>(a, P, Wv[wave], o, lane, &walked, &hi, &set, &dom);
          if (lane == 0) {
             const uint64_t value = verdict == 1 ? mm_report_value(a.t.g, o, a.base_offset) : MM_NO_MATCH;
             a.out[ci] = value;

@@ -552,6 +552,122 @@ __device__ __forceinline__ int mm_resolve_candidate(const A &a, const MmPlanLds 
    return verdict;
 }
 
+// ---- keywords of 65 .. 128 symbols (round 6): D = 64 .. 127 phases, two per lane ------------------------------------
+// Until round 5 such keywords always ran on the forward engine (8 - 11 ms per 4 GiB against 0.73 on the candidate path).
+// The look-back windows work the same way with lane e following phases e AND e + 64 and the phase set as two ballots;
+// only this first resolver knows such maps -- the stored maps of mm_resolve2 / mm_hard_resolve stay 64 bytes -- so a
+// candidate the windows do not settle is counted but not handed on, and the host reads any left-over of such a keyword
+// as "more than the second phase takes": it runs the forward engine on the domains concerned (run_flagged_domains), as
+// it does for any such overflow.
+struct MmSet2 {
+   uint64_t lo, hi;                           // phases 0 .. 63, 64 .. 127
+};
+
+// Map of the (<= 512) positions [lo, lo + npos): *v0 / *v1 = exit phase of entry phase lane / lane + 64 (lanes that are
+// no phase: their own number).  See mm_tile_map.
+template <class WL>
+__device__ __forceinline__ void mm_tile_map2(const MmTileArgs &a, const MmPlanLds &P, WL &W, uint64_t start, int64_t lo, int npos,
+                                             uint32_t lo_mod, int lane, uint32_t *v0, uint32_t *v1, bool *end_matches, bool want_end)
+{
+   start = mm_uniform64(start);
+   lo = (int64_t)mm_uniform64((uint64_t)lo);
+   npos = (int)mm_uniform((uint32_t)npos);
+   lo_mod = mm_uniform(lo_mod);
+   const uint8_t *tile = mm_tile_jumps(a, P, W, start, lo, npos, lane);
+   const uint32_t D = a.plan.L - 1;
+   const uint32_t end_mod = mm_modd(a, lo_mod + (uint32_t)npos);
+   uint32_t v[2];
+#pragma unroll
+   for (int h = 0; h < 2; h++) {
+      const uint32_t e = (uint32_t)lane + 64u * h;
+      v[h] = e;
+      if (e < D) {
+         uint32_t p = e + D - lo_mod;                       // first position of the window in phase e
+         p = p >= D ? p - D : p;
+         while (p < (uint32_t)npos) {
+            p += W.jump[p] & (MM_JUMP_MATCH - 1);
+         }
+         uint32_t x = end_mod + (p - (uint32_t)npos);       // the chain left the window at p in [npos, npos + D)
+         v[h] = x >= D ? x - D : x;
+      }
+   }
+   *v0 = v[0];
+   *v1 = v[1];
+   if (end_matches && want_end) {
+      *end_matches = mm_tile_matches(a, P, tile, npos);
+   }
+   mm_wave_sync();
+}
+
+__device__ __forceinline__ bool mm_set2_has(const MmSet2 &A, uint32_t v)
+{
+   return ((v < 64 ? A.lo >> v : A.hi >> (v - 64)) & 1ull) != 0;
+}
+
+// mm_resolve_candidate for D = 64 .. 127.  1 / 0 / -2 as there; -1: the windows (256, 512, 512 positions) could not tell.
+template <class A, class WL>
+__device__ __forceinline__ int mm_resolve_candidate_long(const A &a, const MmPlanLds &P, WL &W, uint64_t o, int lane,
+                                                         unsigned long long *walked, uint64_t *dom_out)
+{
+   const uint32_t D = a.t.plan.L - 1;
+   const MmSet2 full = {~0ull, D >= 128 ? ~0ull : ((1ull << (D - 64)) - 1ull)};
+   uint64_t b; uint32_t p; int64_t jc;
+   if (!mm_locate_fast(a.t, o, &b, &p, &jc)) {
+      return -2;
+   }
+   const uint64_t start = mm_domain_start(a.t.g, b, p);
+   *dom_out = a.t.g.whole ? 0 : b * a.t.g.S + p;
+   const uint32_t ph = mm_modd64(a.t, (uint64_t)jc);
+   MmSet2 S = {ph < 64 ? 1ull << ph : 0ull, ph >= 64 ? 1ull << (ph - 64) : 0ull};
+   int64_t hi = jc;
+   int verdict = -1;
+   if (jc == 0) {
+      bool matched;
+      mm_step(a.t.plan, [&](int64_t k) { return mm_elem(a.t.g, start, k); }, 0, &matched);
+      verdict = matched ? 1 : 0;
+   }
+   for (int step = 0; step < MM_FAST_STEPS && hi > 0 && verdict < 0; step++) {
+      const int64_t size = step == 0 ? 256 : 512;
+      const int64_t lo = hi > size ? hi - size : 0;
+      bool is_match = true;
+      uint32_t v0, v1;
+      mm_tile_map2(a.t, P, W, start, lo, (int)(hi - lo), mm_modd64(a.t, (uint64_t)lo), lane, &v0, &v1, &is_match, step == 0);
+      (*walked)++;
+      if (!is_match) {
+         verdict = 0;
+         break;
+      }
+      const uint64_t nlo = __ballot((uint32_t)lane < D && mm_set2_has(S, v0));
+      const uint64_t nhi = __ballot((uint32_t)lane + 64u < D && mm_set2_has(S, v1));
+      S.lo = nlo;
+      S.hi = nhi;
+      hi = lo;
+      if ((S.lo == full.lo && S.hi == full.hi) || (S.lo | S.hi) == 0) {
+         verdict = (S.lo | S.hi) ? 1 : 0;
+         break;
+      }
+   }
+   if (verdict < 0 && hi == 0) {
+      verdict = (S.lo & 1ull) ? 1 : 0;         // domain start: the chain is in phase 0
+   }
+   return verdict;
+}
+
+// the resolver of a kernel instantiation: LONG = keywords beyond 64 symbols (hi = -1 marks what mm_resolve_hand_over gets)
+template <bool LONG, class A, class WL>
+__device__ __forceinline__ int mm_resolve_any(const A &a, const MmPlanLds &P, WL &W, uint64_t o, int lane, unsigned long long *walked,
+                                              int64_t *hi_out, mm_set_t *set_out, uint64_t *dom_out)
+{
+   if constexpr (LONG) {
+      *hi_out = -1;
+      *set_out = 0;
+      return mm_resolve_candidate_long(a, P, W, o, lane, walked, dom_out);
+   }
+   else {
+      return mm_resolve_candidate(a, P, W, o, lane, walked, hi_out, set_out, dom_out);
+   }
+}
+
 // lane 0 of the wave that could not settle candidate ci: hand it to mm_resolve2 (or, in the flag
 // pass, mark its domain)
 template <class A>
@@ -559,6 +675,12 @@ __device__ __forceinline__ void mm_resolve_hand_over(const A &a, uint64_t o, uin
 {
    if (a.flag_bits) {
       atomicOr(&a.flag_bits[dom >> 5], 1u << (dom & 31));
+      return;
+   }
+   if (hi < 0) {
+      // (a keyword beyond 64 symbols: counted, not stored -- the second phase does not know its maps, and the host reads
+      // ANY left-over of such a keyword as "more than the second phase takes", finish_pipeline)
+      atomicAdd(a.mid_count, 1u);
       return;
    }
    unsigned int slot = atomicAdd(a.mid_count, 1u);   // beyond MM_MID_CAP: the host sees the count and switches engines
@@ -570,6 +692,7 @@ __device__ __forceinline__ void mm_resolve_hand_over(const A &a, uint64_t o, uin
    }
 }
 
+template <bool LONG>
 __device__ __forceinline__ void mm_resolve_body(const MmResolveArgs &a, const MmPlanLds &P, MmWaveLdsShort &W, MmResolveLds &R)
 {
    const int wave = (int)mm_uniform(threadIdx.x >> 6);
@@ -589,7 +712,7 @@ __device__ __forceinline__ void mm_resolve_body(const MmResolveArgs &a, const Mm
       // wave uniform from here on: the index arithmetic below runs on the scalar unit
       const uint64_t o = mm_candidate(a, excl, ci);
       int64_t hi = 0; mm_set_t set = 0; uint64_t dom = 0;
-      const int verdict = mm_resolve_candidate(a, P, W, o, lane, &walked, &hi, &set, &dom);
+      const int verdict = mm_resolve_any<LONG>(a, P, W, o, lane, &walked, &hi, &set, &dom);
       if (lane == 0) {
          a.out[ci] = verdict == 1 ? mm_report_value(a.t.g, o, a.base_offset) : MM_NO_MATCH;
          if (verdict == -1) {
@@ -615,7 +738,18 @@ __global__ __launch_bounds__(64 * MM_WAVES) void mm_resolve(MmResolveArgs a)
    __shared__ MmResolveLds R;
    mm_resolve_prefix(a, R);
    mm_plan_to_lds(P, a.t.plan);                 // ends with a __syncthreads()
-   mm_resolve_body(a, P, Wv[threadIdx.x >> 6], R);
+   mm_resolve_body<false>(a, P, Wv[threadIdx.x >> 6], R);
+}
+
+// ... for keywords of 65 .. 128 symbols
+__global__ __launch_bounds__(64 * MM_WAVES) void mm_resolve_long(MmResolveArgs a)
+{
+   __shared__ MmPlanLds P;
+   __shared__ MmWaveLdsShort Wv[MM_WAVES];
+   __shared__ MmResolveLds R;
+   mm_resolve_prefix(a, R);
+   mm_plan_to_lds(P, a.t.plan);
+   mm_resolve_body<true>(a, P, Wv[threadIdx.x >> 6], R);
 }
 #endif
 

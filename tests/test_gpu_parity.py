@@ -350,10 +350,10 @@ def test_keyword_lengths(mm, gpu_engine, oracle, L):
 @pytest.mark.parametrize("elem,be", [(1, False), (2, True)])
 def test_long_keywords(mm, gpu_engine, oracle, L, path, elem, be):
     """Keywords beyond 32 symbols, up to the 128 the reference's char-sized tables allow (monkey_moore.cpp:250-253).  Up to
-    64 symbols the per-candidate resolvers take them (round 5: a phase set is a 64-bit ballot over the map's lanes,
-    D = L - 1 <= 63), beyond that D no longer fits a wave and they run on the forward engine (phase maps of 128 bytes,
-    lane e and lane e + 64).  Both reference loops, both element sizes, engine and whole-buffer semantics, the forward
-    engine forced on the shorter ones as well, against the oracle."""
+    64 symbols the per-candidate resolvers take them with a phase set of one 64-bit ballot (D = L - 1 <= 63); beyond that
+    (round 6) the first resolver follows two phases per lane and what its look-back windows leave open goes to the forward
+    engine (phase maps of 128 bytes, lane e and lane e + 64).  Both reference loops, both element sizes, engine and
+    whole-buffer semantics, the forward engine forced on every one of them as well, against the oracle."""
     rng = np.random.default_rng(1000 + L + 7 * elem)
     wildcard = 0
     if path == "simple":
@@ -381,10 +381,10 @@ def test_long_keywords(mm, gpu_engine, oracle, L, path, elem, be):
     for block in (524288, 65536 + 2 * elem):
         want = oracle.engine(oplan, rom, block, be)
         got = gpu_engine.scan(plan, block_bytes=block, big_endian=be)
-        # (candidate path up to 64 symbols -- 2: its hard resolver, 4 / 5: the low-entropy stretches to the forward engine)
-        assert gpu_engine.counters()["path"] == 3 if L > 64 else gpu_engine.counters()["path"] in (0, 2, 4, 5), gpu_engine.counters()
+        # (the candidate path -- 2: its hard resolver, 3 / 4 / 5: the low-entropy stretches to the forward engine)
+        assert gpu_engine.counters()["path"] in (0, 2, 3, 4, 5), gpu_engine.counters()
         assert got.tolist() == want.tolist(), (L, path, elem, block)
-        if L <= 64:
+        if True:
             gpu_engine.set_engine(2)                           # the forward engine's wide maps on the same keyword
             assert gpu_engine.scan(plan, block_bytes=block, big_endian=be).tolist() == want.tolist(), (L, path, elem, block, "forward")
             gpu_engine.set_engine(0)
