@@ -31,6 +31,8 @@
  *   MMOORE_HIP_MULTI         facade: 1 = take the multi-device path whatever the file's size
  *   MMOORE_GATHER_TIMEOUT_S  how long mmh_gather_finish waits for a peer rank before it fails (default 120)
  *   MMOORE_SELFTEST          0 = skip the first-use known-answer test of mmh_create ("route health" below)
+ *   MMOORE_WARMUP            0 = skip the device warm-up of the first mmh_create (~0.26 s once per process: code objects,
+ *                            streams, copy engines, the radix sort); the first scans then pay for it piecemeal
  *   MMOORE_TRACE             diagnostics on stderr: sync, split, lanes, fused, floods, ingest, selftest -- a comma-separated
  *                            list, or 1 for all of them
  *   MMOORE_MAX_CANDIDATES    (tests) where the per-candidate path hands a scan to the flood paths (default 1048576)

@@ -241,7 +241,7 @@ void warm_device(int device)
       for (int engine : {0, 2}) {
          (void)mmh_set_engine(t, engine);
          for (uint32_t elem : {1u, 2u}) {
-            for (uint32_t len : {engine == 0 ? 4u - elem : 12u, 65u}) {
+            for (uint32_t len : {engine == 0 ? 4u - elem : 12u, engine == 0 ? 4u - elem : 65u}) {
                mmh_plan_desc plan;
                if (mmh_plan_relative(elem, kw, len, 0, nullptr, 0, &plan) == MMH_OK) {
                   (void)mmh_scan(t, &plan, 524288, 0, 0, out.data(), out.size(), &count);
@@ -289,7 +289,11 @@ extern "C" int mmh_create(int device, mmh_ctx **out)
       return rc;
    }
    if (device < kSelftestDevices) {
-      std::call_once(g_warm_once[device], [device] { warm_device(device); });
+      // (MMOORE_WARMUP=0: a process that wants its context at once and pays at its first scans instead)
+      static const bool warm = [] { const char *e = getenv("MMOORE_WARMUP"); return !(e && *e == '0'); }();
+      if (warm) {
+         std::call_once(g_warm_once[device], [device] { warm_device(device); });
+      }
    }
    if (selftest_enabled() && device < kSelftestDevices) {
       std::call_once(g_selftest_once[device], [device] {

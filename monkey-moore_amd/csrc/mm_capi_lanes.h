@@ -173,7 +173,8 @@ int submit_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int
    return MMH_OK;
 }
 
-int collect_impl(mmh_ctx *c, int ticket, uint64_t *out, uint64_t cap, uint64_t *out_count, bool *unsettled, bool *overflow = nullptr);
+int collect_impl(mmh_ctx *c, int ticket, uint64_t *out, uint64_t cap, uint64_t *out_count, bool *unsettled, bool *overflow = nullptr,
+                 uint64_t *flood2 = nullptr);
 } // namespace
 
 extern "C" int mmh_scan_collect(mmh_ctx *c, int ticket, uint64_t *out, uint64_t cap, uint64_t *out_count)
@@ -184,7 +185,8 @@ extern "C" int mmh_scan_collect(mmh_ctx *c, int ticket, uint64_t *out, uint64_t 
 namespace {
 // unsettled (tickets of scan_split only): set when the lane could not settle its part -- nothing is rescanned here then;
 // *overflow: ... because the part's bucketed store overflowed (narrower buckets = smaller parts may still do)
-int collect_impl(mmh_ctx *c, int ticket, uint64_t *out, uint64_t cap, uint64_t *out_count, bool *unsettled, bool *overflow)
+// flood2 (with overflow): [0] first byte, [1] bytes of the flooded buckets' extent in the ROM (0 bytes: not known)
+int collect_impl(mmh_ctx *c, int ticket, uint64_t *out, uint64_t cap, uint64_t *out_count, bool *unsettled, bool *overflow, uint64_t *flood2)
 {
    if (!c || !out_count || (!out && cap)) {
       mmh_set_error("mmh_scan_collect: bad argument");
@@ -214,6 +216,10 @@ int collect_impl(mmh_ctx *c, int ticket, uint64_t *out, uint64_t cap, uint64_t *
       if (overflow) {
          // (more candidates than the lane takes: narrower parts hold fewer, like narrower buckets)
          *overflow = oc.bucket_overflow || oc.candidates > w.out_cap || oc.candidates > oc.limit;
+      }
+      if (flood2) {
+         flood2[0] = (p.view ? p.view_first : 0) + oc.flood_first;
+         flood2[1] = oc.bucket_overflow ? oc.flood_bytes : 0;
       }
       rescan = oc.candidates > w.out_cap || oc.candidates > oc.limit || oc.hard_overflow || !oc.sorted_on_device;
       static const bool lane_trace = mm_trace("lanes");     // development: where the lanes' kernels lie in time

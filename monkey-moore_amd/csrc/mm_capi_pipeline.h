@@ -14,6 +14,7 @@ struct Outcome {
    bool hard_overflow = false;
    bool sorted_on_device = false;
    bool bucket_overflow = false;    // (tickets of scan_split only) the bucketed store overflowed and nothing was run again
+   uint64_t flood_first = 0, flood_bytes = 0;   // ... and where: the flooded buckets' extent in the scanned bytes (0 bytes: not known)
    uint32_t limit = 0;              // the candidate limit of the kernels that ran (bucketed store: 2^20, list-based kernels: 2^18)
 };
 
@@ -371,6 +372,13 @@ int finish_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev, 
          HIP_TRY(hipEventSynchronize(ev[2]));
          oc->candidates = ~0ull;
          oc->bucket_overflow = true;
+         if (w.h_result[1] >> 32 & 1) {
+            // (mm_scan_tail2 says where the overflowing buckets are, in units of 16 buckets of this scan's bucket width)
+            const uint64_t unit = 16ull << mm::bucket_geom(g.nbytes).shift;
+            const uint64_t lo = w.h_result[1] & 0xFFFF, hi = (w.h_result[1] >> 16) & 0xFFFF;
+            oc->flood_first = lo * unit;
+            oc->flood_bytes = std::min<uint64_t>((hi + 1) * unit, g.nbytes) - oc->flood_first;
+         }
          w.ctrl_clean = false;
          return MMH_OK;
       }

@@ -58,9 +58,13 @@ struct SplitProgress {
 // probe: the stage's first part goes alone -- behind a part that flooded the next one may well flood too, and parts in
 // flight behind a part that does not settle are scanned for nothing.
 int split_stage(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int big_endian, uint64_t base_offset, uint64_t *out,
-                uint64_t cap, SplitProgress *pg, uint64_t unit, bool adaptive, bool *overflowed, bool probe = false, uint64_t stop_block = ~0ull)
+                uint64_t cap, SplitProgress *pg, uint64_t unit, bool adaptive, bool *overflowed, bool probe = false, uint64_t stop_block = ~0ull,
+                uint64_t *flood2 = nullptr)
 {
    *overflowed = false;
+   if (flood2) {
+      flood2[0] = flood2[1] = 0;                    // where the part that ended the stage floods (bytes of the ROM; [1] = 0: not known)
+   }
    const uint64_t N = c->rom_bytes, S = plan->elem_bytes;
    const uint64_t nblocks = std::min<uint64_t>((N + block_bytes - 1) / block_bytes, stop_block);    // (stop_block: the stage ends there)
    const uint64_t overlap = (uint64_t)(plan->L - 1) * S;
@@ -77,7 +81,8 @@ int split_stage(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int
       const uint64_t room = failed ? 0 : (pg->total <= cap ? cap - pg->total : 0);
       uint64_t nowhere = 0;                         // (no room left: the part is only counted)
       c->device_idle_hint = next_block >= nblocks;       // (everything is submitted: what is still collected lies in the open)
-      int rc = collect_impl(c, tickets[0], room ? out + pg->total : &nowhere, room, &n, &unsettled, &overflow);
+      uint64_t where[2] = {0, 0};
+      int rc = collect_impl(c, tickets[0], room ? out + pg->total : &nowhere, room, &n, &unsettled, &overflow, where);
       c->device_idle_hint = false;
       if (rc == MMH_E_CAPACITY) {
          // (the part's list is in its lane's block; only the count matters now: the caller comes back with more room)
@@ -100,6 +105,10 @@ int split_stage(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int
       }
       if (unsettled) {
          *overflowed = overflow;
+         if (flood2 && overflow) {
+            flood2[0] = where[0];
+            flood2[1] = where[1];
+         }
          failed = true;
          return;
       }
@@ -168,7 +177,19 @@ int scan_split(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int 
    const auto t_start = std::chrono::steady_clock::now();
    SplitProgress pg;
    bool overflowed = false;
-   int rc = split_stage(c, plan, block_bytes, big_endian, base_offset, out, cap, &pg, unit, true, &overflowed);
+   uint64_t flood[2] = {0, 0};
+   // MMOORE_TRACE=split: what every stage of this scan did and when (host clock, us from the scan's start)
+   static const bool tracing = mm_trace("split");
+   auto note = [&](const char *what, uint64_t b0, uint64_t b1) {
+      if (tracing) {
+         fprintf(stderr, "   split %8.1f us  %-26s blocks [%llu, %llu)  done %llu of %llu, %llu offsets, %u parts%s\n",
+                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() * 1e6, what, (unsigned long long)b0,
+                 (unsigned long long)b1, (unsigned long long)pg.done_blocks, (unsigned long long)nblocks, (unsigned long long)pg.total, pg.parts,
+                 overflowed ? (flood[1] ? "  [flood, extent known]" : "  [flood]") : "");
+      }
+   };
+   int rc = split_stage(c, plan, block_bytes, big_endian, base_offset, out, cap, &pg, unit, true, &overflowed, false, ~0ull, flood);
+   note("stage 1 (adaptive)", 0, nblocks);
    uint64_t path = 0;
    std::vector<uint64_t> rest_list;                 // (what scan_impl keeps of a list that only exists on the host: not needed here)
    // [first block, behind the last) in one synchronous scan, its list behind what the parts delivered
@@ -191,6 +212,7 @@ int scan_split(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int 
       path = std::max<uint64_t>(path, c->counters[3]);
       pg.parts++;
       pg.done_blocks = b1;
+      note(dense ? "forward engine on" : "one synchronous scan of", b0, b1);
       return r;
    };
    // (stage 1 above; from here on: behind every flood the coarse parts again)
@@ -201,12 +223,46 @@ int scan_split(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int 
          rc = scan_rest(pg.done_blocks, nblocks, false);
          break;
       }
+      if (flood[1] != 0 && flood[1] <= fine * block_bytes / 4) {
+         // The tail kernel said WHERE the part floods (the overflowing buckets' extent: padding that matches the keyword
+         // wholesale is a MiB or two of a ROM): the blocks in front of it on the candidate path, the forward engine on the
+         // flooded blocks alone, the coarse parts again behind them.  (A keyword's length of slack on either side: buckets
+         // are keyed on a candidate's anchor.)
+         const uint64_t f0 = std::max<uint64_t>(pg.done_blocks, (flood[0] > 256 ? flood[0] - 256 : 0) / block_bytes);
+         const uint64_t f1 = std::min<uint64_t>(nblocks, (flood[0] + flood[1] + 256 + block_bytes - 1) / block_bytes);
+         flood[1] = 0;
+         if (f0 > pg.done_blocks) {
+            bool again = false;
+            rc = split_stage(c, plan, block_bytes, big_endian, base_offset, out, cap, &pg, std::max<uint64_t>(fine, 1), false, &again, false, f0);
+            note("parts up to the flood", pg.done_blocks, f0);
+            if (rc != MMH_OK) {
+               break;
+            }
+            if (pg.done_blocks < f0) {
+               overflowed = again;                  // (it did not get there: the general way from where it stands)
+               if (again) {
+                  goto general;
+               }
+               continue;
+            }
+         }
+         floods++;
+         rc = scan_rest(pg.done_blocks, floods > 2 ? nblocks : std::max(f1, pg.done_blocks + 1), true);
+         if (rc != MMH_OK || pg.done_blocks >= nblocks) {
+            break;
+         }
+         rc = split_stage(c, plan, block_bytes, big_endian, base_offset, out, cap, &pg, unit, true, &overflowed, true, ~0ull, flood);
+         note("coarse parts again", f1, nblocks);
+         continue;
+      }
+   general:
       // The coarse part at done_blocks flooded: ITS extent in parts half as wide (narrower buckets), the first one alone.
       const uint64_t coarse_end = std::min(nblocks, pg.done_blocks + unit);
       bool other = false;                           // a fine part failed for another reason than a flood
       while (rc == MMH_OK && pg.done_blocks < coarse_end && !other) {
          if (fine < unit) {
             rc = split_stage(c, plan, block_bytes, big_endian, base_offset, out, cap, &pg, fine, false, &overflowed, true, coarse_end);
+            note("finer parts", pg.done_blocks, coarse_end);
             if (rc != MMH_OK || pg.done_blocks >= coarse_end) {
                break;
             }
@@ -229,7 +285,8 @@ int scan_split(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int 
          continue;                                  // (-> the rest of the ROM the usual way)
       }
       // behind the flooded part: coarse parts again, the adaptive way (the first one alone: it may flood as well)
-      rc = split_stage(c, plan, block_bytes, big_endian, base_offset, out, cap, &pg, unit, true, &overflowed, true);
+      rc = split_stage(c, plan, block_bytes, big_endian, base_offset, out, cap, &pg, unit, true, &overflowed, true, ~0ull, flood);
+      note("coarse parts again", pg.done_blocks, nblocks);
    }
    path = path ? path : (pg.hard ? 2 : 0);
    // The parts' timings as ONE entry of the history: [streaming kernels of all parts, summed -- they overlap, so the sum

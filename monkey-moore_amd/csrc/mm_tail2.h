@@ -29,6 +29,7 @@ struct MmTail2Lds {
    unsigned int super_excl[MM_MAX_BUCKETS / MM_SUPER + 1];   // candidates in front of every super-bucket; [nsuper] = all
    unsigned int holes, walked;
    int last_block;
+   uint32_t flood_lo[MM_WAVES], flood_hi[MM_WAVES];          // first / last thread (= 16 buckets) with an overflowing bucket, per wave
 };
 
 // ---- several candidates per wave (round 4) --------------------------------------------------------------------------
@@ -167,15 +168,24 @@ __global__ __launch_bounds__(64 * MM_WAVES, OCC) void mm_scan_tail2(MmFusedArgs 
    {
       const uint4 *row = reinterpret_cast<const uint4 *>(a.bcount) + (uint64_t)threadIdx.x * 4;
       unsigned int sum = 0;
+      bool flooded = false;                                               // one of this thread's 16 buckets holds more than its store
 #pragma unroll
       for (int k = 0; k < 4; k++) {
          const uint4 v = row[k];                                          // (buckets behind the ROM's last one were never touched: zero)
          sum += v.x + v.y + v.z + v.w;
+         flooded = flooded || v.x > MM_BUCKET_CAP || v.y > MM_BUCKET_CAP || v.z > MM_BUCKET_CAP || v.w > MM_BUCKET_CAP;
       }
       sum += (unsigned int)__shfl_xor((int)sum, 1);
       sum += (unsigned int)__shfl_xor((int)sum, 2);
       if ((threadIdx.x & 3) == 0) {
          T.super_excl[(threadIdx.x >> 2) + 1] = sum;
+      }
+      // WHERE a flood is (round 6): the first and the last thread with an overflowing bucket, i.e. the flood's extent in
+      // units of 16 buckets -- the host sends the forward engine there and nowhere else (mm_capi_split.h)
+      const unsigned long long fl = __ballot(flooded);
+      if (lane == 0) {
+         T.flood_lo[wave] = fl ? (uint32_t)(64 * wave + __builtin_ctzll(fl)) : 0xFFFFu;
+         T.flood_hi[wave] = fl ? (uint32_t)(64 * wave + 63 - __builtin_clzll(fl)) : 0u;
       }
    }
    if (threadIdx.x == 0) {
@@ -427,6 +437,16 @@ __global__ __launch_bounds__(64 * MM_WAVES, OCC) void mm_scan_tail2(MmFusedArgs 
       unsigned long long h = 0;
       switch (lane) {
       case 0: h = overflow ? ~0ull : ncand; break;         // candidates = slots (~0: a bucket overflowed)
+      case 1: {                                            // a flood's extent: bit 32 | first | last << 16, in units of 16 buckets
+         uint32_t lo = 0xFFFFu, hi = 0u;
+#pragma unroll
+         for (int w = 0; w < MM_WAVES; w++) {
+            lo = T.flood_lo[w] < lo ? T.flood_lo[w] : lo;
+            hi = T.flood_hi[w] > hi ? T.flood_hi[w] : hi;
+         }
+         h = overflow && lo != 0xFFFFu ? (1ull << 32) | lo | ((unsigned long long)hi << 16) : 0;
+         break;
+      }
       case 2: h = tiles; break;
       case 4: h = (resolvable ? MM_HDR_SPARSE : 0) | (resolvable && !direct ? MM_HDR_ON_DEVICE : 0); break;
       case 5: h = mid; break;

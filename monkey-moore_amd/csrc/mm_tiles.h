@@ -52,7 +52,9 @@ constexpr int MM_FAST_STEPS = 3;              // look-back windows of the per-ca
 constexpr int MM_MID_CHUNK = 512;             // mm_resolve2: a workgroup's waves map chunks of this many positions in parallel
 constexpr int MM_MID_CAP = 2048;              // candidates mm_resolve hands to mm_resolve2 per scan
 constexpr int MM_HARD_PARTS = 64;             // workgroups per hard candidate
-constexpr int MM_HARD_CAP = 32;               // hard candidates handled per scan
+constexpr int MM_HARD_CAP = 32;               // hard candidates handled per scan (round 6 measured 128: a periodic keyword -- `abcd`, ~30
+                                              // hard candidates per GiB of random bytes -- then settles inside the split pipeline's parts, and
+                                              // takes 5.2 ms per 4 GiB instead of 4.2: the flag pass + forward engine on the domains is faster)
 constexpr int MM_HARD_MAX_TILES = 8192;       // longest prefix (in tiles) mm_hard_resolve maps
 constexpr int MM_JUMP_MATCH = 0x80;           // flag in a stored jump: the compare loop reported a match here
 
