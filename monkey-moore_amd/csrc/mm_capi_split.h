@@ -188,7 +188,30 @@ int scan_split(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int 
                  overflowed ? (flood[1] ? "  [flood, extent known]" : "  [flood]") : "");
       }
    };
-   int rc = split_stage(c, plan, block_bytes, big_endian, base_offset, out, cap, &pg, unit, true, &overflowed, false, ~0ull, flood);
+   // A keyword whose deltas all lie on one line -- `aaaa`, `abcd`, `ab*de`: every literal is its left neighbour plus the
+   // same step per place -- matches padding and ramps wholesale, and ROMs are full of those: its first part goes alone
+   // (what is in flight behind a part that floods is scanned for nothing: three eighths of the ROM).  Read off the plan,
+   // not remembered from an earlier scan.
+   bool on_a_line = true;
+   bool have_step = false;
+   int64_t step_num = 0;
+   for (uint32_t i = 0; i < plan->L && on_a_line; i++) {
+      if (plan->cmp_mask[i] == 0 || plan->bridge[i] >= 0) {
+         continue;
+      }
+      const int64_t places = -(int64_t)plan->bridge[i];
+      if (plan->expected[i] % places != 0) {
+         on_a_line = false;
+      }
+      else if (!have_step) {
+         have_step = true;
+         step_num = plan->expected[i] / places;
+      }
+      else {
+         on_a_line = plan->expected[i] / places == step_num;
+      }
+   }
+   int rc = split_stage(c, plan, block_bytes, big_endian, base_offset, out, cap, &pg, unit, true, &overflowed, on_a_line && have_step, ~0ull, flood);
    note("stage 1 (adaptive)", 0, nblocks);
    uint64_t path = 0;
    std::vector<uint64_t> rest_list;                 // (what scan_impl keeps of a list that only exists on the host: not needed here)

@@ -197,6 +197,10 @@ int prepare_scans(mmh_ctx *c)
    if (rc == MMH_OK) {
       rc = ensure_fetch_ring(c);
    }
+   if (rc == MMH_OK) {
+      // the flag pass's domain bitmap + list (run_flagged_domains, run_candidate_floods): blocks of >= 64 KiB, both alignments
+      rc = grow(&c->d_domains, &c->domains_cap, 3 * (c->rom_bytes >> 16) + 64);
+   }
    if (rc != MMH_OK) {
       return rc;
    }
