@@ -40,7 +40,7 @@
 #define MM_FORWARD_H
 
 
-constexpr int MM_FWD_BATCH = 16;               // tiles per batch (one wave): 32 Ki positions
+constexpr int MM_FWD_BATCH = 16;               // tiles per batch (one wave) at most: 32 Ki positions (MmForwardArgs::batch: 16, or 4 for small inputs)
 // positions per tile: a tile's positions sit in up to 3 slots further on (MmFwdLds), and 64 lanes own
 // 64 groups of 32 slots -- 2044 + 3 slots still fit them
 constexpr int MM_FWD_TILE = MM_TILE - 4;
@@ -71,6 +71,7 @@ struct MmForwardArgs {
    const uint32_t *dom_list; // nullptr: every domain; else the domains to work on
    uint32_t tpd;             // tiles per domain
    uint32_t bpd;             // batches per domain
+   uint32_t batch;           // tiles per batch (<= MM_FWD_BATCH)
    uint8_t *agg;             // [ndom * bpd][MAXD] published batch maps (MAXD = 32, or 128 for keywords beyond 32 symbols)
    unsigned long long *status;   // [ndom * bpd] look-back words (zeroed before the launch): state | exit phase << 8
    unsigned long long *ticket;   // next batch to hand out (zeroed before the launch)
@@ -779,8 +780,8 @@ __global__ __launch_bounds__(64 * MM_WAVES) __attribute__((amdgpu_waves_per_eu(E
       uint64_t start; int64_t nv;
       mm_fwd_domain(a, dom, &start, &nv);
       start = mm_uniform64(start);
-      const uint32_t t0 = b * MM_FWD_BATCH;
-      const uint32_t t1 = t0 + MM_FWD_BATCH < a.tpd ? t0 + MM_FWD_BATCH : a.tpd;
+      const uint32_t t0 = b * a.batch;
+      const uint32_t t1 = t0 + a.batch < a.tpd ? t0 + a.batch : a.tpd;
 
       // ---- pass 1: tile maps.  Two ways through the batch's tiles, one loop (the mapping code exists once):
       //

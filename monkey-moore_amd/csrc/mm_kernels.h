@@ -114,7 +114,8 @@ size_t rank_partials_bytes(uint32_t max_n);
 struct DenseGeom {
    uint64_t ndom;
    uint32_t tpd;             // tiles per domain
-   uint32_t bpd;             // batches (of MM_FWD_BATCH tiles) per domain
+   uint32_t batch;           // tiles per batch: MM_FWD_BATCH (16), 4 for small inputs (see dense_geom)
+   uint32_t bpd;             // batches per domain
    size_t status_bytes;      // ticket + look-back words, at the start of `maps`
    size_t loud_bytes;        // ... followed by the pre-pass's tile bitmap (0 with listed domains)
    size_t maps_bytes;        // ... followed by one published map per batch

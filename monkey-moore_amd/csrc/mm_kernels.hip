@@ -938,7 +938,12 @@ DenseGeom dense_geom(const MmGeom &g, uint64_t listed_domains)
       most = nv > most ? nv : most;
    }
    d.tpd = (uint32_t)((most + MM_FWD_TILE - 1) / MM_FWD_TILE);
-   d.bpd = (d.tpd + MM_FWD_BATCH - 1) / MM_FWD_BATCH;
+   // A wave maps the tiles of its batch one after the other, and a tile full of matches takes it ~60 us (dependent LDS
+   // chains with nobody to hide them): a flood a MiB wide in a small input -- the split pipeline's "forward engine on the
+   // flooded blocks", a few flagged domains -- is 32 batches of 16 tiles = a millisecond on 32 waves while the device
+   // idles.  Inputs that do not fill the device go in batches of 4 (round 6: 1.3 -> 0.5 ms for 5 MiB around a ramp).
+   d.batch = d.ndom * d.tpd < 48u * 1024u ? 4u : (uint32_t)MM_FWD_BATCH;
+   d.bpd = (d.tpd + d.batch - 1) / d.batch;
    // [ticket, pad][one look-back word per batch], then one map per batch
    d.status_bytes = (((size_t)d.ndom * d.bpd + 2) * sizeof(unsigned long long) + 255) & ~(size_t)255;
    // ... the pre-pass's tile bitmap (whole-ROM passes only; two words of slack: a batch's bits are read as two words) ...
@@ -953,7 +958,7 @@ static void launch_forward(hipStream_t st, const MmGeom &g, const mmh_plan_desc 
 {
    MmForwardArgs a{};
    a.t = tile_args(g, pl);
-   a.ndom = dg.ndom; a.dom_list = dom_list; a.tpd = dg.tpd; a.bpd = dg.bpd;
+   a.ndom = dg.ndom; a.dom_list = dom_list; a.tpd = dg.tpd; a.bpd = dg.bpd; a.batch = dg.batch;
    const uint64_t nbatches = dg.ndom * dg.bpd;
    a.ticket = reinterpret_cast<unsigned long long *>(db.maps);
    a.status = a.ticket + 2;
