@@ -257,28 +257,51 @@ int run_flagged_domains(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, ui
       return rc;
    }
    uint32_t *d_bits = reinterpret_cast<uint32_t *>(c->d_domains);
-   HIP_TRY(hipMemsetAsync(d_bits, 0, words * sizeof(uint32_t), st));
-   HIP_TRY(hipMemsetAsync(w.d_ctrl, 0, mm::ctrl_bytes(), st));
-   w.ctrl_clean = false;
-   // the candidate lists of the first pass are gone with the control block: run the filter again
-   mm::FilterChoice fc;
-   mm::choose_filter(pl, &fc);
-   const mm::ResolveBuffers rb = resolve_buffers(w);
-   mm::launch_filter(st, g, pl, fc, w.d_cand, w.d_ctrl, w.cand_cap);
-   mm::launch_resolve(st, g, pl, rb, base_offset, max_candidates, d_bits);
-   HIP_TRY(hipGetLastError());
    std::vector<uint32_t> bits(words);
    std::vector<uint64_t> slots(first_pass_slots);
-   unsigned long long seen = 0;
-   HIP_TRY(hipMemcpyAsync(bits.data(), d_bits, words * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-   // every candidate got its slot again (same candidates; their order may differ from the first pass)
-   HIP_TRY(hipMemcpyAsync(slots.data(), w.d_out, first_pass_slots * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-   HIP_TRY(hipMemcpyAsync(&seen, w.d_ctrl + MM_CTRL_TOTAL, sizeof seen, hipMemcpyDeviceToHost, st));
-   HIP_TRY(hipStreamSynchronize(st));
-   if (seen != first_pass_slots) {
-      // (~0: a list overflowed and mm_resolve did nothing -- found by a fuzz soak: 'bbbb' on a two-symbol
-      // alphabet, 165 K candidates in 1 MiB, reported 527 of 43538 matches from stale slots)
-      return MMH_OK;
+   if (w.mid_listed != ~0ull && w.mid_listed <= mm::mid_cap()) {
+      // Round 6: the first pass itself listed every candidate its windows left open (d_mid_off: the hand-over to the second
+      // phase, complete while it did not overflow) and left every candidate's verdict in its slot: the domains concerned
+      // are the domains of that list -- a superset of what the second phase could not settle either --, and the flag pass
+      // below (the filter over the whole ROM once more: 0.7 ms per 4 GiB) is not needed.
+      std::vector<uint64_t> open(w.mid_listed);
+      if (!open.empty()) {
+         HIP_TRY(hipMemcpyAsync(open.data(), w.d_mid_off, open.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+      }
+      HIP_TRY(hipMemcpyAsync(slots.data(), w.d_out, first_pass_slots * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      for (uint64_t o : open) {
+         const uint64_t blk = o / g.block_bytes;
+         const uint64_t d = blk * g.S + (o - blk * g.block_bytes) % g.S;
+         if (d < ndom) {
+            bits[d >> 5] |= 1u << (d & 31);
+         }
+      }
+      // (the second phase has written verdicts into some of the listed candidates' slots: they lie in flagged domains
+      // and are dropped below like every other verdict there)
+   }
+   else {
+      HIP_TRY(hipMemsetAsync(d_bits, 0, words * sizeof(uint32_t), st));
+      HIP_TRY(hipMemsetAsync(w.d_ctrl, 0, mm::ctrl_bytes(), st));
+      w.ctrl_clean = false;
+      // the candidate lists of the first pass are gone with the control block: run the filter again
+      mm::FilterChoice fc;
+      mm::choose_filter(pl, &fc);
+      const mm::ResolveBuffers rb = resolve_buffers(w);
+      mm::launch_filter(st, g, pl, fc, w.d_cand, w.d_ctrl, w.cand_cap);
+      mm::launch_resolve(st, g, pl, rb, base_offset, max_candidates, d_bits);
+      HIP_TRY(hipGetLastError());
+      unsigned long long seen = 0;
+      HIP_TRY(hipMemcpyAsync(bits.data(), d_bits, words * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      // every candidate got its slot again (same candidates; their order may differ from the first pass)
+      HIP_TRY(hipMemcpyAsync(slots.data(), w.d_out, first_pass_slots * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(&seen, w.d_ctrl + MM_CTRL_TOTAL, sizeof seen, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      if (seen != first_pass_slots) {
+         // (~0: a list overflowed and mm_resolve did nothing -- found by a fuzz soak: 'bbbb' on a two-symbol
+         // alphabet, 165 K candidates in 1 MiB, reported 527 of 43538 matches from stale slots)
+         return MMH_OK;
+      }
    }
 
    std::vector<uint32_t> doms;

@@ -81,6 +81,7 @@ int enqueue_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev,
       max_candidates = list_candidate_limit(w, max_candidates);
    }
    w.limit = max_candidates;
+   w.mid_listed = ~0ull;
    if (bucketed) {
       const int rc = ensure_buckets(c, w, st, g.nbytes);
       if (rc != MMH_OK) {
@@ -423,6 +424,9 @@ int finish_pipeline(mmh_ctx *c, MmWorkspace &w, hipStream_t st, hipEvent_t *ev, 
       return MMH_OK;
    }
    w.ctrl_clean = false;                        // kept for the second phase
+   if (leftovers <= mm::mid_cap() && pl.L <= MM_RESOLVER_MAX_KEYWORD) {
+      w.mid_listed = leftovers;                 // (run_flagged_domains: the domains concerned without another pass over the ROM)
+   }
    // (keywords beyond 64 symbols: the first resolver counts what it cannot settle but hands nothing on -- the second
    // phase's stored maps are 64 bytes --: any left-over is "more than the second phase takes", csrc/mm_tiles.h)
    if (pl.L > MM_RESOLVER_MAX_KEYWORD) {

@@ -38,6 +38,8 @@ struct MmWorkspace {
    uint64_t *d_out = nullptr;       // unordered matches
    uint64_t out_cap = 0;
    uint32_t limit = 0;              // candidate limit of the scan enqueued last (enqueue_pipeline)
+   uint64_t mid_listed = ~0ull;     // the scan's first phase handed this many undecided candidates on, all of them in d_mid_off
+                                    // (~0: not known / more than the list holds / a keyword whose left-overs are only counted)
    unsigned long long *d_ctrl = nullptr;   // counters + arrival tickets, zeroed per scan (mm::ResolveBuffers)
    uint64_t *d_mid_off = nullptr;   // hand-over list mm_resolve -> mm_resolve2
    uint64_t *d_mid_hi = nullptr;
