@@ -102,7 +102,24 @@ int fetch_device_list(mmh_ctx *c, const uint64_t *d_list, uint64_t n, uint64_t *
          holes = true;
       }
       if (dst && kept + valid <= cap) {
-         std::memcpy(dst + kept, src, valid * sizeof(uint64_t));
+         // (one thread copies out of pinned memory at 8-9 GB/s: a two-symbol keyword's 16 M matches spent 15 ms here.  Whole
+         // pieces go in four slices side by side)
+         if (valid >= kPiece / 2) {
+            constexpr int kSlices = 4;
+            std::thread helpers[kSlices - 1];
+            const uint64_t each = (valid + kSlices - 1) / kSlices;
+            for (int t = 1; t < kSlices; t++) {
+               const uint64_t a = std::min<uint64_t>(valid, each * t), b = std::min<uint64_t>(valid, each * (t + 1));
+               helpers[t - 1] = std::thread([=] { std::memcpy(dst + kept + a, src + a, (b - a) * sizeof(uint64_t)); });
+            }
+            std::memcpy(dst + kept, src, std::min<uint64_t>(valid, each) * sizeof(uint64_t));
+            for (auto &h : helpers) {
+               h.join();
+            }
+         }
+         else {
+            std::memcpy(dst + kept, src, valid * sizeof(uint64_t));
+         }
       }
       kept += valid;
       if (holes) {
