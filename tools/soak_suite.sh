@@ -7,7 +7,8 @@ TAG=${1:?tag}; N=${2:-6}
 LEDGER=${LEDGER:-profiles/r06_suite_soak.tsv}
 for i in $(seq 1 "$N"); do
    for attempt in 1 2 3 4 5 6; do
-      /usr/local/graft/bin/gpurun --timeout 2400 -- 'S=$(date +%s); python -m pytest tests -x -q -m gpu 2>&1 | tail -3 > gpurun_out/soak_suite.log; E=$(date +%s); echo "LEDGER $(hostname)-$(cat /proc/sys/kernel/random/boot_id | cut -c1-8) $((E-S))s $(tail -1 gpurun_out/soak_suite.log)"' > gpurun_out/soak_suite_$i.out 2>&1
+      # (pytest's summary line is not the last one: RCCL prints its version banner when the process ends)
+      /usr/local/graft/bin/gpurun --timeout 2400 -- 'S=$(date +%s); python -m pytest tests -x -q -m gpu > gpurun_out/soak_suite.log 2>&1; RC=$?; E=$(date +%s); echo "LEDGER $(hostname)-$(cat /proc/sys/kernel/random/boot_id | cut -c1-8) pytest rc=$RC $((E-S))s $(grep -E " passed| failed| error" gpurun_out/soak_suite.log | tail -1)"; grep -E "^FAILED|^ERROR" gpurun_out/soak_suite.log | head -5' > gpurun_out/soak_suite_$i.out 2>&1
       rc=$?
       if [ "$rc" != "2" ] && [ "$rc" != "3" ]; then break; fi
       sleep 45
