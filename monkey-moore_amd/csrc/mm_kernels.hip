@@ -1,36 +1,21 @@
 // SPDX-License-Identifier: GPL-3.0-or-later
-// mm_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the relative-search engine.
+// mm_kernels.hip -- launchers and the small kernels of the gfx950 (MI355X / CDNA4) relative-search engine.
 //
-// Pipeline of one scan (one stream; the host polls a word in pinned memory for the end):
-//
-//   mm_filter_u8 / mm_filter_u16   HBM-bound streaming pass over the whole ROM.
-//        Coalesced 16 B/lane loads; two stages: the first two SWAR conditions
-//        (pattern deltas) on every byte position, 4 positions per 32-bit VALU
-//        op; pieces with a stage-1 hit get all conditions (up to 4) from a
-//        re-read; the survivors -- CANDIDATES: positions where the reference's
-//        compare loop may report a match IF its chain visits them -- are
-//        appended wave-aggregated to 64 lists.
-//   mm_scan_tail  (mm_fused.h, mm_tiles.h)   one wavefront per candidate.  The
-//        reference is not a complete matcher: it only tests the positions its
-//        skip chain visits.  The wave verifies the compare loop
-//        at the candidate and decides "is it on the chain of its domain" exactly,
-//        by pulling the set of acceptable chain phases (phase = position mod
-//        (L-1)) back through the phase maps of one or two short windows until
-//        the set is empty, full, or the domain start (phase 0) is reached; it
-//        also counts the candidates with a smaller offset -- its place in the
-//        ascending list -- and writes the verdict there, in pinned host memory
-//        and in HBM (for the multi-GPU gather).  The last workgroup adds the
-//        header and raises the scan's sequence number.
-//   ROMs of up to 4 MiB: mm_scan_fused runs both stages in ONE launch (grid barrier).
-//   Second phase, only when candidates are left over (host decides from the published
-//   counters): mm_resolve2 -> mm_hard_resolve (mm_tiles.h) -> mm_rank_count / mm_rank_scatter.
-//   The lanes of mmh_scan_submit run the same two kernels; MMOORE_FUSED=0 brings back the round-1
-//   chain mm_filter -> mm_resolve -> mm_rank_count -> mm_rank_scatter everywhere.
-//
-// Other engines: mm_forward (mm_forward.h), the candidate-free forward engine, for
-// inputs the per-candidate path does not suit and for keywords beyond 32 symbols;
-// mm_chain_seq, one lane per domain walking the chain literally, as an on-device
-// cross-check.
+// The device code of the hot path lives in headers (everything a template or __forceinline__):
+//   mm_filter.h   the streaming filter -- mm_filter_u8 / mm_filter_u16<SHAPE>, HBM-bound: coalesced 16 B/lane loads, two SWAR
+//                 stages, survivors (CANDIDATES: positions where the reference's compare loop may report a match IF its chain
+//                 visits them) into ROM-ordered buckets -- whose 62 shapes are instantiated in the units of
+//                 mm_filter_shapes.hip and looked up here by table (mm_filter_shapes.h);
+//   mm_tail2.h    mm_scan_tail2, one launch behind the filter: every candidate verified, resolved and ranked into the
+//                 ascending list in pinned host memory and HBM; header; the flag word the host polls;
+//   mm_fused.h    mm_scan_fused (ROMs of up to 4 MiB: both stages in ONE launch, a grid barrier between them) and the
+//                 list-based tail mm_scan_tail;
+//   mm_tiles.h    the resolvers: exact chain membership through phase maps of look-back windows (mm_resolve_candidate, and
+//                 _long for keywords beyond 64 symbols), mm_resolve / mm_resolve2 / mm_hard_resolve for what they leave open;
+//   mm_forward.h  mm_forward, the candidate-free forward engine, for inputs the per-candidate path does not suit.
+// Here: the launch wrappers mm_capi.hip calls (choose_filter: which SWAR conditions a plan gets), the sequential
+// cross-check engine mm_chain_seq, the rank kernels of the event-synchronised chain, ROM fill / gather helpers.
+// Routes are switched at run time (mmh_set_route), not by environment.
 //
 // No MFMA anywhere: the path is integer byte comparison (BASELINE.json).
 #include <atomic>
