@@ -50,8 +50,9 @@ extern "C" {
 /* Longest keyword a plan holds.  The reference has no explicit limit, but its wildcard-path tables
  * store keyword_len - 1 in a char (src/core/monkey_moore.cpp:250-253, :270-272): from 129 symbols
  * on that wraps negative and its skip arithmetic changes meaning, so 128 is where parity ends.
- * Keywords of up to 64 symbols take the streaming filter + per-candidate resolvers; longer ones
- * always run on the forward engine (csrc/mm_forward.h), whose phase maps are sized for 127 phases. */
+ * Every length takes the streaming filter + per-candidate resolvers (beyond 64 symbols the first resolver follows two
+ * phases per lane and leaves what it cannot settle to the forward engine, csrc/mm_forward.h, whose phase maps are sized
+ * for 127 phases). */
 #define MMH_MAX_KEYWORD 128
 
 enum {
