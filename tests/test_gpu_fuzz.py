@@ -263,8 +263,9 @@ def test_fuzz_with_a_small_candidate_limit(tmp_path):
     import subprocess
     import sys
     report = tmp_path / "paths.json"
+    # (its own seeds, whatever a soak run set for this process: the floors below were measured on them)
     env = dict(os.environ, MMOORE_MAX_CANDIDATES="16384", MM_FUZZ_SEEDS="48", MM_FUZZ_MEDIUM="32", MM_FUZZ_LONG="1",
-               MM_FUZZ_REPORT=str(report))
+               MM_FUZZ_FIRST="0", MM_FUZZ_MEDIUM_FIRST="0", MM_FUZZ_REPORT=str(report))
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_fuzz.py"), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
                         "-k", "against_oracle or medium_roms or reached_every"], env=env, capture_output=True, text=True, timeout=1500,
