@@ -401,7 +401,11 @@ bool choose_filter(const mmh_plan_desc &pl, FilterChoice *fc)
    // above leave the streaming loop or the resolver short -- fewer than 3 (8-bit) / 2 (16-bit) conditions -- and a wide choice
    // has more.  Condition 1 of a wide choice is the literal next to the anchor's left (the kernels are compiled for the two
    // gaps only); ties go to equal gaps (one stream of deltas on the hot path), then to short ones, then to the rightmost anchor.
-   if ((int)best.ncond < std::min(u8 ? 3 : 2, want)) {
+   // ... and where their two per-byte conditions have different gaps (`qz*k`, `q*vk`: two exact SWAR subtractions per dword,
+   // 21 operations) while a wide choice has as many conditions: its seven-bit stage costs 14 (round 6, 4 GiB: the scan on
+   // the device 0.860 -> 0.803 ms and 0.830 -> 0.798 ms, profiles/r06_wide_shapes.log)
+   const bool mixed = u8 && best.ncond >= 2 && best.gap[0] != best.gap[1];
+   if ((int)best.ncond < std::min(u8 ? 3 : 2, want) || mixed) {
       auto wide_gap = [&](int i) -> int {
          if (i < 1 || pl.cmp_mask[i] == 0) {
             return 0;
@@ -443,7 +447,7 @@ bool choose_filter(const mmh_plan_desc &pl, FilterChoice *fc)
             wbest_cost = cost;
          }
       }
-      if (wbest.ncond > best.ncond) {
+      if (wbest.ncond > best.ncond || (mixed && wbest.ncond >= best.ncond)) {
          *fc = wbest;
          for (uint32_t k = 0; k < 4; k++) {
             const bool used = k < fc->ncond;

@@ -162,6 +162,16 @@ def test_filter_conditions_chosen(mm, elem, kw, conds, verify):
         assert info["verify_in_filter"] == verify
 
 
+def test_mixed_gaps_on_the_per_byte_stage_take_a_wide_shape(mm):
+    """Two per-byte conditions of different gaps cost the one-dword shapes two exact SWAR subtractions per dword; the wide
+    shapes' seven-bit stage takes them where it has as many conditions (csrc/mm_kernels.hip choose_filter)."""
+    for kw in ("qz*k", "q*vk"):
+        info = mm.filter_shape(mm.plan_relative(1, kw, ord("*")))
+        assert info["ncond"] == 2 and info["shape"] & 0x200, (kw, info)
+    info = mm.filter_shape(mm.plan_relative(1, "ab*de", ord("*")))       # (two conditions of the SAME gap moved up: stays)
+    assert info["shape"] & 0x200 == 0 and info["conditions"][:2] == [(4, 1), (1, 1)], info
+
+
 def test_filter_conditions_are_necessary_for_a_match(mm, oracle):
     """Each chosen condition (position i, gap g, expected delta of the plan) must hold at every
     match the oracle reports: the filter may only over-approximate the reference."""
