@@ -33,6 +33,15 @@
 //     and finds the tiles with something to report through the streaming filter's SWAR test
 //     (mm_fwd_loud_mask in the kernel for 8-bit elements, a bitmap from the filter itself for 16-bit
 //     ones).  1 GiB: 0.87 -> 0.43 ms (plain keyword), 0.97 -> 0.28 ms (wildcard keyword).
+//   * (round 6) LOUD batches -- most tiles have something to report: two- and three-symbol keywords, planted floods -- are
+//     WALKED: the batch sweeps its last tiles for its exit phase only, takes its entry phase from the look-back and goes
+//     through its tiles once, mm_fwd_emit handing the phase on (before: every tile mapped, then every tile walked -- jumps
+//     and exit tables twice).  Two-symbol keywords have one phase: no maps, no look-back, the finds straight off the
+//     flags.  Inside a tile: the positions whose first compare holds are resolved by all lanes at once after the table
+//     pass (not one at a time inside it), the compare loop keeps four steps' LDS reads in flight, the one phase goes
+//     through the 64 groups by super-group tables (23 - 31 dependent reads, not 64), short keywords walk a group on a bit
+//     mask in registers.  Forced engine, 1 GiB: planted flood 5.30 -> 1.86 ms, `qz` 3.10 -> 0.71, `q*v` 3.35 -> 1.49
+//     (profiles/r06_forward_engine.log; where a wave's cycles go: MM_FWD_PROFILE below).
 // Batches are handed out through tickets in order (blocks of 4 per workgroup, its waves taking them
 // one by one): a waiting wave only ever waits for batches that running waves own or will take next:
 // no residency assumption, no deadlock.
@@ -45,6 +54,23 @@ constexpr int MM_FWD_BATCH = 16;               // tiles per batch (one wave) at 
 // 64 groups of 32 slots -- 2044 + 3 slots still fit them
 constexpr int MM_FWD_TILE = MM_TILE - 4;
 constexpr unsigned long long MM_FWD_AGGREGATE = 1, MM_FWD_INCLUSIVE = 2;
+
+// Dev builds (EXTRA=-DMM_FWD_PROFILE tools/build_variant.sh prof): where a wave's cycles go, phase by phase -- wave 0 of a
+// few workgroups prints its sums when it is done.  MM_PROF(k): the cycles since the last mark belong to phase k.
+#ifdef MM_FWD_PROFILE
+__shared__ unsigned long long mm_prof[MM_WAVES][16];
+__shared__ unsigned long long mm_prof_t[MM_WAVES];
+#define MM_PROF(k)                                                                          \
+   do {                                                                                     \
+      if ((threadIdx.x & 63) == 0) {                                                        \
+         const unsigned long long now_ = __builtin_readcyclecounter();                      \
+         mm_prof[threadIdx.x >> 6][k] += now_ - mm_prof_t[threadIdx.x >> 6];                \
+         mm_prof_t[threadIdx.x >> 6] = now_;                                                \
+      }                                                                                     \
+   } while (0)
+#else
+#define MM_PROF(k) do { } while (0)
+#endif
 
 // a wave's working set: one tile of MM_TILE positions of ELEM-byte elements
 template <int ELEM>
@@ -135,12 +161,43 @@ __device__ __forceinline__ void mm_fwd_tables(MmFwdTables &T, const MmPlanLds &P
 }
 
 // the reference's compare loop at position q of the staged tile, from keyword position `from`
-// downwards (everything above already holds): the jump, | MM_JUMP_MATCH when the loop reports a match
+// downwards (everything above already holds): the jump, | MM_JUMP_MATCH when the loop reports a match.
+// A step is three dependent LDS reads (its bridge, then the two elements) and a planted match runs L of them -- one after
+// the other they were over half of a flooded tile's time (round 6, MM_FWD_PROFILE).  While three or more steps remain the
+// reads of four steps are in flight together and the steps are looked at in the reference's order; the last one or two
+// go one by one (keywords of three or four symbols have no more than that: reads for steps that do not exist cost
+// padding floods, whose every position comes here, a fifth more time).
 __device__ __forceinline__ int mm_deep_jump(const MmTileArgs &a, const MmPlanLds &P, const uint8_t *tile, int q, int from)
 {
    const int S = (int)a.g.S;
    const bool be = a.g.big_endian != 0;
-   for (int i = from; i >= 0; --i) {
+   int i = from;
+   for (; i >= 2; i -= 4) {
+      int at[4], br[4], di[4];
+      uint32_t bad[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+         at[k] = i - k > 0 ? i - k : 0;                          // (steps below 0: step 0's reads again, not looked at)
+         br[k] = P.bridge[at[k]];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+         const int ci = mm_tile_elem(tile, q + at[k], S, be);
+         const int pi = mm_tile_elem(tile, q + at[k] + br[k], S, be);
+         di[k] = ci - pi;
+         bad[k] = (uint32_t)(di[k] ^ P.expected[at[k]]) & P.cmp_mask[at[k]];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+         if (i - k >= 0 && bad[k] != 0) {
+            const int s = mm_tile_skip(a, P, di[k]);
+            const int w = P.wst[at[k]];
+            const int J = s < w ? s : w;
+            return J < 1 ? 1 : J;
+         }
+      }
+   }
+   for (; i >= 0; --i) {
       const int ci = mm_tile_elem(tile, q + i, S, be);
       const int pi = mm_tile_elem(tile, q + i + P.bridge[i], S, be);
       const int di = ci - pi;
@@ -172,8 +229,10 @@ __device__ __forceinline__ void mm_fwd_jumps(const MmForwardArgs &a, const MmPla
       *shift = 0;
       return;
    }
+   MM_PROF(0);
    const int mis = mm_stage_tile(a.t, W, start, lo, npos, lane);
    mm_wave_sync();
+   MM_PROF(2);
    const uint8_t *tile = reinterpret_cast<const uint8_t *>(W.tile) + mis;
    // position p compares LDS byte p + base with the byte g1 in front of it; LDS dword b4 + u holds
    // the compared bytes of slots 4u .. 4u + 3 (positions 4u - r + k)
@@ -182,8 +241,15 @@ __device__ __forceinline__ void mm_fwd_jumps(const MmForwardArgs &a, const MmPla
    const int ndw = (npos + r + 3) >> 2;
    uint32_t *jump32 = reinterpret_cast<uint32_t *>(W.jump);
    const uint32_t sh1 = 32u - 8u * a.g1;
-   bool m = false;
-   for (int u = lane; u < ndw; u += 64) {
+   // Pass 1: the table jump of every position; the positions whose first compare holds (1/256 of random ones) are only
+   // noted, a bit per position in `hits` (a lane owns at most 8 dwords = 32 positions of a tile).  Pass 2: every lane works
+   // off its own hits -- all lanes at once.  (Until round 6 a hit was resolved inside pass 1, the other 63 lanes waiting:
+   // two thirds of the steps have a hit somewhere, and its second lookup and compare loop -- LDS round trips, one after the
+   // other -- were paid eight times a tile instead of once or twice.)
+   static_assert((MM_FWD_TILE + 3 + 3) / 4 <= 8 * 64, "a lane's hits of one tile fit 32 bits");
+   uint32_t hits = 0;
+   int round = 0;
+   for (int u = lane; u < ndw; u += 64, round++) {
       const int mdw = b4 + u;
       const uint32_t w = W.tile[mdw];
       const uint32_t wp = W.tile[mdw - 1];                     // (mdw = 0: the pad dword in front of the tile; only positions < 0 use it)
@@ -196,36 +262,39 @@ __device__ __forceinline__ void mm_fwd_jumps(const MmForwardArgs &a, const MmPla
       }
       // Dword 0 may start up to three positions in front of the tile and the last one may end behind
       // it: their jumps are computed like the others (from whatever bytes are there) and never read.
-      const int p0 = 4 * u - r;
-      uint32_t on = jj & 0x80808080u;                         // first compare holds: 1/256 of the positions
-      if (__ballot(on != 0) != 0) {
-         while (on) {
-            const int k = (__ffs((int)on) - 1) >> 3;
-            on &= on - 1;
-            const int q = p0 + k;
-            int J = 1;
-            if (q >= 0 && q < npos) {
-               if (a.has2) {
-                  const int c2 = tile[q + (int)a.i2], p2 = tile[q + (int)a.i2 - (int)a.g2];
-                  J = T.jump2[c2 - p2 + 255];
-                  if (J & MM_JUMP_MATCH) {
-                     J = mm_deep_jump(a.t, P, tile, q, (int)a.i2 - 1);
-                  }
-               }
-               else {
-                  J = mm_deep_jump(a.t, P, tile, q, (int)a.i1 - 1);
+      const uint32_t on = (jj >> 7) & 0x01010101u;            // first compare holds
+      hits |= ((on * 0x10204080u) >> 28) << (4 * round);      // (bit 8 k -> bit 28 + k: no two products meet)
+      jump32[u + (u >> 3)] = jj;                               // 8 dwords = one group of 32 slots, groups 9 dwords apart
+   }
+   bool m = false;
+   if (__ballot(hits != 0) != 0) {
+      while (hits) {
+         const int bit = __ffs((int)hits) - 1;
+         hits &= hits - 1;
+         const int u = lane + 64 * (bit >> 2), k = bit & 3;
+         const int q = 4 * u - r + k;
+         int J = 1;
+         if (q >= 0 && q < npos) {
+            if (a.has2) {
+               const int c2 = tile[q + (int)a.i2], p2 = tile[q + (int)a.i2 - (int)a.g2];
+               J = T.jump2[c2 - p2 + 255];
+               if (J & MM_JUMP_MATCH) {
+                  J = mm_deep_jump(a.t, P, tile, q, (int)a.i2 - 1);
                }
             }
-            jj = (jj & ~(0xFFu << (8 * k))) | ((uint32_t)J << (8 * k));
+            else {
+               J = mm_deep_jump(a.t, P, tile, q, (int)a.i1 - 1);
+            }
          }
+         m = m || (J & MM_JUMP_MATCH) != 0;
+         W.jump[4 * (u + (u >> 3)) + k] = (uint8_t)J;          // (the lane's own dword, stored above)
       }
-      m = m || (jj & 0x80808080u) != 0;
-      jump32[u + (u >> 3)] = jj;                               // 8 dwords = one group of 32 slots, groups 9 dwords apart
    }
    *any_match = __ballot(m) != 0;
    *tile_out = tile;
    *shift = r;
    mm_wave_sync();
+   MM_PROF(3);
 }
 
 // x mod D for x < 2^16, any D <= 127 (mm_modd's 16-bit reciprocal is only exact for small D)
@@ -279,6 +348,7 @@ __device__ __forceinline__ uint8_t *mm_fwd_exit_tables(WL &W, int nq, int lane)
       Xg[k] = (uint8_t)x;
    }
    mm_wave_sync();
+   MM_PROF(4);
    return X;
 }
 
@@ -342,6 +412,7 @@ __device__ __forceinline__ void mm_fwd_map(const MmTileArgs &a, WL &W, uint8_t (
       }
    }
    mm_wave_sync();
+   MM_PROF(5);
 }
 
 __device__ __forceinline__ void mm_fwd_domain(const MmForwardArgs &a, uint64_t dom, uint64_t *start, int64_t *nv)
@@ -355,42 +426,144 @@ __device__ __forceinline__ void mm_fwd_domain(const MmForwardArgs &a, uint64_t d
    *nv = mm_domain_nv(a.t.g, b, p);
 }
 
-// the matches on the chain inside one tile, given the phase in which the chain enters it
+// mm_fwd_emit's super-group tables: keywords of up to MM_FWD_SXW - 2 symbols (D + 3 entry offsets per super-group)
+constexpr int MM_FWD_SXW = 16;
+struct MmFwdEmitLds {
+   uint8_t sx[MM_TILE / 256][MM_FWD_SXW];   // [s][e]: the chain e slots behind the start of super-group s (8 groups) -> behind its end
+   uint8_t sentry[MM_TILE / 256];           // how far behind the start of super-group s the true chain enters it
+};
+
+// the matches on the chain inside one tile, given the phase in which the chain enters it; returns the phase in which it
+// leaves the tile (what the tile's map would say of `entry`)
 template <class WL>
-__device__ __forceinline__ void mm_fwd_emit(const MmForwardArgs &a, WL &W, int shift, uint64_t start, int64_t lo, int npos,
-                                            uint32_t entry, int lane)
+__device__ __forceinline__ uint32_t mm_fwd_emit(const MmForwardArgs &a, WL &W, MmFwdEmitLds &E, int shift, uint64_t start, int64_t lo, int npos,
+                                                uint32_t entry, int lane)
 {
    const uint32_t D = a.t.plan.L - 1;
    const uint32_t list = blockIdx.x & (MM_CAND_LISTS - 1);
    const uint32_t lo_mod = mm_modd64(a.t, (uint64_t)lo);
    const int nq = npos + shift;
    const int ngroups = (nq + 31) >> 5;
-   const uint8_t *X = mm_fwd_exit_tables(W, nq, lane);
-   if (lane == 0) {
-      uint32_t off = entry + D - lo_mod;                         // first position >= 0 in phase `entry` ...
-      off = (off >= D ? off - D : off) + (uint32_t)shift;        // ... as a slot
-      for (int g = 0; g < ngroups; g++) {
-         W.gentry[g] = (uint8_t)(off < 255 ? off : 255);         // (>= 32: the chain jumps over the group)
-         off = mm_fwd_through_group(X, nq, g, off);
-      }
-   }
-   mm_wave_sync();
-   // lane g walks group g and notes the visited slots where the compare loop matched: found[32 g ...], as
-   // offsets inside the group -- over the exit tables, which have served their purpose
-   uint8_t *found = reinterpret_cast<uint8_t *>(W.tile);
    const uint32_t first = 32u * (uint32_t)lane;
-   uint32_t q = first + W.gentry[lane < ngroups ? lane : 0];
-   mm_wave_sync();
+   const uint32_t end = first + 32 < (uint32_t)nq ? first + 32 : (uint32_t)nq;
+   uint8_t *found = reinterpret_cast<uint8_t *>(W.tile);      // lane g's finds: found[32 g ...], offsets inside the group
    int nfound = 0;
-   if (lane < ngroups) {
-      const uint32_t end = first + 32 < (uint32_t)nq ? first + 32 : (uint32_t)nq;
-      while (q < end) {
-         const uint32_t j = W.jump[MM_FWD_AT(q)];
-         if (j & MM_JUMP_MATCH) {
-            found[first + nfound++] = (uint8_t)(q - first);
+   uint32_t beyond = 0;                                          // how far behind the tile's end the chain leaves it
+   if (D == 1) {
+      // Two-symbol keywords: every jump is 1, every position is on the chain -- no exit tables, no threading: the finds are
+      // the slots that carry the flag, eight dwords of jumps per lane.  (Round 6: a two-symbol keyword floods any ROM, and
+      // threading one phase through 64 groups was a third of its tiles' time.)
+      mm_wave_sync();                                            // (the staged bytes are about to become `found`)
+      const uint32_t *jw = reinterpret_cast<const uint32_t *>(W.jump) + 9 * lane;
+#pragma unroll 1
+      for (int i = 0; i < 8; i++) {
+         uint32_t m = jw[i] & 0x80808080u;
+         while (m) {
+            const uint32_t q = first + 4u * i + ((uint32_t)(__ffs((int)m) - 1) >> 3);
+            m &= m - 1;
+            if (q >= (uint32_t)shift && q < end) {
+               found[first + nfound++] = (uint8_t)(q - first);
+            }
          }
-         q += j & (MM_JUMP_MATCH - 1);
       }
+      MM_PROF(9);
+   }
+   else {
+      const uint8_t *X = mm_fwd_exit_tables(W, nq, lane);
+      uint32_t off0 = entry + D - lo_mod;                        // first position >= 0 in phase `entry` ...
+      off0 = (off0 >= D ? off0 - D : off0) + (uint32_t)shift;    // ... as a slot
+      const uint32_t width = D + 3;
+      uint32_t q = end;                                          // where lane g's walk of group g starts
+      if (width <= (uint32_t)MM_FWD_SXW) {
+         // One phase through 64 groups is 64 dependent LDS reads on one lane (round 6: a fifth of a flooded tile's time).
+         // As mm_fwd_map does it: every entry offset through the 8 groups of every super-group at once (8 x (D + 3) tasks),
+         // lane 0 through the 8 super-groups, then lane g from its super-group's start to its group: 8 + 8 + 7 reads.
+         const int nsuper = (ngroups + 7) >> 3;
+         const uint32_t ntasks = (uint32_t)nsuper * width;
+         for (uint32_t task = (uint32_t)lane; task < ntasks; task += 64) {
+            uint32_t sg = 0, off = task;
+            while (off >= width) {
+               off -= width;
+               sg++;
+            }
+            const uint32_t e = off;
+            const int g1 = 8 * (int)sg + 8 < ngroups ? 8 * (int)sg + 8 : ngroups;
+            for (int g = 8 * (int)sg; g < g1; g++) {
+               off = mm_fwd_through_group(X, nq, g, off);
+            }
+            E.sx[sg][e] = (uint8_t)off;
+         }
+         mm_wave_sync();
+         if (lane == 0) {
+            uint32_t off = off0;
+            for (int sg = 0; sg < nsuper; sg++) {
+               E.sentry[sg] = (uint8_t)off;
+               const uint32_t len = (uint32_t)(nq - 256 * sg < 256 ? nq - 256 * sg : 256);
+               off = off < len ? E.sx[sg][off] : off - len;      // (off < D + 3: inside a full super-group)
+            }
+            beyond = off;
+         }
+         mm_wave_sync();
+         if (lane < ngroups) {
+            uint32_t off = E.sentry[lane >> 3];
+            for (int g = lane & ~7; g < lane; g++) {
+               off = mm_fwd_through_group(X, nq, g, off);
+            }
+            q = first + off;                                     // (off >= 32: the chain jumps over the group)
+         }
+      }
+      else {
+         if (lane == 0) {
+            uint32_t off = off0;
+            for (int g = 0; g < ngroups; g++) {
+               W.gentry[g] = (uint8_t)(off < 255 ? off : 255);   // (>= 32: the chain jumps over the group)
+               off = mm_fwd_through_group(X, nq, g, off);
+            }
+            beyond = off;
+         }
+         mm_wave_sync();
+         q = first + W.gentry[lane < ngroups ? lane : 0];
+      }
+      beyond = (uint32_t)__builtin_amdgcn_readfirstlane((int)beyond);
+      mm_wave_sync();
+      MM_PROF(8);
+      // lane g walks group g and notes the visited slots where the compare loop matched -- over the exit tables, which have
+      // served their purpose
+      if (D <= 8) {
+         // Short keywords: a walk of 32 / (mean jump) dependent LDS reads -- 10 to 30 of them.  Instead the group's 32 jumps
+         // from 8 dwords, and the set of visited slots as a bit mask, slot by slot in registers: slot k is visited when an
+         // earlier visited slot jumps onto it (bit k + J <= 31 + 8).  No read depends on another, no lane on its data.
+         const uint32_t *jw = reinterpret_cast<const uint32_t *>(W.jump) + 9 * lane;
+         uint32_t jd[8];
+#pragma unroll
+         for (int i = 0; i < 8; i++) {
+            jd[i] = jw[i];
+         }
+         unsigned long long visited = lane < ngroups && q - first < 32u ? 1ull << (q - first) : 0ull;
+         uint32_t matching = 0;
+#pragma unroll
+         for (int k = 0; k < 32; k++) {
+            const uint32_t j = (jd[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+            matching |= (j >> 7) << k;
+            visited |= ((visited >> k) & 1ull) << (k + (j & 15u));   // (jumps <= D <= 8)
+         }
+         uint32_t mine = (uint32_t)visited & matching;
+         mine &= end > first ? (end - first >= 32u ? 0xFFFFFFFFu : (1u << (end - first)) - 1u) : 0u;
+         while (mine) {
+            found[first + nfound++] = (uint8_t)(__ffs((int)mine) - 1);
+            mine &= mine - 1;
+         }
+      }
+      else if (lane < ngroups) {
+         while (q < end) {
+            const uint32_t j = W.jump[MM_FWD_AT(q)];
+            if (j & MM_JUMP_MATCH) {
+               found[first + nfound++] = (uint8_t)(q - first);
+            }
+            q += j & (MM_JUMP_MATCH - 1);
+         }
+      }
+      MM_PROF(9);
    }
    // one atomic per tile reserves the output range; lanes copy their finds in group order
    int incl = nfound;
@@ -415,6 +588,9 @@ __device__ __forceinline__ void mm_fwd_emit(const MmForwardArgs &a, WL &W, int s
       }
    }
    mm_wave_sync();
+   MM_PROF(10);
+   const uint32_t ph = mm_fwd_modd(a.t, lo_mod + (uint32_t)npos) + beyond;   // (as mm_fwd_map ends)
+   return ph >= D ? ph - D : ph;
 }
 
 // The loud tiles among tiles [t0, t0 + ntiles) of the domain (positions [t0 TILE, lo1)): bit k set when a position of tile t0 + k
@@ -715,6 +891,7 @@ __global__ __launch_bounds__(64 * MM_WAVES) __attribute__((amdgpu_waves_per_eu(E
    __shared__ uint8_t lookback[MM_WAVES][MAXD];
    __shared__ uint8_t lookback2[MM_WAVES][MAXD];      // the sweep's second composition (lookback: its first)
    __shared__ uint8_t centry[MM_WAVES][MM_FWD_BATCH]; // ... and the entry phases it finds
+   __shared__ MmFwdEmitLds emit_lds[MM_WAVES];
    // (the super-group tables of mm_fwd_map overlay the tile's jumps: those have served their purpose once the exit
    // tables exist, and the 1.3 KiB this saves is what keeps six workgroups on a CU)
    static_assert(sizeof(uint8_t[MM_TILE / 256 + 1][MAXD + 4]) <= sizeof(WL::jump), "super-group tables overlay the jumps");
@@ -747,6 +924,14 @@ __global__ __launch_bounds__(64 * MM_WAVES) __attribute__((amdgpu_waves_per_eu(E
       q_ready[0] = q_ready[1] = 0;
       q_readers[0] = q_readers[1] = 0;
    }
+#ifdef MM_FWD_PROFILE
+   if (threadIdx.x < 16 * MM_WAVES) {
+      mm_prof[threadIdx.x >> 4][threadIdx.x & 15] = 0;
+   }
+   if ((threadIdx.x & 63) == 0) {
+      mm_prof_t[threadIdx.x >> 6] = __builtin_readcyclecounter();
+   }
+#endif
    __syncthreads();
    for (;;) {
       unsigned long long mine = 0;
@@ -775,6 +960,7 @@ __global__ __launch_bounds__(64 * MM_WAVES) __attribute__((amdgpu_waves_per_eu(E
       if (item >= nbatches) {
          break;
       }
+      MM_PROF(11);
       const uint64_t dom = item / a.bpd;
       const uint32_t b = (uint32_t)(item % a.bpd);
       uint64_t start; int64_t nv;
@@ -811,6 +997,7 @@ __global__ __launch_bounds__(64 * MM_WAVES) __attribute__((amdgpu_waves_per_eu(E
                         : (int)t0 - 1;
       bool sweep = (a.loud != nullptr || (ELEM == 1 && a.loud_shape != 0)) && tl >= (int)t0;
       uint32_t loud = 0;
+      MM_PROF(0);
       if (ELEM == 1 && sweep && a.loud == nullptr) {
          const int64_t lo1 = (int64_t)(tl + 1) * MM_FWD_TILE;
          loud = mm_fwd_loud_mask(a, start, (int64_t)t0 * MM_FWD_TILE, lo1 < nv ? lo1 : nv, lane);
@@ -930,6 +1117,35 @@ __global__ __launch_bounds__(64 * MM_WAVES) __attribute__((amdgpu_waves_per_eu(E
          have |= quiet;
          mm_wave_sync();
       }
+      // WALK (round 6).  A batch most of whose tiles are loud (short keywords: two or three symbols match somewhere in every
+      // tile; planted floods) gains nothing from the sweep's second question: every tile is the target in turn, every tile
+      // gets mapped AND walked -- jumps and exit tables twice.  Such a batch only sweeps for its exit phase (the last one to
+      // four tiles), takes its entry phase from the look-back -- the batches in front publish theirs as early -- and walks
+      // its tiles bottom up with the phase in hand: mm_fwd_emit says where the chain leaves a tile.  No maps but the
+      // sweep's few.  (Chains that do not merge -- padding under a keyword of equal symbols -- never settle the exit
+      // phase: the sweep arrives at the first tile still asking and the batch is filled as before.)
+      MM_PROF(1);
+      const bool walk = sweep && loud != 0 && 2 * __popc(loud) >= 32 - __clz((int)loud);
+      if (walk) {
+         flagged = loud;
+      }
+      if (D == 1 && sweep) {
+         // Two-symbol keywords: ONE phase.  The batch's exit phase and every tile's entry phase are known without a map or a
+         // look-back; the loud tiles are walked, the others not even staged.
+         if (lane == 0) {
+            __hip_atomic_store(a.status + item, MM_FWD_INCLUSIVE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+         }
+         for (uint32_t rest = loud; rest; rest &= rest - 1) {
+            const int64_t lo = (int64_t)(t0 + (uint32_t)__ffs((int)rest) - 1u) * MM_FWD_TILE;
+            const int npos = (int)(nv - lo < MM_FWD_TILE ? nv - lo : MM_FWD_TILE);
+            bool any = false;
+            const uint8_t *tile;
+            int shift;
+            mm_fwd_jumps(a, P, T, W, start, lo, npos, lane, &any, &tile, &shift);
+            mm_fwd_emit(a, W, emit_lds[wave], shift, start, lo, npos, 0u, lane);
+         }
+         continue;
+      }
       bool need_ex = sweep, need_tg = false;
       uint32_t target = 0;
       uint8_t *ex = lookback[wave], *tg = lookback2[wave];
@@ -957,7 +1173,7 @@ __global__ __launch_bounds__(64 * MM_WAVES) __attribute__((amdgpu_waves_per_eu(E
             if (!need_ex && !need_tg) {
                // nothing asks for maps: on to the next loud tile down
                const uint32_t below = loud & ((2u << (t - (int)t0)) - 1u);
-               if (below == 0) {
+               if (below == 0 || walk) {
                   break;
                }
                t = (int)t0 + 31 - __clz((int)below);
@@ -1040,7 +1256,7 @@ __global__ __launch_bounds__(64 * MM_WAVES) __attribute__((amdgpu_waves_per_eu(E
          }
          if (any) {
             flagged |= 1u << (t - (int)t0);
-            if (sweep) {
+            if (sweep && !walk) {
                // the lowest tile that reports so far: the ones above get their entry phases through the maps in between
                // (all made: the question never went away)
                target = (uint32_t)t;
@@ -1057,6 +1273,7 @@ __global__ __launch_bounds__(64 * MM_WAVES) __attribute__((amdgpu_waves_per_eu(E
          t += sweep ? -1 : 1;
       }
       const bool swept = sweep;
+      MM_PROF(6);
       uint32_t entry = 0;                           // first batch of a domain: the chain starts at its first position
       if (!swept) {
       // (tiles past the domain's end: identity)
@@ -1109,6 +1326,7 @@ __global__ __launch_bounds__(64 * MM_WAVES) __attribute__((amdgpu_waves_per_eu(E
             __hip_atomic_store(a.status + item, MM_FWD_AGGREGATE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
          }
       }
+      MM_PROF(12);
       if (b != 0 && (flagged != 0 || !constant)) {
          // decoupled look-back: f[e] = the phase at OUR entry when the chain enters batch k+1 in phase e
          // (kept in LDS: composing it with a batch's map is one lookup per phase)
@@ -1153,6 +1371,7 @@ __global__ __launch_bounds__(64 * MM_WAVES) __attribute__((amdgpu_waves_per_eu(E
          }
          entry = mm_uniform(entry);
       }
+      MM_PROF(7);
       if (b != 0 && !constant) {
          // now that the entry is known, tell the batches behind us where the chain leaves this one
          uint32_t ph = entry;
@@ -1164,6 +1383,28 @@ __global__ __launch_bounds__(64 * MM_WAVES) __attribute__((amdgpu_waves_per_eu(E
                                __HIP_MEMORY_SCOPE_AGENT);
          }
       }
+      }
+      if (swept && walk) {
+         // ---- the walk: entry phase from the batches in front, then tile by tile up to the last loud one
+         MM_PROF(6);
+         uint32_t ph = b != 0 ? mm_fwd_lookback<NH, MAXD>(a, item, lane, lookback[wave]) : 0u;
+         MM_PROF(7);
+         const int last = (int)t0 + 31 - __clz((int)loud);
+         for (int t = (int)t0; t <= last; t++) {
+            const uint32_t bit = 1u << (t - (int)t0);
+            if ((loud & bit) == 0 && (have & bit) != 0) {
+               ph = tilemap[wave][t - (int)t0][ph];           // (a quiet tile the sweep mapped)
+               continue;
+            }
+            const int64_t lo = (int64_t)t * MM_FWD_TILE;
+            const int npos = (int)(nv - lo < MM_FWD_TILE ? nv - lo : MM_FWD_TILE);
+            bool any = false;
+            const uint8_t *tile;
+            int shift;
+            mm_fwd_jumps(a, P, T, W, start, lo, npos, lane, &any, &tile, &shift);
+            ph = mm_fwd_emit(a, W, emit_lds[wave], shift, start, lo, npos, ph, lane);   // (a quiet tile: nothing to report, the phase moves on)
+         }
+         continue;
       }
       // ---- pass 2 (rare): the tiles to report from, walked with their true entry phase: the batch's entry phase
       // carried through every tile's map (filled batches), or what the sweep found (centry) carried on through the
@@ -1184,7 +1425,7 @@ __global__ __launch_bounds__(64 * MM_WAVES) __attribute__((amdgpu_waves_per_eu(E
                const uint8_t *tile;
                int shift;
                mm_fwd_jumps(a, P, T, W, start, lo, npos, lane, &any, &tile, &shift);
-               mm_fwd_emit(a, W, shift, start, lo, npos, ph, lane);
+               mm_fwd_emit(a, W, emit_lds[wave], shift, start, lo, npos, ph, lane);
             }
             ph_known = ph_known && (have & bit) != 0;
             if (ph_known) {
@@ -1193,6 +1434,15 @@ __global__ __launch_bounds__(64 * MM_WAVES) __attribute__((amdgpu_waves_per_eu(E
          }
       }
    }
+#ifdef MM_FWD_PROFILE
+   if (threadIdx.x == 0 && blockIdx.x % 389 == 0) {
+      MM_PROF(11);
+      const unsigned long long *q = mm_prof[0];
+      printf("mm_forward wg %4u wave 0, kilocycles: other %llu  loud %llu  stage %llu  jumps %llu  exit-tables %llu  map %llu  sweep %llu  look-back %llu  "
+             "emit: thread %llu  walk %llu  output %llu | ticket %llu  fill/publish %llu\n", blockIdx.x, q[0] >> 10, q[1] >> 10, q[2] >> 10, q[3] >> 10,
+             q[4] >> 10, q[5] >> 10, q[6] >> 10, q[7] >> 10, q[8] >> 10, q[9] >> 10, q[10] >> 10, q[11] >> 10, q[12] >> 10);
+   }
+#endif
 }
 
 #endif

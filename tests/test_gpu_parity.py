@@ -797,3 +797,51 @@ def test_forward_engine_sweep_on_mixed_roms(mm, gpu_engine, oracle, seed):
             assert gpu_engine.scan(plan, cap=1 << 21).tolist() == oracle.search(oplan, data).tolist(), (seed, kw, "whole")
     finally:
         gpu_engine.set_engine(0)
+
+
+LOUD_CASES = [(1, "qz", 0, False, 0), (1, "q*", ord("*"), False, 0), (1, "q*v", ord("*"), False, 0), (1, "abc", 0, False, 0),
+              (1, "qzvk", 0, False, 300), (1, "relativesrch", 0, False, 250), (1, "re*ative*ear*hxy", ord("*"), False, 250),
+              (1, "a keyword of twenty-two", 0, False, 300), (1, "k" * 40, 0, False, 500),
+              (2, "qz", 0, False, 700), (2, "q*v", ord("*"), True, 0), (2, "te*ts*h", ord("*"), False, 300)]
+
+
+@pytest.mark.parametrize("elem,kw,wc,be,every", LOUD_CASES, ids=["%d-%s-%d" % (c[0], c[1][:12], c[4]) for c in LOUD_CASES])
+def test_forward_engine_on_loud_batches(mm, gpu_engine, oracle, elem, kw, wc, be, every):
+    """The forward engine forced on ROMs where most tiles of a batch have something to report (csrc/mm_forward.h, round 6):
+    two-symbol keywords (one phase: no maps, no look-back, the finds straight off the flags), three-symbol wildcard keywords
+    (chains merge: the batch sweeps for its exit phase only and WALKS its tiles with the entry phase from the look-back;
+    the walk on a bit mask in registers), 'abc' (chains never merge: sweep -> fill), keywords planted every `every`
+    elements (the walk with super-group tables, with the one-lane threading beyond 13 phases, with wide maps beyond 32),
+    16-bit keywords on the bitmap pre-pass -- blocks of 512 KiB, 8191 bytes and one chain over the whole buffer, a ragged
+    end, against the oracle."""
+    rng = np.random.default_rng(4242 + len(kw) + 7 * elem + every)
+    hi = 256 if elem == 1 else 65536
+    n = (6 << 20) // elem + int(rng.integers(1, 3000))
+    d = rng.integers(0, hi, n).astype(np.int64)
+    vals = [None if (wc and ord(c) == wc) else ord(c) for c in kw]
+    lits = [v for v in vals if v is not None]
+    if every:
+        for pos in range(int(rng.integers(0, every)), n - len(kw), every):
+            pos += int(rng.integers(0, every // 2))
+            sh = int(rng.integers(-min(lits), hi - max(lits)))
+            for j, v in enumerate(vals):
+                if v is not None and pos + j < n:
+                    d[pos + j] = v + sh
+    quiet = int(rng.integers(0, n - 400000))
+    d[quiet:quiet + 300000] = rng.integers(0, hi, 300000) & ~1 if len(lits) < 4 else d[quiet:quiet + 300000]   # (a stretch with fewer hits)
+    rom = d.astype(np.uint8 if elem == 1 else (">u2" if be else "<u2")).view(np.uint8)
+    gpu_engine.upload(rom)
+    plan, oplan = mm.plan_relative(elem, kw, wc), oracle.plan(elem, kw, wc)
+    gpu_engine.set_engine(2)
+    try:
+        for block in (524288, 8191):
+            got = gpu_engine.scan(plan, block_bytes=block, big_endian=be, cap=1 << 23)
+            assert gpu_engine.counters()["path"] == 3
+            want = oracle.engine(oplan, rom, block, be)
+            assert got.size == want.size and np.array_equal(got, want), (kw, block, got.size, want.size)
+        if not be:
+            data = rom if elem == 1 else rom[: (rom.size // 2) * 2].view("<u2")
+            got, want = gpu_engine.scan(plan, cap=1 << 23), oracle.search(oplan, data)
+            assert got.size == want.size and np.array_equal(got, want), (kw, "whole", got.size, want.size)
+    finally:
+        gpu_engine.set_engine(0)

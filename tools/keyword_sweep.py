@@ -2,7 +2,8 @@
 """Dev probe (round 5): what a synchronous mmh_scan costs over KEYWORD CLASSES on one 4 GiB ROM (C2's recipe: random bytes,
 a planted match per MiB, 1 MiB runs of 0x00 / 0xFF / a ramp) -- lengths 2 .. 128, wildcards in every place, 8- and 16-bit:
 where the cliffs are (few conditions -> candidate floods -> flood paths / forward engine).
-    python tools/keyword_sweep.py        -> profiles/r06_keyword_sweep.log"""
+    python tools/keyword_sweep.py        -> profiles/r06_keyword_sweep.log
+    [MMOORE_TRACE=split] python tools/keyword_sweep.py aaaa 'ab*de' 2:qz     only these (N: = N-byte elements; trace: what the scan's stages did)"""
 import os
 import sys
 import time
@@ -23,6 +24,8 @@ CASES = [(1, "relativesrch"), (1, "qz"), (1, "qzv"), (1, "qzvk"), (1, "qzvkm"), 
          (1, "Qzvkm"), (1, "qzvkmbxwqzvkmbxwqzvkmbxwqzvkmbxwq"),
          (1, "q" * 2 + "zvkmbxw" * 9), (1, "zvkmbxw" * 18), (1, "aaaa"), (1, "abcd"),
          (2, "qz"), (2, "qzv"), (2, "qzvk"), (2, "textsrch"), (2, "q*vk"), (2, "qz*k"), (2, "q*v*m"), (2, "q**k"), (2, "qz**mb"), (2, "q***k**x")]
+if len(sys.argv) > 1:
+    CASES = [(int(a[0]), a[2:]) if a[1:2] == ":" and a[0] in "12" else (1, a) for a in sys.argv[1:]]
 print("# synchronous mmh_scan over keyword classes: 4 GiB (C2's ROM), 512 KiB blocks; wall ms = median of 5 after 2 warm-up scans")
 for elem, kw in CASES:
     wc = ord("*") if "*" in kw else 0
