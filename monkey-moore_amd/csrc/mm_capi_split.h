@@ -246,6 +246,16 @@ int scan_split(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int 
          rc = scan_rest(pg.done_blocks, nblocks, false);
          break;
       }
+      if (flood[1] == 0 && floods == 0) {
+         // The first part to flood has more candidates than a scan keeps, and no bucket of it overflowed: they lie all over
+         // the part -- a two-symbol keyword, `q*v`: a candidate every 256 bytes of any ROM --, not in a run of padding.
+         // Narrower parts would hold as many per byte (and the per-candidate path costs 2.4 ms per million of them, the
+         // forward engine 0.7 - 1.9 ms per GiB whatever the data): the rest of the ROM on the forward engine, now.  (Until
+         // round 6: parts half as wide, the forward engine on two of them, then the rest -- 4 ms of a two-symbol scan.)
+         floods = 3;
+         rc = scan_rest(pg.done_blocks, nblocks, true);
+         break;
+      }
       if (flood[1] != 0 && flood[1] <= fine * block_bytes / 4) {
          // The tail kernel said WHERE the part floods (the overflowing buckets' extent: padding that matches the keyword
          // wholesale is a MiB or two of a ROM): the blocks in front of it on the candidate path, the forward engine on the
