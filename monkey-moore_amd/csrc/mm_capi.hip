@@ -711,9 +711,15 @@ int scan_impl(mmh_ctx *c, const mmh_plan_desc *plan, uint64_t block_bytes, int b
    }
    if (device_list) {
       // device -> the caller's buffer, no host list in between (a communicator may ask for the list later: then it is kept)
+      static const bool tracing = mm_trace("split");
+      const auto t_fetch = std::chrono::steady_clock::now();
       rc = fetch_device_list(c, c->d_sort_out, device_list_n, out, cap, &oc.matches);
       if (rc != MMH_OK) {
          return rc;
+      }
+      if (tracing) {
+         fprintf(stderr, "      %llu ordered slots -> %llu offsets in the caller's buffer: %.1f us (waiting for the sort included)\n", (unsigned long long)device_list_n,
+                 (unsigned long long)oc.matches, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_fetch).count() * 1e6);
       }
       if (c->mg.comm) {
          if (oc.matches <= cap) {

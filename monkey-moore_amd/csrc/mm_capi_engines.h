@@ -191,6 +191,9 @@ int run_dense(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, uint64_t bas
          return rc;
       }
    }
+   static const bool tracing = mm_trace("split");           // (with the stages of scan_split: where a forward-engine stage's time goes)
+   const auto t_start = std::chrono::steady_clock::now();
+   auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() * 1e6; };
    HIP_TRY(hipMemsetAsync(c->ws[0].d_ctrl, 0, mm::ctrl_bytes(), st));
    c->ws[0].ctrl_clean = false;
    begin_scan_events(c, false);
@@ -207,8 +210,13 @@ int run_dense(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, uint64_t bas
    HIP_TRY(hipGetLastError());
    std::vector<unsigned long long> ctrl(mm::ctrl_bytes() / sizeof(unsigned long long));
    HIP_TRY(hipMemcpyAsync(ctrl.data(), c->ws[0].d_ctrl, mm::ctrl_bytes(), hipMemcpyDeviceToHost, st));
+   const double t_enqueued = tracing ? since() : 0;
    HIP_TRY(hipStreamSynchronize(st));
    c->scans_recorded++;
+   if (tracing) {
+      fprintf(stderr, "      forward engine: %llu domains of %u tiles (batches of %u) enqueued in %.1f us, engine + packed lists + counters back after %.1f us\n",
+              (unsigned long long)dg.ndom, dg.tpd, dg.batch, t_enqueued, since());
+   }
 
    uint64_t most = 0, total = 0;
    for (int l = 0; l < MM_CAND_LISTS; l++) {
@@ -228,7 +236,11 @@ int run_dense(mmh_ctx *c, const MmGeom &g, const mmh_plan_desc &pl, uint64_t bas
    // order them the way search_engine.cpp:193-197 does -- on the device
    if (!found) {
       *device_n = total;
-      return total ? sort_on_device(c, c->d_sort_in, total) : MMH_OK;
+      const int rc = total ? sort_on_device(c, c->d_sort_in, total) : MMH_OK;
+      if (tracing) {
+         fprintf(stderr, "      forward engine: %llu offsets, their sort enqueued after %.1f us\n", (unsigned long long)total, since());
+      }
+      return rc;
    }
    return sort_to_host(c, c->d_sort_in, total, found);
 }
