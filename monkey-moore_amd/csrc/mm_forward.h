@@ -76,6 +76,7 @@ __shared__ unsigned long long mm_prof_t[MM_WAVES];
 template <int ELEM>
 struct MmFwdLds {
    static constexpr int kPositions = MM_TILE;
+   static constexpr int kElem = ELEM;
    uint32_t tile_pad[1];                     // tile[-1]: mm_fwd_jumps reads the dword in front of any tile dword unconditionally
    // Slots: position p of the tile is slot q = p + r (r = 0..3: the jumps of four positions are stored as one
    // dword, see mm_fwd_jumps); groups of 32 slots are 36 bytes apart (MM_FWD_AT) so that 64 lanes working
@@ -218,7 +219,7 @@ template <class WL>
 __device__ __forceinline__ void mm_fwd_jumps(const MmForwardArgs &a, const MmPlanLds &P, const MmFwdTables &T, WL &W, uint64_t start,
                                              int64_t lo, int npos, int lane, bool *any_match, const uint8_t **tile_out, int *shift)
 {
-   if (!a.fast) {
+   if (WL::kElem != 1 || !a.fast) {                  // (the table path is for 8-bit elements: the 16-bit kernels do not carry it)
       const uint8_t *tile = mm_tile_jumps(a.t, P, W, start, lo, npos, lane, true);
       bool m = false;
       for (int q = lane; q < npos; q += 64) {
@@ -267,6 +268,47 @@ __device__ __forceinline__ void mm_fwd_jumps(const MmForwardArgs &a, const MmPla
       jump32[u + (u >> 3)] = jj;                               // 8 dwords = one group of 32 slots, groups 9 dwords apart
    }
    bool m = false;
+   // Dwords ALL of whose four positions hit -- padding under a keyword of equal symbols, a ramp under `abcd`: every
+   // position, 32 a lane, each of them a handful of LDS round trips one after the other -- take the rest of the compare
+   // loop four positions at a time: per step the four compared bytes and their four partners as two (unaligned) dwords,
+   // the byte-wise difference against the step's expected one -- modular where the plan says so, exact (difference AND
+   // borrow: c - p == e  <=>  (c - p) mod 256 == e mod 256 and (c < p) == (e < 0)) where it says so.  Four matches: the
+   // dword's jumps are the match jump, done; anything else: the four go the way of all hits below.
+   if (__ballot((hits & (hits >> 1) & (hits >> 2) & (hits >> 3) & 0x11111111u) != 0) != 0) {
+      const uint32_t *t32 = W.tile;
+      for (int round = 0; 64 * round < ndw; round++) {
+         const int u = lane + 64 * round;
+         const int p0 = 4 * u - r;
+         bool dense = ((hits >> (4 * round)) & 15u) == 15u && p0 >= 0 && p0 + 3 < npos;
+         if (__ballot(dense) == 0) {
+            continue;
+         }
+         uint32_t holds = dense ? 0x80808080u : 0u;
+         for (int i = (int)a.i1 - 1; i >= 0 && __ballot(holds != 0) != 0; --i) {
+            const uint32_t mask = P.cmp_mask[i];
+            if (mask == 0) {
+               continue;                                       // (a wildcard's place: nothing is compared)
+            }
+            const int e = P.expected[i];
+            const int at = mis + (dense ? p0 : 0) + i, pat = at + P.bridge[i];
+            const uint32_t c = __builtin_amdgcn_alignbyte(t32[(at >> 2) + 1], t32[at >> 2], (uint32_t)at & 3u);
+            const uint32_t q = __builtin_amdgcn_alignbyte(t32[(pat >> 2) + 1], t32[pat >> 2], (uint32_t)pat & 3u);
+            const uint32_t x = mm_bytesub(c, q);
+            const uint32_t ne = x ^ (((uint32_t)e & 0xFFu) * 0x01010101u);
+            uint32_t ok = ~(((ne & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | ne) & 0x80808080u;      // bytes of ne that are zero, exactly
+            if (mask == 0xFFFFFFFFu) {
+               const uint32_t lt = ((~c & q) | (~(c ^ q) & x)) & 0x80808080u;            // borrow of c - q, byte by byte
+               ok &= e >= 0 ? ~lt : lt;
+            }
+            holds &= ok;
+         }
+         if (holds == 0x80808080u) {
+            jump32[u + (u >> 3)] = (a.t.plan.match_jump | (uint32_t)MM_JUMP_MATCH) * 0x01010101u;
+            hits &= ~(15u << (4 * round));
+            m = true;
+         }
+      }
+   }
    if (__ballot(hits != 0) != 0) {
       while (hits) {
          const int bit = __ffs((int)hits) - 1;

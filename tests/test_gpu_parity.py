@@ -845,3 +845,49 @@ def test_forward_engine_on_loud_batches(mm, gpu_engine, oracle, elem, kw, wc, be
             assert got.size == want.size and np.array_equal(got, want), (kw, "whole", got.size, want.size)
     finally:
         gpu_engine.set_engine(0)
+
+
+RUN_KEYWORDS = [("aaaa", 0), ("abcd", 0), ("dcba", 0), ("aceg", 0), ("aa", 0), ("abc", 0), ("a*a*a", ord("*")), ("ab*d", ord("*")), ("d*ba", ord("*")),
+                ("a" * 40, 0), ("abcdefghijklmnopqrstuvwxyz", 0)]
+
+
+@pytest.mark.parametrize("kw,wc", RUN_KEYWORDS, ids=[k[:8] + str(len(k)) for k, _ in RUN_KEYWORDS])
+def test_forward_engine_on_runs_and_ramps(mm, gpu_engine, oracle, kw, wc):
+    """Keywords that match padding and ramps wholesale, the forward engine forced and the library's own routing: runs of one
+    byte, ramps up and down and in steps of two -- modulo 256, so that a ramp's wrap (255 -> 0) separates the plain loop's
+    exact differences from the wildcard loop's modular ones -- from three bytes to hundreds of KiB long, at tile, batch and
+    block edges.  Every position of such a stretch passes the first compare: dwords whose four positions all hit take the
+    rest of the compare loop four at a time (csrc/mm_forward.h, mm_fwd_jumps), the others one by one; both against the
+    oracle, blocks of 512 KiB, 8191 bytes and one chain over the whole buffer."""
+    rng = np.random.default_rng(777 + len(kw) + wc)
+    n = (5 << 20) + int(rng.integers(1, 3000))
+    d = rng.integers(0, 256, n).astype(np.int64)
+    at = int(rng.integers(0, 5000))
+    kind = 0
+    while at < n - 700000:
+        ln = int(rng.choice([3, 4, 5, 7, 17, 40, 300, 2044, 2045, 5000, 40000, 600000], p=[.1, .1, .1, .1, .1, .1, .1, .05, .05, .1, .07, .03]))
+        base = int(rng.integers(0, 256))
+        if kind % 4 == 0:
+            d[at:at + ln] = base
+        elif kind % 4 == 1:
+            d[at:at + ln] = (base + np.arange(ln)) % 256
+        elif kind % 4 == 2:
+            d[at:at + ln] = (base - np.arange(ln)) % 256
+        else:
+            d[at:at + ln] = (base + 2 * np.arange(ln)) % 256
+        kind += 1
+        gap = int(rng.choice([0, 1, 2, 3, 50, 2044 - (at + ln) % 2044, 30000]))
+        at += ln + gap
+    rom = d.astype(np.uint8)
+    gpu_engine.upload(rom)
+    plan, oplan = mm.plan_relative(1, kw, wc), oracle.plan(1, kw, wc)
+    for engine in (2, 0):
+        gpu_engine.set_engine(engine)
+        try:
+            for block in (524288, 8191):
+                got, want = gpu_engine.scan(plan, block_bytes=block, cap=1 << 22), oracle.engine(oplan, rom, block, False)
+                assert got.size == want.size and np.array_equal(got, want), (kw, engine, block, got.size, want.size)
+            got, want = gpu_engine.scan(plan, cap=1 << 22), oracle.search(oplan, rom)
+            assert got.size == want.size and np.array_equal(got, want), (kw, engine, "whole", got.size, want.size)
+        finally:
+            gpu_engine.set_engine(0)
